@@ -1,0 +1,27 @@
+/* oracle/gst114.h — TEST INFRASTRUCTURE ONLY.  See gst114.c. */
+#ifndef GST114_ORACLE_H
+#define GST114_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+enum { GST114_BT601 = 0, GST114_BT709 = 1, GST114_BT2020 = 2 };
+enum { GST114_BGRA = 0, GST114_RGBA = 1 };
+enum { GST114_BILINEAR = 0, GST114_NEAREST = 1 };
+
+void gst114_yuv_to_rgb (int matrix, int Y, int U, int V, int *r, int *g, int *b);
+int gst114_yuv420_to_rgb (const uint8_t *yp, int ys, const uint8_t *up, int us, const uint8_t *vp, int vs,
+    int planar, int w, int h, int matrix, int cosited, int out_format, uint8_t *out, int os);
+void gst114_vtaps (int in_h, int out_h, int y, int *i0, int *i1, int *w);
+uint32_t gst114_hinc (int in_w, int out_w);
+int gst114_nearest_index (int in, int out, int j);
+int gst114_scale_4u8 (const uint8_t *in, int is, int w, int h, uint8_t *out, int os, int ow, int oh, int method);
+int gst114_default_matrix (int height);
+int gst114_default_cosited (int height);
+int gst114_convertscale_yuv420 (const uint8_t *yp, int ys, const uint8_t *up, int us, const uint8_t *vp, int vs,
+    int planar, int w, int h, int matrix, int cosited, int out_format, int method,
+    uint8_t *out, int os, int ow, int oh);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""tools/gen_goldens.py — regenerate tests/golden/*.npz from the REAL GStreamer 1.14.0 elements.
+
+Runs only in the build container (GStreamer 1.14.0 under /opt/conda); never on the
+GPU box.  It is the script that made the committed fixtures: every expected output below is what
+`videoconvert ! videoscale` (the oracle BASELINE.json's north_star names) produced for the stored
+input.  No reference (visioforge/gstreamer-metal) code is involved: that plugin cannot be built on
+Linux and its tests pin no pixel values.
+
+    python tools/gen_goldens.py            # rewrites tests/golden/convertscale_gst114*.npz
+"""
+import hashlib, json, os, subprocess, sys, tempfile
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+ENV = dict(os.environ)
+ENV.update(PATH="/opt/conda/bin:" + ENV["PATH"], GST_PLUGIN_SYSTEM_PATH="/opt/conda/lib/gstreamer-1.0",
+           GST_PLUGIN_SCANNER="/opt/conda/libexec/gstreamer-1.0/gst-plugin-scanner",
+           GST_REGISTRY="/tmp/gst-registry.bin", LD_LIBRARY_PATH="/opt/conda/lib")
+INC = ["-I/opt/conda/include/gstreamer-1.0", "-I/opt/conda/include/glib-2.0", "-I/opt/conda/lib/glib-2.0/include"]
+LIB = ["-L/opt/conda/lib", "-lgstreamer-1.0", "-lgobject-2.0", "-lglib-2.0", "-Wl,-rpath,/opt/conda/lib"]
+
+
+def build_helper(tmp):
+    exe = os.path.join(tmp, "gst114_run")
+    subprocess.check_call(["gcc", "-O1", "-o", exe, os.path.join(ROOT, "tools", "gst114_run.c")] + INC + LIB)
+    return exe
+
+
+def gst_run(exe, tmp, raw, frame_bytes, incaps, middle, outcaps):
+    i, o = os.path.join(tmp, "in.raw"), os.path.join(tmp, "out.raw")
+    with open(i, "wb") as f:
+        f.write(raw)
+    r = subprocess.run([exe, i, str(frame_bytes), incaps, middle, outcaps, o], env=ENV, capture_output=True, text=True)
+    if r.returncode:
+        raise RuntimeError(r.stderr)
+    with open(o, "rb") as f:
+        return f.read()
+
+
+def videotestsrc(tmp, fmt, w, h, pattern="smpte"):
+    o = os.path.join(tmp, "vts.raw")
+    cmd = (f"gst-launch-1.0 -q videotestsrc num-buffers=1 pattern={pattern} ! video/x-raw,format={fmt},width={w},height={h} "
+           f"! filesink location={o}")
+    subprocess.check_call(cmd, shell=True, env=ENV)
+    with open(o, "rb") as f:
+        return f.read()
+
+
+def r4(x):
+    return (x + 3) // 4 * 4
+
+
+def nv12_layout(w, h):
+    """GstVideoInfo default layout: strides rounded to 4, UV plane at stride*ROUND_UP_2(h)."""
+    ys = r4(w); hp = (h + 1) // 2 * 2
+    return ys, ys * hp, ys, ys * hp + ys * (hp // 2)          # ystride, uv offset, uvstride, size
+
+
+def i420_layout(w, h):
+    ys = r4(w); hp = (h + 1) // 2 * 2; cs = r4((w + 1) // 2)
+    uo = ys * hp; vo = uo + cs * (hp // 2)
+    return ys, uo, vo, cs, vo + cs * (hp // 2)
+
+
+def rand_frame(rng, fmt, w, h):
+    if fmt == "NV12":
+        ys, uo, us, size = nv12_layout(w, h)
+    else:
+        ys, uo, vo, cs, size = i420_layout(w, h)
+    return rng.integers(0, 256, size, dtype=np.uint8).tobytes()
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    cases, arrays = [], {}
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = build_helper(tmp)
+
+        def add(name, fmt, w, h, raw, col, site, method, ofmt, ow, oh):
+            caps = f"video/x-raw,format={fmt},width={w},height={h},framerate=1/1"
+            if col:
+                caps += f",colorimetry={col}"
+            if site:
+                caps += f",chroma-site={site}"
+            m = "nearest-neighbour" if method == "nearest" else "bilinear"
+            out = gst_run(exe, tmp, raw, len(raw), caps, f"videoconvert ! videoscale method={m}",
+                          f"video/x-raw,format={ofmt},width={ow},height={oh}")
+            assert len(out) == ow * oh * 4, (name, len(out))
+            arrays[name + "_in"] = np.frombuffer(raw, np.uint8)
+            arrays[name + "_out"] = np.frombuffer(out, np.uint8)
+            cases.append(dict(name=name, in_format=fmt, w=w, h=h, colorimetry=col, chroma_site=site, method=method,
+                              out_format=ofmt, ow=ow, oh=oh, in_sha256=hashlib.sha256(raw).hexdigest(),
+                              out_sha256=hashlib.sha256(out).hexdigest()))
+            print(name, cases[-1]["out_sha256"][:16])
+
+        # BASELINE configs 0 and 1: videotestsrc frame 0, caps carry no colorimetry -> GStreamer's by-height default
+        add("c1_vts_1080_to_640x480", "NV12", 1920, 1080, videotestsrc(tmp, "NV12", 1920, 1080), None, None, "bilinear", "BGRA", 640, 480)
+        add("c2_vts_2160_to_1080", "NV12", 3840, 2160, videotestsrc(tmp, "NV12", 3840, 2160), None, None, "bilinear", "BGRA", 1920, 1080)
+
+        rng = np.random.default_rng(20261004)
+        cols, sites = ["bt601", "bt709", "bt2020"], ["jpeg", "mpeg2"]
+        fixed = [(64, 36, 32, 18), (128, 72, 50, 30), (64, 36, 64, 36), (64, 36, 100, 50), (48, 40, 20, 37), (48, 40, 96, 38),
+                 (2, 2, 2, 2), (3, 3, 7, 5), (16, 16, 1, 1), (33, 17, 16, 8), (200, 8, 100, 4), (8, 200, 4, 100)]
+        t = 0
+        for fmt in ["NV12", "I420"]:
+            for (w, h, ow, oh) in fixed + [tuple(int(v) for v in rng.integers(2, 97, 4)) for _ in range(18)]:
+                col, site = cols[t % 3], sites[(t // 3) % 2]
+                method = "nearest" if t % 7 == 3 else "bilinear"
+                ofmt = "RGBA" if t % 5 == 1 else "BGRA"
+                add(f"{fmt.lower()}_{t:03d}_{w}x{h}_to_{ow}x{oh}", fmt, w, h, rand_frame(rng, fmt, w, h), col, site, method, ofmt, ow, oh)
+                t += 1
+    arrays["manifest"] = np.frombuffer(json.dumps(cases).encode(), np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "convertscale_gst114.npz"), **arrays)
+    print("wrote", len(cases), "cases")
+
+
+if __name__ == "__main__":
+    main()
