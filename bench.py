@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json headline: frames/s + achieved HBM GB/s, NV12 3840x2160 -> BGRA 1920x1080
+bilinear (config[1]) through libvfhip's C ABI, gst-exact numerics, on N GPUs of one node.
+
+A "step" is ONE batched launch of the hot-path kernel over a device-resident ring of `--frames`
+distinct synthetic frames (inputs already in HBM; the ring — in + out — is far larger than the 256 MiB
+Infinity Cache, so the traffic is real HBM traffic).  One process per GPU; frames/streams are
+independent, so ranks share nothing (no collective on the data path; torch.distributed is used only
+for the barrier and the max-over-ranks time) -> "scaling": "weak".
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md §measurement for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "gstreamer-metal_amd"))
+
+IN_W, IN_H, OUT_W, OUT_H = 3840, 2160, 1920, 1080
+ALG_BYTES_PER_FRAME = IN_W * IN_H * 3 // 2 + OUT_W * OUT_H * 4      # 20,736,000
+HBM_PEAK_GBS = 8000.0                                               # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The CPU oracle (bit-exact restatement of GStreamer 1.14 videoconvert+videoscale, OpenMP over the host
+    cores) timed on a bounded sample of the same workload.  Reported next to the GPU number; not the target."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib
+    orc = oracle_lib.load()
+    cores = os.cpu_count() or 1
+    rng = np.random.default_rng(0)
+    raw = rng.integers(0, 256, IN_W * IN_H * 3 // 2, dtype=np.uint8)
+    orc.convertscale("NV12", IN_W, IN_H, raw, "bt2020", "mpeg2", "bilinear", "BGRA", OUT_W, OUT_H)   # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        orc.convertscale("NV12", IN_W, IN_H, raw, "bt2020", "mpeg2", "bilinear", "BGRA", OUT_W, OUT_H)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or n >= 400:
+            break
+    return {"value": round(n / el, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} frames NV12 {IN_W}x{IN_H} -> BGRA {OUT_W}x{OUT_H}, oracle/gst114.c -O3 -march=native OpenMP x{cores}"}
+
+
+def load_traffic(frames):
+    """HBM bytes per launch from the committed PMC summary (separate rocprofv3 --pmc passes, corrected as
+    MI355X_MICROARCH.md §HBM prescribes), rescaled to this run's frames per launch; None if absent."""
+    p = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(p) as f:
+            t = json.load(f)
+        return round(t["hbm_bytes_per_frame"] * frames)
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=128, help="frames per launch (= ring size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import vfhip                                   # fails loudly when libvfhip.so is missing
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    F = args.frames
+    _, in_size = vfhip.plane_layout("NV12", IN_W, IN_H)
+    in_pitch = (in_size + 255) // 256 * 256
+    out_pitch = OUT_W * OUT_H * 4
+    g = torch.Generator(device="cuda").manual_seed(0x9E3779B9 ^ rank)
+    ring_in = torch.randint(0, 256, (F, in_pitch), dtype=torch.uint8, device="cuda", generator=g)   # synthetic, in HBM
+    ring_out = torch.empty((F, out_pitch), dtype=torch.uint8, device="cuda")
+
+    cs = vfhip.ConvertScale(local_rank)
+    cs.configure("NV12", IN_W, IN_H, "BGRA", OUT_W, OUT_H, method="bilinear", numerics="gst-exact",
+                 colorimetry="bt2020", chroma_site="mpeg2")          # GStreamer's default colorimetry at 2160 lines
+    kernel = cs.kernel_name
+    stream = torch.cuda.Stream()
+
+    def step():
+        cs.process_device(ring_in.data_ptr(), ring_out.data_ptr(), stream=stream.cuda_stream, n_frames=F,
+                          in_pitch=in_pitch, out_pitch=out_pitch)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)                      # HIP events on the stream the kernel is launched on
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0
+    fence()
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps          # average launch duration (back-to-back launches)
+
+    t = torch.tensor([t_local], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t_max = float(t.item())
+
+    if rank == 0:
+        fps = world * F * args.steps / t_max
+        achieved = ALG_BYTES_PER_FRAME * F / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "frames/sec + achieved HBM GB/s, NV12->BGRA 2160p->1080p",
+            "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(t_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "vfhipconvertscale NV12 3840x2160 -> BGRA 1920x1080 bilinear, gst-exact (BASELINE configs[1])",
+                       "frames_per_step": F, "kernel": kernel, "colorimetry": "bt2020/mpeg2", "parallelism": f"independent-streams x{world}",
+                       "device": vfhip.device_name(local_rank)},
+            "achieved_GBps_whole_job": round(fps * ALG_BYTES_PER_FRAME / 1e9, 1),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_traffic(F),
+                         "kernel": kernel, "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": ALG_BYTES_PER_FRAME * F},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    cs.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

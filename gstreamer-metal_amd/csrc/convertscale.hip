@@ -1,0 +1,286 @@
+// csrc/convertscale.hip — vfhip_convertscale_* : host side of the fused colourspace-convert + scale.
+// Mirrors MetalConvertScaleRenderer (reference convertscale/metalconvertscalerenderer.{h,m}):
+//   -init                               -> vfhip_convertscale_new
+//   -configureWithInputInfo:...         -> vfhip_convertscale_configure   (:226-330)
+//   -processFrame:output:               -> vfhip_convertscale_process     (:332-512)
+//   -cleanup                            -> vfhip_convertscale_cleanup     (:514-528)
+#include "vfhip_internal.h"
+#include "convertscale_kernels.h"
+#include "convertscale_metal_kernels.h"
+#include <cmath>
+
+using namespace vfhip;
+
+static const int kOrcCoef[3][5] = {
+  { 298, 409, 516, -100, -208 },   // bt601
+  { 298, 459, 541,  -55, -136 },   // bt709
+  { 298, 430, 548,  -48, -167 },   // bt2020
+};
+
+struct VfHipConvertScale {
+  std::mutex mu;
+  Device *dev = nullptr;
+  Staging st;
+  bool configured = false;
+  VfHipVideoInfo in {}, out {};
+  int method = 0, add_borders = 0, numerics = 0;
+  uint32_t border_color = 0;
+  int rx = 0, ry = 0, rw = 0, rh = 0;
+  int *d_vtab = nullptr, *d_htab = nullptr;
+  int vfirst = 1, hscale_on = 0;
+  uint32_t hinc = 0;
+  enum Kernel { K_NONE, K_HALF, K_GENERIC, K_METAL } kernel = K_NONE;
+  const char *kernel_name = "none";
+};
+
+static void free_tables (VfHipConvertScale *h)
+{
+  if (h->d_vtab) (void) hipFree (h->d_vtab);
+  if (h->d_htab) (void) hipFree (h->d_htab);
+  h->d_vtab = h->d_htab = nullptr;
+}
+
+// GStreamer 1.14 nearest-neighbour source index: floor(((j + .5) / out) * in) in IEEE double, in that order.
+static int nearest_index (int in, int out, int j)
+{
+  volatile double t = ((double) j + 0.5) / (double) out;
+  volatile double p = t * (double) in;
+  int i = (int) std::floor (p);
+  return i < 0 ? 0 : (i > in - 1 ? in - 1 : i);
+}
+
+// inner rectangle when add-borders is set: aspect-preserving, centred (reference
+// -_computeViewportWithAddBorders:, metalconvertscalerenderer.m:137-166)
+static void compute_rect (VfHipConvertScale *h)
+{
+  const int iw = h->in.width, ih = h->in.height, ow = h->out.width, oh = h->out.height;
+  h->rx = h->ry = 0; h->rw = ow; h->rh = oh;
+  if (!h->add_borders || iw == 0 || ih == 0) return;
+  const float src = (float) iw / (float) ih, dst = (float) ow / (float) oh;
+  if (src > dst) { h->rh = (int) std::lround ((double) oh * (dst / src)); }
+  else { h->rw = (int) std::lround ((double) ow * (src / dst)); }
+  if (h->rw < 1) h->rw = 1;
+  if (h->rh < 1) h->rh = 1;
+  if (h->rw > ow) h->rw = ow;
+  if (h->rh > oh) h->rh = oh;
+  h->rx = (ow - h->rw) / 2; h->ry = (oh - h->rh) / 2;
+}
+
+static uint32_t border_in_output_order (uint32_t argb, int out_format)
+{
+  const uint32_t a = argb >> 24, r = (argb >> 16) & 0xff, g = (argb >> 8) & 0xff, b = argb & 0xff;
+  if (out_format == VFHIP_FORMAT_RGBA) return r | (g << 8) | (b << 16) | (a << 24);
+  return b | (g << 8) | (r << 16) | (a << 24);
+}
+
+template <int ROWS>
+static void launch_half (const CsParams &p, int n_frames, hipStream_t s)
+{
+  const int cgpr = p.out_w / 4, strips = (p.out_h + ROWS - 1) / ROWS;
+  dim3 grid ((unsigned) (((size_t) cgpr * strips + 255) / 256), (unsigned) n_frames);
+  if (p.cosited) {
+    if (p.out_rgba) hipLaunchKernelGGL ((k_cs_nv12_half<ROWS, true, true>), grid, dim3 (256), 0, s, p);
+    else hipLaunchKernelGGL ((k_cs_nv12_half<ROWS, true, false>), grid, dim3 (256), 0, s, p);
+  } else {
+    if (p.out_rgba) hipLaunchKernelGGL ((k_cs_nv12_half<ROWS, false, true>), grid, dim3 (256), 0, s, p);
+    else hipLaunchKernelGGL ((k_cs_nv12_half<ROWS, false, false>), grid, dim3 (256), 0, s, p);
+  }
+}
+
+extern "C" {
+
+VfHipConvertScale *vfhip_convertscale_new (int device)
+{
+  Device *d = get_device (device);
+  if (!d) return nullptr;
+  VfHipConvertScale *h = new (std::nothrow) VfHipConvertScale ();
+  if (!h) { set_error (VFHIP_ERR_NOMEM, "out of memory"); return nullptr; }
+  h->dev = d;
+  if (h->st.init (d) != VFHIP_OK) { delete h; return nullptr; }
+  return h;
+}
+
+int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in, const VfHipVideoInfo *out,
+    int method, int add_borders, uint32_t border_color, int numerics)
+{
+  if (!h || !in || !out) return set_error (VFHIP_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk (h->mu);
+  if (in->width <= 0 || in->height <= 0 || out->width <= 0 || out->height <= 0 || in->width > 32768 || in->height > 32768 ||
+      out->width > 32768 || out->height > 32768)
+    return set_error (VFHIP_ERR_INVALID, "bad frame size %dx%d -> %dx%d", in->width, in->height, out->width, out->height);
+  if (format_n_planes (in->format) < 0 || format_n_planes (out->format) < 0) return VFHIP_ERR_INVALID;
+  if (method != VFHIP_SCALE_BILINEAR && method != VFHIP_SCALE_NEAREST) return set_error (VFHIP_ERR_INVALID, "bad method %d", method);
+  if (numerics != VFHIP_NUMERICS_GST_EXACT && numerics != VFHIP_NUMERICS_METAL) return set_error (VFHIP_ERR_INVALID, "bad numerics %d", numerics);
+  if (in->color_matrix < 0 || in->color_matrix > 2 || out->color_matrix < 0 || out->color_matrix > 2)
+    return set_error (VFHIP_ERR_INVALID, "bad colour matrix");
+  VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
+  h->configured = false;
+  free_tables (h);
+  h->in = *in; h->out = *out; h->method = method; h->add_borders = add_borders ? 1 : 0;
+  h->border_color = border_color; h->numerics = numerics;
+  compute_rect (h);
+
+  const bool in_420_or_rgb = in->format == VFHIP_FORMAT_NV12 || in->format == VFHIP_FORMAT_I420 ||
+                             in->format == VFHIP_FORMAT_BGRA || in->format == VFHIP_FORMAT_RGBA;
+  const bool out_rgb = out->format == VFHIP_FORMAT_BGRA || out->format == VFHIP_FORMAT_RGBA;
+  // gst-exact covers the cells whose GStreamer arithmetic is pinned; every other cell of
+  // the 6x6 matrix runs the reference-shader (metal) arithmetic.
+  const bool exact = numerics == VFHIP_NUMERICS_GST_EXACT && in_420_or_rgb && out_rgb;
+  if (!exact) {
+    h->kernel = VfHipConvertScale::K_METAL; h->kernel_name = "k_cs_metal";
+    h->configured = true;
+    return VFHIP_OK;
+  }
+
+  // tap tables for the destination rectangle (host double arithmetic identical to GstVideoResampler's 2-tap/1-tap set-up)
+  std::vector<int> vt ((size_t) h->rh * 4, 0), ht;
+  if (method == VFHIP_SCALE_NEAREST) {
+    for (int y = 0; y < h->rh; y++) vt[4 * y] = nearest_index (in->height, h->rh, y);
+    ht.resize (h->rw);
+    for (int x = 0; x < h->rw; x++) ht[x] = nearest_index (in->width, h->rw, x);
+  } else {
+    for (int y = 0; y < h->rh; y++) {
+      int i0 = y, i1 = y, w = 0;
+      if (h->rh != in->height) {
+        const double p = (y + 0.5) * in->height / h->rh - 0.5;
+        const int i = (int) std::floor (p);
+        w = (int) std::floor ((p - i) * 256.0 + 0.5);
+        i0 = i < 0 ? 0 : (i > in->height - 1 ? in->height - 1 : i);
+        i1 = i + 1 < 0 ? 0 : (i + 1 > in->height - 1 ? in->height - 1 : i + 1);
+      }
+      vt[4 * y] = i0; vt[4 * y + 1] = i1; vt[4 * y + 2] = w;
+    }
+  }
+  h->hscale_on = (method == VFHIP_SCALE_BILINEAR && h->rw != in->width) ? 1 : 0;
+  h->hinc = h->rw > 1 ? (uint32_t) ((((uint64_t) (in->width - 1)) << 16) / (uint64_t) (h->rw - 1)) - 1 : 0;
+  h->vfirst = in->height > h->rh + 2 ? 1 : 0;      // GstVideoScaler pass order (oracle/gst114.c rule 3)
+  VFHIP_CHECK_HIP (hipMalloc (&h->d_vtab, vt.size () * sizeof (int)));
+  VFHIP_CHECK_HIP (hipMemcpy (h->d_vtab, vt.data (), vt.size () * sizeof (int), hipMemcpyHostToDevice));
+  if (!ht.empty ()) {
+    VFHIP_CHECK_HIP (hipMalloc (&h->d_htab, ht.size () * sizeof (int)));
+    VFHIP_CHECK_HIP (hipMemcpy (h->d_htab, ht.data (), ht.size () * sizeof (int), hipMemcpyHostToDevice));
+  }
+
+  const bool half = in->format == VFHIP_FORMAT_NV12 && method == VFHIP_SCALE_BILINEAR && !h->add_borders &&
+                    in->width == 2 * out->width && in->height == 2 * out->height && (out->width % 4) == 0 && out->height >= 3;
+  if (half) { h->kernel = VfHipConvertScale::K_HALF; h->kernel_name = "k_cs_nv12_half"; }
+  else { h->kernel = VfHipConvertScale::K_GENERIC; h->kernel_name = "k_cs_generic"; }
+  h->configured = true;
+  return VFHIP_OK;
+}
+
+const char *vfhip_convertscale_kernel_name (VfHipConvertScale *h) { return h ? h->kernel_name : "none"; }
+
+static int validate_frames (VfHipConvertScale *h, const VfHipFrame *in, const VfHipFrame *out)
+{
+  if (!h || !in || !out) return set_error (VFHIP_ERR_INVALID, "null argument");
+  if (!h->configured) return set_error (VFHIP_ERR_NOT_CONFIGURED, "convertscale: process before configure");
+  if (in->info.format != h->in.format || in->info.width != h->in.width || in->info.height != h->in.height ||
+      out->info.format != h->out.format || out->info.width != h->out.width || out->info.height != h->out.height)
+    return set_error (VFHIP_ERR_INVALID, "frame does not match the configured caps");
+  for (int p = 0; p < format_n_planes (in->info.format); p++)
+    if (!in->data[p] || in->stride[p] < plane_width_bytes (in->info.format, p, in->info.width))
+      return set_error (VFHIP_ERR_INVALID, "input plane %d: null pointer or short stride", p);
+  for (int p = 0; p < format_n_planes (out->info.format); p++)
+    if (!out->data[p] || out->stride[p] < plane_width_bytes (out->info.format, p, out->info.width))
+      return set_error (VFHIP_ERR_INVALID, "output plane %d: null pointer or short stride", p);
+  return VFHIP_OK;
+}
+
+// launch on device frames; caller holds the mutex
+static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame *out, size_t in_pitch, size_t out_pitch,
+    int n_frames, hipStream_t s)
+{
+  if (n_frames <= 0) return VFHIP_OK;
+  if (n_frames > 65535) return set_error (VFHIP_ERR_INVALID, "batch of %d frames exceeds 65535", n_frames);
+  if (h->kernel == VfHipConvertScale::K_METAL)
+    return cs_metal_launch (h->in, h->out, h->method, h->add_borders, h->border_color, in, out, in_pitch, out_pitch, n_frames, s);
+  CsParams p {};
+  for (int k = 0; k < 3; k++) { p.in[k] = (const uint8_t *) in->data[k]; p.is[k] = in->stride[k]; }
+  p.out = (uint8_t *) out->data[0]; p.os = out->stride[0];
+  p.in_pitch = in_pitch; p.out_pitch = out_pitch;
+  p.in_w = h->in.width; p.in_h = h->in.height; p.out_w = h->out.width; p.out_h = h->out.height;
+  p.rx = h->rx; p.ry = h->ry; p.rw = h->rw; p.rh = h->rh;
+  p.in_fmt = h->in.format; p.out_rgba = h->out.format == VFHIP_FORMAT_RGBA;
+  for (int k = 0; k < 5; k++) p.c[k] = kOrcCoef[h->in.color_matrix][k];
+  p.cosited = h->in.chroma_site == VFHIP_CHROMA_SITE_H_COSITED;
+  p.nearest = h->method == VFHIP_SCALE_NEAREST; p.vfirst = h->vfirst; p.hscale_on = h->hscale_on; p.hinc = h->hinc;
+  p.vtab = h->d_vtab; p.htab = h->d_htab;
+  p.border = border_in_output_order (h->border_color, h->out.format);
+
+  bool half = h->kernel == VfHipConvertScale::K_HALF;
+  if (half) {
+    // vector-access preconditions of the fast path; otherwise the generic kernel computes the same bytes
+    const uintptr_t a = (uintptr_t) p.in[0] | (uintptr_t) p.in[1] | (uintptr_t) p.is[0] | (uintptr_t) p.is[1] | (uintptr_t) in_pitch;
+    const uintptr_t b = (uintptr_t) p.out | (uintptr_t) p.os | (uintptr_t) out_pitch;
+    if ((a & 7) || (b & 15)) half = false;
+  }
+  if (half) {
+    // rows per lane: long strips amortise the 2-row chroma prologue; short ones keep a single frame wide enough
+    const size_t waves16 = (size_t) (p.out_w / 4) * ((p.out_h + 15) / 16) * n_frames / 64;
+    const size_t waves8 = (size_t) (p.out_w / 4) * ((p.out_h + 7) / 8) * n_frames / 64;
+    const size_t want = (size_t) h->dev->n_cu * 16;
+    if (waves16 >= want) launch_half<16> (p, n_frames, s);
+    else if (waves8 >= want) launch_half<8> (p, n_frames, s);
+    else launch_half<4> (p, n_frames, s);
+  } else {
+    dim3 grid ((unsigned) ((p.out_w + 63) / 64), (unsigned) ((p.out_h + 3) / 4), (unsigned) n_frames);
+    hipLaunchKernelGGL (k_cs_generic, grid, dim3 (64, 4), 0, s, p);
+  }
+  VFHIP_CHECK_HIP (hipGetLastError ());
+  return VFHIP_OK;
+}
+
+int vfhip_convertscale_process_device_batch (VfHipConvertScale *h, const VfHipFrame *in0, VfHipFrame *out0,
+    size_t in_frame_pitch, size_t out_frame_pitch, int n_frames, void *stream)
+{
+  int rc = validate_frames (h, in0, out0);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk (h->mu);
+  VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
+  return launch_device (h, in0, out0, in_frame_pitch, out_frame_pitch, n_frames, stream ? (hipStream_t) stream : h->st.s_compute);
+}
+
+int vfhip_convertscale_process_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame *out, void *stream)
+{
+  return vfhip_convertscale_process_device_batch (h, in, out, 0, 0, 1, stream);
+}
+
+int vfhip_convertscale_process (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame *out)
+{
+  int rc = validate_frames (h, in, out);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk (h->mu);
+  VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
+  VfHipFrame din, dout;
+  if ((rc = upload_frame (h->st, 0, in, &din))) return rc;                 // pinned staging + async H2D on the h2d stream
+  if ((rc = alloc_device_frame (h->st, 1, &h->out, &dout))) return rc;
+  VFHIP_CHECK_HIP (hipStreamWaitEvent (h->st.s_compute, h->st.ev_h2d, 0));
+  if ((rc = launch_device (h, &din, &dout, 0, 0, 1, h->st.s_compute))) return rc;
+  VFHIP_CHECK_HIP (hipEventRecord (h->st.ev_compute, h->st.s_compute));
+  return download_frame (h->st, 1, &dout, out);                              // async D2H on the d2h stream, then sync
+}
+
+void vfhip_convertscale_cleanup (VfHipConvertScale *h)
+{
+  if (!h) return;
+  std::lock_guard<std::mutex> lk (h->mu);
+  (void) hipSetDevice (h->dev->ordinal);
+  free_tables (h);
+  for (auto &b : h->st.slots) {
+    if (b.host) (void) hipHostFree (b.host);
+    if (b.devp) (void) hipFree (b.devp);
+  }
+  h->st.slots.clear ();
+  h->configured = false;
+}
+
+void vfhip_convertscale_free (VfHipConvertScale *h)
+{
+  if (!h) return;
+  vfhip_convertscale_cleanup (h);
+  h->st.destroy ();
+  delete h;
+}
+
+}  // extern "C"

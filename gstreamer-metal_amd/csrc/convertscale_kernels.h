@@ -1,0 +1,279 @@
+// csrc/convertscale_kernels.h — device code of vfhipconvertscale (gfx950 / CDNA4 only).
+//
+// Replaces the reference's render pass convertScaleVertex + convertScaleFragment{RGBA,NV12,I420,UYVY,YUY2}
+// (convertscale/metalconvertscale_shaders.h:48-198) and yuvToRGB (common/vfmetalshaders.m:40-79).
+// Two arithmetic families (SURVEY.md finding 3):
+//   gst-exact : the integer arithmetic of GStreamer 1.14 videoconvert+videoscale (bit-exact; oracle/gst114.c)
+//   metal     : the float arithmetic of the reference shaders (convertscale_metal_kernels.h)
+//
+// Kernels in this file (all HBM-bound streaming kernels, no MFMA — there is no contraction):
+//   k_cs_nv12_half   : NV12 -> BGRA/RGBA at exactly 2:1 in both axes, bilinear (the BASELINE headline
+//                      2160p -> 1080p).  Each lane owns 4 adjacent output pixels (one 16-byte store per
+//                      row) and slides down a strip of ROWS output rows, keeping the horizontally
+//                      up-sampled chroma rows j-1, j in registers, so every input byte is loaded once.
+//                      Packed-byte ALU: v_lerp_u8 for the (a+b+1)>>1 / (3a+b+2)>>2 chroma filters and the
+//                      w=128 vertical tap, v_mad_i32_i16 with op_sel for the ORC mulhs matrix,
+//                      v_sat_pk_u8_i16 for the clamps, v_pk_mad_u16 for the horizontal taps.
+//   k_cs_generic     : any size / method / {NV12,I420,BGRA,RGBA} -> {BGRA,RGBA}; 4 taps per output pixel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vfhip {
+
+struct CsParams {
+  const uint8_t *in[3];
+  int is[3];
+  uint8_t *out;
+  int os;
+  size_t in_pitch, out_pitch;       // batch: frame k at base + k * pitch
+  int in_w, in_h, out_w, out_h;     // full frame sizes
+  int rx, ry, rw, rh;               // destination rectangle (== full frame unless add-borders)
+  int in_fmt, out_rgba;             // out_rgba: 1 = RGBA byte order, 0 = BGRA
+  int c[5];                         // ORC matrix p1..p5
+  int cosited, nearest, vfirst, hscale_on;
+  uint32_t hinc;                    // 16.16 horizontal increment (bilinear)
+  const int *vtab;                  // bilinear: rh * {i0, i1, w, pad}; nearest: rh * {i, 0, 0, 0}
+  const int *htab;                  // nearest: rw source columns
+  uint32_t border;                  // border colour in output byte order
+};
+
+// ------------------------------------------------------------------------------------------------
+// packed-byte helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lerp_u8 (uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_lerp (a, b, c); }
+// (3a + b + 2) >> 2 per byte == (a + ((a + b) >> 1) + 1) >> 1   (exact)
+__device__ __forceinline__ uint32_t filt31_u8 (uint32_t a, uint32_t b) { return lerp_u8 (a, lerp_u8 (a, b, 0u), 0x01010101u); }
+__device__ __forceinline__ uint32_t avg_rnd_u8 (uint32_t a, uint32_t b) { return lerp_u8 (a, b, 0x01010101u); }
+__device__ __forceinline__ uint32_t perm_b32 (uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm (hi, lo, sel); }
+__device__ __forceinline__ uint32_t alignbyte (uint32_t hi, uint32_t lo, uint32_t n) { return __builtin_amdgcn_alignbyte (hi, lo, n); }
+
+template <int HI>
+__device__ __forceinline__ int mad_i32_i16 (uint32_t a, int coef, int acc)
+{
+  int d;
+  if (HI) asm ("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(a), "v"(coef), "v"(acc));
+  else    asm ("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(coef), "v"(acc));
+  return d;
+}
+__device__ __forceinline__ uint32_t sat_pk_u8_i16 (uint32_t v)
+{
+  uint32_t d;
+  asm ("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(v));
+  return d;
+}
+
+// ORC video_orc_convert_AYUV_ARGB on one pixel.  `ys`: two byte-splatted int16 luma samples (already ^0x80),
+// YHI picks the half; `uvs`: [U U V V] (already ^0x80).  Returns the packed BGRA/RGBA pixel, alpha 255.
+template <int YHI, bool RGBA>
+__device__ __forceinline__ uint32_t orc_pixel (uint32_t ys, uint32_t uvs, int c0, int c1, int c2, int c3, int c4, int bias)
+{
+  // wy = mulhs(splat(Y), p1) kept in the high half, with +128 folded in; low half cleared so that later
+  // products floor independently (mulhs(a)+mulhs(b) != mulhs(a+b)).
+  int wy = mad_i32_i16<YHI> (ys, c0, bias) & (int) 0xffff0000;
+  int tr = mad_i32_i16<1> (uvs, c1, wy);                                  // + mulhs(splat(V), p2)
+  int tb = mad_i32_i16<0> (uvs, c2, wy);                                  // + mulhs(splat(U), p3)
+  int tg = mad_i32_i16<1> (uvs, c4, mad_i32_i16<0> (uvs, c3, wy) & (int) 0xffff0000);
+  uint32_t lo, hi;
+  if (RGBA) { lo = perm_b32 ((uint32_t) tg, (uint32_t) tr, 0x07060302u); hi = perm_b32 (0u, (uint32_t) tb, 0x0c0d0302u); }
+  else      { lo = perm_b32 ((uint32_t) tg, (uint32_t) tb, 0x07060302u); hi = perm_b32 (0u, (uint32_t) tr, 0x0c0d0302u); }
+  // lo = [X.hi16 | G.hi16 << 16], hi = [Z.hi16 | 0x00ff << 16]; saturate each int16 to u8 and pack
+  return (sat_pk_u8_i16 (lo) & 0xffffu) | (sat_pk_u8_i16 (hi) << 16);
+}
+
+typedef unsigned short u16x2 __attribute__ ((ext_vector_type (2)));
+__device__ __forceinline__ u16x2 as_u16x2 (uint32_t v) { return __builtin_bit_cast (u16x2, v); }
+__device__ __forceinline__ uint32_t as_u32 (u16x2 v) { return __builtin_bit_cast (uint32_t, v); }
+
+// (a*(256-f) + b*f) >> 8 on the 4 bytes of two packed pixels; f2/wf2 = f and 256-f replicated in both halves
+__device__ __forceinline__ uint32_t hlerp_px (uint32_t a, uint32_t b, uint32_t f2, uint32_t wf2)
+{
+  u16x2 a02 = as_u16x2 (a & 0x00ff00ffu), a13 = as_u16x2 (perm_b32 (0u, a, 0x0c030c01u));
+  u16x2 b02 = as_u16x2 (b & 0x00ff00ffu), b13 = as_u16x2 (perm_b32 (0u, b, 0x0c030c01u));
+  u16x2 f = as_u16x2 (f2), wf = as_u16x2 (wf2);
+  u16x2 t02 = a02 * wf + b02 * f;
+  u16x2 t13 = a13 * wf + b13 * f;
+  return perm_b32 (as_u32 (t13), as_u32 (t02), 0x07030501u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_cs_nv12_half
+// ------------------------------------------------------------------------------------------------
+struct CRow { uint32_t e01, e23, o01, o23; };   // horizontally up-sampled chroma of 8 source columns: even / odd columns
+
+template <bool COSITED>
+__device__ __forceinline__ CRow load_crow (const uint8_t *row, int cg, int cgpr)
+{
+  const uint2 v = *reinterpret_cast<const uint2 *> (row + 8 * (size_t) cg);      // [U0V0U1V1][U2V2U3V3]
+  uint32_t right = (cg == cgpr - 1) ? (v.y >> 16) : *reinterpret_cast<const uint16_t *> (row + 8 * (size_t) cg + 8);
+  uint32_t r01 = alignbyte (v.y, v.x, 2);          // [U1V1U2V2]
+  uint32_t r23 = alignbyte (right, v.y, 2);        // [U3V3U4V4]
+  CRow c;
+  if (COSITED) {
+    c.e01 = v.x; c.e23 = v.y;
+    c.o01 = avg_rnd_u8 (v.x, r01); c.o23 = avg_rnd_u8 (v.y, r23);
+  } else {
+    uint32_t left = (cg == 0) ? (v.x & 0xffffu) : *reinterpret_cast<const uint16_t *> (row + 8 * (size_t) cg - 2);
+    uint32_t l01 = (v.x << 16) | left;             // [U-1V-1U0V0]
+    uint32_t l23 = alignbyte (v.y, v.x, 2);        // [U1V1U2V2]
+    c.e01 = filt31_u8 (v.x, l01); c.e23 = filt31_u8 (v.y, l23);
+    c.o01 = filt31_u8 (v.x, r01); c.o23 = filt31_u8 (v.y, r23);
+  }
+  return c;
+}
+
+template <bool RGBA>
+__device__ __forceinline__ void half_row_pixels (uint2 y, uint32_t e01, uint32_t e23, uint32_t o01, uint32_t o23,
+    const int *c, int bias, uint32_t px_even[4], uint32_t px_odd[4])
+{
+  const uint32_t yx0 = y.x ^ 0x80808080u, yx1 = y.y ^ 0x80808080u;
+  const uint32_t ys0 = perm_b32 (0u, yx0, 0x01010000u), ys1 = perm_b32 (0u, yx0, 0x03030202u);   // cols 0,1 | 2,3
+  const uint32_t ys2 = perm_b32 (0u, yx1, 0x01010000u), ys3 = perm_b32 (0u, yx1, 0x03030202u);   // cols 4,5 | 6,7
+  e01 ^= 0x80808080u; e23 ^= 0x80808080u; o01 ^= 0x80808080u; o23 ^= 0x80808080u;
+  // output pixel n uses source columns 2n (even, chroma e) and 2n+1 (odd, chroma o)
+  px_even[0] = orc_pixel<0, RGBA> (ys0, perm_b32 (0u, e01, 0x01010000u), c[0], c[1], c[2], c[3], c[4], bias);
+  px_odd[0]  = orc_pixel<1, RGBA> (ys0, perm_b32 (0u, o01, 0x01010000u), c[0], c[1], c[2], c[3], c[4], bias);
+  px_even[1] = orc_pixel<0, RGBA> (ys1, perm_b32 (0u, e01, 0x03030202u), c[0], c[1], c[2], c[3], c[4], bias);
+  px_odd[1]  = orc_pixel<1, RGBA> (ys1, perm_b32 (0u, o01, 0x03030202u), c[0], c[1], c[2], c[3], c[4], bias);
+  px_even[2] = orc_pixel<0, RGBA> (ys2, perm_b32 (0u, e23, 0x01010000u), c[0], c[1], c[2], c[3], c[4], bias);
+  px_odd[2]  = orc_pixel<1, RGBA> (ys2, perm_b32 (0u, o23, 0x01010000u), c[0], c[1], c[2], c[3], c[4], bias);
+  px_even[3] = orc_pixel<0, RGBA> (ys3, perm_b32 (0u, e23, 0x03030202u), c[0], c[1], c[2], c[3], c[4], bias);
+  px_odd[3]  = orc_pixel<1, RGBA> (ys3, perm_b32 (0u, o23, 0x03030202u), c[0], c[1], c[2], c[3], c[4], bias);
+}
+
+// grid: x = ceil(cgpr * strips / 256), y = frames.  cgpr = out_w / 4 column groups per row.
+template <int ROWS, bool COSITED, bool RGBA>
+__global__ __launch_bounds__ (256) void k_cs_nv12_half (const CsParams p)
+{
+  const int cgpr = p.out_w >> 2;
+  const int strips = (p.out_h + ROWS - 1) / ROWS;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= cgpr * strips) return;
+  const int strip = t / cgpr, cg = t - strip * cgpr;
+  const int y0 = strip * ROWS;
+  const int ch = p.out_h;                       // chroma rows == output rows at 2:1
+  const uint8_t *yp = p.in[0] + (size_t) blockIdx.y * p.in_pitch;
+  const uint8_t *uvp = p.in[1] + (size_t) blockIdx.y * p.in_pitch;
+  uint8_t *op = p.out + (size_t) blockIdx.y * p.out_pitch;
+  const int c[5] = { p.c[0], p.c[1], p.c[2], p.c[3], p.c[4] };
+  const int bias = 128 << 16;
+
+  // horizontal tap weights of this lane's 4 output pixels (row independent)
+  uint32_t f2[4], wf2[4];
+#pragma unroll
+  for (int n = 0; n < 4; n++) {
+    uint32_t tt = (uint32_t) (cg * 4 + n) * p.hinc;
+    uint32_t f = (tt >> 8) & 0xffu;
+    f2[n] = f | (f << 16);
+    wf2[n] = 0x01000100u - f2[n];
+  }
+
+  CRow hm = load_crow<COSITED> (uvp + (size_t) max (y0 - 1, 0) * p.is[1], cg, cgpr);
+  CRow hc = load_crow<COSITED> (uvp + (size_t) y0 * p.is[1], cg, cgpr);
+  const int yend = min (y0 + ROWS, p.out_h);
+  for (int y = y0; y < yend; y++) {
+    const CRow hn = load_crow<COSITED> (uvp + (size_t) min (y + 1, ch - 1) * p.is[1], cg, cgpr);
+    const uint2 yt = *reinterpret_cast<const uint2 *> (yp + (size_t) (2 * y) * p.is[0] + 8 * (size_t) cg);
+    const uint2 yb = *reinterpret_cast<const uint2 *> (yp + (size_t) (2 * y + 1) * p.is[0] + 8 * (size_t) cg);
+    uint32_t te[4], to[4], be[4], bo[4];
+    // vertical chroma filter: source row 2y leans on chroma row y-1, row 2y+1 on chroma row y+1
+    half_row_pixels<RGBA> (yt, filt31_u8 (hc.e01, hm.e01), filt31_u8 (hc.e23, hm.e23), filt31_u8 (hc.o01, hm.o01), filt31_u8 (hc.o23, hm.o23), c, bias, te, to);
+    half_row_pixels<RGBA> (yb, filt31_u8 (hc.e01, hn.e01), filt31_u8 (hc.e23, hn.e23), filt31_u8 (hc.o01, hn.o01), filt31_u8 (hc.o23, hn.o23), c, bias, be, bo);
+    uint4 o;
+    // vertical 2-tap with w = 128: s1 + (((s2-s1)*128+128)>>8) == (s1+s2+1)>>1; then the horizontal 2-tap
+    o.x = hlerp_px (avg_rnd_u8 (te[0], be[0]), avg_rnd_u8 (to[0], bo[0]), f2[0], wf2[0]);
+    o.y = hlerp_px (avg_rnd_u8 (te[1], be[1]), avg_rnd_u8 (to[1], bo[1]), f2[1], wf2[1]);
+    o.z = hlerp_px (avg_rnd_u8 (te[2], be[2]), avg_rnd_u8 (to[2], bo[2]), f2[2], wf2[2]);
+    o.w = hlerp_px (avg_rnd_u8 (te[3], be[3]), avg_rnd_u8 (to[3], bo[3]), f2[3], wf2[3]);
+    *reinterpret_cast<uint4 *> (op + (size_t) y * p.os + 16 * (size_t) cg) = o;
+    hm = hc; hc = hn;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_cs_generic: one output pixel per thread, 4 converted taps
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int clampi (int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int splat16 (int x) { int v = ((x ^ 0x80) & 0xff) * 257; return v >= 32768 ? v - 65536 : v; }
+
+// converted source pixel at (cx, cy) as 4 channel ints in OUTPUT byte order
+__device__ __forceinline__ void cs_tap (const CsParams &p, const uint8_t *const in[3], int cx, int cy, int px[4])
+{
+  if (p.in_fmt == VFHIP_FORMAT_BGRA || p.in_fmt == VFHIP_FORMAT_RGBA) {
+    const uint32_t v = *reinterpret_cast<const uint32_t *> (in[0] + (size_t) cy * p.is[0] + 4 * (size_t) cx);
+    const bool swap = (p.in_fmt == VFHIP_FORMAT_RGBA) != (p.out_rgba != 0);
+    px[0] = swap ? (v >> 16) & 0xff : v & 0xff;
+    px[1] = (v >> 8) & 0xff;
+    px[2] = swap ? v & 0xff : (v >> 16) & 0xff;
+    px[3] = v >> 24;
+    return;
+  }
+  const int cw = (p.in_w + 1) >> 1, chh = (p.in_h + 1) >> 1;
+  const int Y = in[0][(size_t) cy * p.is[0] + cx];
+  const int j = cy >> 1, k = cx >> 1;
+  int U, V;
+  if (p.in_fmt == VFHIP_FORMAT_I420) {      // GStreamer's I420 fast path: nearest-replicated chroma
+    U = in[1][(size_t) j * p.is[1] + k];
+    V = in[2][(size_t) j * p.is[2] + k];
+  } else {
+    const int jn = (cy & 1) ? min (j + 1, chh - 1) : max (j - 1, 0);
+    const uint8_t *r0 = in[1] + (size_t) j * p.is[1], *r1 = in[1] + (size_t) jn * p.is[1];
+    const int kn = (cx & 1) ? min (k + 1, cw - 1) : max (k - 1, 0);
+    int u0, v0, u1, v1;
+    if (p.cosited) {
+      if (cx & 1) { u0 = (r0[2 * k] + r0[2 * kn] + 1) >> 1; v0 = (r0[2 * k + 1] + r0[2 * kn + 1] + 1) >> 1;
+                    u1 = (r1[2 * k] + r1[2 * kn] + 1) >> 1; v1 = (r1[2 * k + 1] + r1[2 * kn + 1] + 1) >> 1; }
+      else { u0 = r0[2 * k]; v0 = r0[2 * k + 1]; u1 = r1[2 * k]; v1 = r1[2 * k + 1]; }
+    } else {
+      u0 = (3 * r0[2 * k] + r0[2 * kn] + 2) >> 2; v0 = (3 * r0[2 * k + 1] + r0[2 * kn + 1] + 2) >> 2;
+      u1 = (3 * r1[2 * k] + r1[2 * kn] + 2) >> 2; v1 = (3 * r1[2 * k + 1] + r1[2 * kn + 1] + 2) >> 2;
+    }
+    U = (3 * u0 + u1 + 2) >> 2; V = (3 * v0 + v1 + 2) >> 2;
+  }
+  const int wy = (splat16 (Y) * p.c[0]) >> 16;
+  const int r = clampi (wy + ((splat16 (V) * p.c[1]) >> 16), -128, 127) + 128;
+  const int b = clampi (wy + ((splat16 (U) * p.c[2]) >> 16), -128, 127) + 128;
+  const int g = clampi (wy + ((splat16 (U) * p.c[3]) >> 16) + ((splat16 (V) * p.c[4]) >> 16), -128, 127) + 128;
+  px[0] = p.out_rgba ? r : b; px[1] = g; px[2] = p.out_rgba ? b : r; px[3] = 255;
+}
+
+__global__ __launch_bounds__ (256) void k_cs_generic (const CsParams p)
+{
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= p.out_w || y >= p.out_h) return;
+  const uint8_t *in[3] = { p.in[0] + (size_t) blockIdx.z * p.in_pitch,
+                           p.in[1] ? p.in[1] + (size_t) blockIdx.z * p.in_pitch : nullptr,
+                           p.in[2] ? p.in[2] + (size_t) blockIdx.z * p.in_pitch : nullptr };
+  uint32_t *o = reinterpret_cast<uint32_t *> (p.out + (size_t) blockIdx.z * p.out_pitch + (size_t) y * p.os) + x;
+  const int dx = x - p.rx, dy = y - p.ry;
+  if (dx < 0 || dy < 0 || dx >= p.rw || dy >= p.rh) { *o = p.border; return; }
+  int r[4];
+  if (p.nearest) {
+    cs_tap (p, in, p.htab[dx], p.vtab[4 * dy], r);
+  } else {
+    const int i0 = p.vtab[4 * dy], i1 = p.vtab[4 * dy + 1], w = p.vtab[4 * dy + 2];
+    int xa = dx, xb = dx, f = 0;
+    if (p.hscale_on) {
+      const uint32_t t = (uint32_t) dx * p.hinc;
+      xa = (int) (t >> 16); f = (int) ((t >> 8) & 0xff); xb = min (xa + 1, p.in_w - 1);
+    }
+    int a0[4], b0[4], a1[4], b1[4];
+    cs_tap (p, in, xa, i0, a0); cs_tap (p, in, xb, i0, b0);
+    cs_tap (p, in, xa, i1, a1); cs_tap (p, in, xb, i1, b1);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (p.vfirst) {
+        const int va = a0[k] + (((a1[k] - a0[k]) * w + 128) >> 8);
+        const int vb = b0[k] + (((b1[k] - b0[k]) * w + 128) >> 8);
+        r[k] = p.hscale_on ? (va * (256 - f) + vb * f) >> 8 : va;
+      } else {
+        const int h0 = (a0[k] * (256 - f) + b0[k] * f) >> 8;
+        const int h1 = (a1[k] * (256 - f) + b1[k] * f) >> 8;
+        r[k] = h0 + (((h1 - h0) * w + 128) >> 8);
+      }
+    }
+  }
+  *o = (uint32_t) r[0] | ((uint32_t) r[1] << 8) | ((uint32_t) r[2] << 16) | ((uint32_t) r[3] << 24);
+}
+
+}  // namespace vfhip

@@ -1,0 +1,221 @@
+// csrc/metal_common.h — device helpers for the `metal` numerics family: the float arithmetic the
+// reference's Metal shaders perform on unorm8 samples.  Shared by the
+// convertscale metal path, videofilter, compositor and deinterlace kernels.
+//
+// Restates (does not copy) reference common/vfmetalshaders.m:40-168 (matrices, yuvToRGB, rgbaToNV12 /
+// rgbaToI420) and convertscale/metalconvertscale_shaders.h:151-269 (packed YUV fetch / store).
+// The CPU twin used by the tests is oracle/metalref.c; both are compiled with -ffp-contract=off and
+// evaluate every expression in the same order, so they normally agree bit for bit (tests allow +-1 LSB).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vfhip.h"
+
+namespace vfhip {
+namespace metal {
+
+struct Img {                 // one video frame in device memory
+  const uint8_t *p[3];
+  int s[3];
+  int w, h, fmt;
+  int m709;                  // reference rule: BT.709 iff matrix == BT709, else BT.601 (vfmetaltextureutil.m:35-41)
+};
+struct OutImg {
+  uint8_t *p[3];
+  int s[3];
+  int w, h, fmt;
+  int m709;
+};
+
+struct F4 { float r, g, b, a; };
+
+__device__ __forceinline__ float un8 (uint32_t v) { return (float) v * (1.0f / 255.0f); }
+__device__ __forceinline__ float clamp01 (float x) { return fminf (fmaxf (x, 0.0f), 1.0f); }
+__device__ __forceinline__ uint32_t quant8 (float x) { return (uint32_t) __float2int_rn (clamp01 (x) * 255.0f); }   // unorm8 write: RNE
+__device__ __forceinline__ int iclamp (int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// limited-range YCbCr -> RGB (reference yuvToRGB)
+__device__ __forceinline__ F4 yuv_to_rgb (float y, float cb, float cr, int m709)
+{
+  const float yy = y - 16.0f / 255.0f, u = cb - 128.0f / 255.0f, v = cr - 128.0f / 255.0f;
+  F4 o;
+  if (m709) {
+    o.r = 1.164383f * yy + 0.0f * u + 1.792741f * v;
+    o.g = 1.164383f * yy + -0.213249f * u + -0.532909f * v;
+    o.b = 1.164383f * yy + 2.112402f * u + 0.0f * v;
+  } else {
+    o.r = 1.164383f * yy + 0.0f * u + 1.596027f * v;
+    o.g = 1.164383f * yy + -0.391762f * u + -0.812968f * v;
+    o.b = 1.164383f * yy + 2.017232f * u + 0.0f * v;
+  }
+  o.r = clamp01 (o.r); o.g = clamp01 (o.g); o.b = clamp01 (o.b); o.a = 1.0f;
+  return o;
+}
+
+// RGB -> limited-range YCbCr, unclamped (reference bt601/709_rgb_matrix)
+__device__ __forceinline__ void rgb_to_yuv (float r, float g, float b, int m709, float *y, float *u, float *v)
+{
+  if (m709) {
+    *y = 0.182586f * r + 0.614231f * g + 0.062007f * b + 16.0f / 255.0f;
+    *u = -0.100644f * r + -0.338572f * g + 0.439216f * b + 128.0f / 255.0f;
+    *v = 0.439216f * r + -0.398942f * g + -0.040274f * b + 128.0f / 255.0f;
+  } else {
+    *y = 0.256788f * r + 0.504129f * g + 0.097906f * b + 16.0f / 255.0f;
+    *u = -0.148223f * r + -0.290993f * g + 0.439216f * b + 128.0f / 255.0f;
+    *v = 0.439216f * r + -0.367788f * g + -0.071427f * b + 128.0f / 255.0f;
+  }
+}
+
+// ---- texture sampling ---------------------------------------------------
+struct Taps { int i0, i1; float f; };
+__device__ __forceinline__ Taps lin_taps (int n, float coord)          // coord normalised 0..1
+{
+  const float x = coord * (float) n - 0.5f;
+  const float fl = floorf (x);
+  Taps t; t.f = x - fl;
+  const int i = (int) fl;
+  t.i0 = iclamp (i, 0, n - 1); t.i1 = iclamp (i + 1, 0, n - 1);
+  return t;
+}
+__device__ __forceinline__ int near_tap (int n, float coord) { return iclamp ((int) floorf (coord * (float) n), 0, n - 1); }
+__device__ __forceinline__ float lerp2 (float a, float b, float f) { return a + (b - a) * f; }
+
+// one channel of a plane with `bpt` bytes per texel
+__device__ __forceinline__ float plane_linear (const uint8_t *p, int stride, int bpt, int ch, int W, int H, float u, float v)
+{
+  const Taps tx = lin_taps (W, u), ty = lin_taps (H, v);
+  const uint8_t *r0 = p + (size_t) ty.i0 * stride, *r1 = p + (size_t) ty.i1 * stride;
+  const float a = lerp2 (un8 (r0[tx.i0 * bpt + ch]), un8 (r0[tx.i1 * bpt + ch]), tx.f);
+  const float b = lerp2 (un8 (r1[tx.i0 * bpt + ch]), un8 (r1[tx.i1 * bpt + ch]), tx.f);
+  return lerp2 (a, b, ty.f);
+}
+__device__ __forceinline__ float plane_nearest (const uint8_t *p, int stride, int bpt, int ch, int W, int H, float u, float v)
+{
+  return un8 (p[(size_t) near_tap (H, v) * stride + near_tap (W, u) * bpt + ch]);
+}
+__device__ __forceinline__ float plane_sample (const uint8_t *p, int stride, int bpt, int ch, int W, int H, float u, float v, bool linear)
+{
+  return linear ? plane_linear (p, stride, bpt, ch, W, H, u, v) : plane_nearest (p, stride, bpt, ch, W, H, u, v);
+}
+
+// sample any of the six input formats at normalised (u, v) -> logical RGBA float
+__device__ __forceinline__ F4 sample_rgba (const Img &im, float u, float v, bool linear)
+{
+  F4 o;
+  switch (im.fmt) {
+    case VFHIP_FORMAT_BGRA: case VFHIP_FORMAT_RGBA: {
+      const int ro = im.fmt == VFHIP_FORMAT_RGBA ? 0 : 2;
+      o.r = plane_sample (im.p[0], im.s[0], 4, ro, im.w, im.h, u, v, linear);
+      o.g = plane_sample (im.p[0], im.s[0], 4, 1, im.w, im.h, u, v, linear);
+      o.b = plane_sample (im.p[0], im.s[0], 4, 2 - ro, im.w, im.h, u, v, linear);
+      o.a = plane_sample (im.p[0], im.s[0], 4, 3, im.w, im.h, u, v, linear);
+      return o;
+    }
+    case VFHIP_FORMAT_NV12: {
+      const int cw = (im.w + 1) / 2, chh = (im.h + 1) / 2;
+      const float y = plane_sample (im.p[0], im.s[0], 1, 0, im.w, im.h, u, v, linear);
+      const float cb = plane_sample (im.p[1], im.s[1], 2, 0, cw, chh, u, v, linear);
+      const float cr = plane_sample (im.p[1], im.s[1], 2, 1, cw, chh, u, v, linear);
+      return yuv_to_rgb (y, cb, cr, im.m709);
+    }
+    case VFHIP_FORMAT_I420: {
+      const int cw = (im.w + 1) / 2, chh = (im.h + 1) / 2;
+      const float y = plane_sample (im.p[0], im.s[0], 1, 0, im.w, im.h, u, v, linear);
+      const float cb = plane_sample (im.p[1], im.s[1], 1, 0, cw, chh, u, v, linear);
+      const float cr = plane_sample (im.p[2], im.s[2], 1, 0, cw, chh, u, v, linear);
+      return yuv_to_rgb (y, cb, cr, im.m709);
+    }
+    default: {   // UYVY / YUY2: always nearest macro-pixel (reference metalconvertscalerenderer.m:184-185)
+      const int tw = im.w / 2;                           // macro-pixels; an odd last column is dropped (:420)
+      const float texw = (float) tw, fullw = texw * 2.0f;
+      const float px = u * fullw;
+      const float mx = floorf (px / 2.0f);
+      const float sub = px - mx * 2.0f;
+      const int tx = near_tap (tw, (mx + 0.5f) / texw), ty = near_tap (im.h, v);
+      const uint8_t *t = im.p[0] + (size_t) ty * im.s[0] + 4 * tx;
+      float y, cb, cr;
+      if (im.fmt == VFHIP_FORMAT_UYVY) { cb = un8 (t[0]); cr = un8 (t[2]); y = sub < 1.0f ? un8 (t[1]) : un8 (t[3]); }
+      else { cb = un8 (t[1]); cr = un8 (t[3]); y = sub < 1.0f ? un8 (t[0]) : un8 (t[2]); }
+      return yuv_to_rgb (y, cb, cr, im.m709);
+    }
+  }
+}
+
+// exact-texel fetch at integer (x, y) (clamped) -> logical RGBA float; NV12/I420 chroma texel floor(x/2), floor(y/2)
+// (a 1:1 sample with a linear or nearest sampler lands exactly on the texel; chroma: see *_chroma_linear below)
+__device__ __forceinline__ uint32_t pack_rgba8 (uint32_t r, uint32_t g, uint32_t b, uint32_t a) { return r | (g << 8) | (b << 16) | (a << 24); }
+__device__ __forceinline__ uint32_t quant_rgba8 (F4 c) { return pack_rgba8 (quant8 (c.r), quant8 (c.g), quant8 (c.b), quant8 (c.a)); }
+__device__ __forceinline__ F4 unpack_rgba8 (uint32_t q)
+{
+  F4 o; o.r = un8 (q & 0xff); o.g = un8 ((q >> 8) & 0xff); o.b = un8 ((q >> 16) & 0xff); o.a = un8 (q >> 24);
+  return o;
+}
+
+// ---- output epilogue: one thread owns a 2x2 block of logical RGBA8 pixels -----------------------------
+// q[dy][dx] must be edge-clamped duplicates when the block hangs over the right / bottom edge.
+// Replaces the reference's separate RGBA->NV12 / I420 / UYVY / YUY2 compute passes and the render-target
+// read-back (common/vfmetalshaders.m:90-168, convertscale/metalconvertscale_shaders.h:202-269) — the 8-bit
+// intermediate stays in registers instead of making two more trips through memory.
+__device__ __forceinline__ void store_block (const OutImg &o, int bx, int by, const uint32_t q[2][2])
+{
+  const int x0 = 2 * bx, y0 = 2 * by;
+  switch (o.fmt) {
+    case VFHIP_FORMAT_BGRA: case VFHIP_FORMAT_RGBA: {
+#pragma unroll
+      for (int dy = 0; dy < 2; dy++) {
+        if (y0 + dy >= o.h) break;
+        uint32_t *row = reinterpret_cast<uint32_t *> (o.p[0] + (size_t) (y0 + dy) * o.s[0]);
+#pragma unroll
+        for (int dx = 0; dx < 2; dx++) {
+          if (x0 + dx >= o.w) break;
+          uint32_t v = q[dy][dx];
+          if (o.fmt == VFHIP_FORMAT_BGRA) v = (v & 0xff00ff00u) | ((v & 0xff) << 16) | ((v >> 16) & 0xff);
+          row[x0 + dx] = v;
+        }
+      }
+      return;
+    }
+    case VFHIP_FORMAT_NV12: case VFHIP_FORMAT_I420: {
+      float sr = 0.0f, sg = 0.0f, sb = 0.0f;
+#pragma unroll
+      for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+        for (int dx = 0; dx < 2; dx++) {
+          const F4 c = unpack_rgba8 (q[dy][dx]);
+          sr += c.r; sg += c.g; sb += c.b;
+          if (x0 + dx < o.w && y0 + dy < o.h) {
+            float y, u, v; rgb_to_yuv (c.r, c.g, c.b, o.m709, &y, &u, &v);
+            o.p[0][(size_t) (y0 + dy) * o.s[0] + x0 + dx] = (uint8_t) quant8 (y);
+          }
+        }
+      sr *= 0.25f; sg *= 0.25f; sb *= 0.25f;
+      float y, u, v; rgb_to_yuv (sr, sg, sb, o.m709, &y, &u, &v);
+      if (o.fmt == VFHIP_FORMAT_NV12) {
+        uint8_t *d = o.p[1] + (size_t) by * o.s[1] + 2 * bx;
+        d[0] = (uint8_t) quant8 (u); d[1] = (uint8_t) quant8 (v);
+      } else {
+        o.p[1][(size_t) by * o.s[1] + bx] = (uint8_t) quant8 (u);
+        o.p[2][(size_t) by * o.s[2] + bx] = (uint8_t) quant8 (v);
+      }
+      return;
+    }
+    default: {   // UYVY / YUY2: one macro-pixel per block row; an odd last column is dropped
+      if (bx >= o.w / 2) return;
+#pragma unroll
+      for (int dy = 0; dy < 2; dy++) {
+        if (y0 + dy >= o.h) break;
+        const F4 c0 = unpack_rgba8 (q[dy][0]), c1 = unpack_rgba8 (q[dy][1]);
+        float ya, ua, va, yb, ub, vb;
+        rgb_to_yuv (c0.r, c0.g, c0.b, o.m709, &ya, &ua, &va);
+        rgb_to_yuv (c1.r, c1.g, c1.b, o.m709, &yb, &ub, &vb);
+        const uint32_t U = quant8 ((ua + ub) * 0.5f), V = quant8 ((va + vb) * 0.5f), Y0 = quant8 (ya), Y1 = quant8 (yb);
+        uint32_t *d = reinterpret_cast<uint32_t *> (o.p[0] + (size_t) (y0 + dy) * o.s[0]) + bx;
+        *d = o.fmt == VFHIP_FORMAT_UYVY ? pack_rgba8 (U, Y0, V, Y1) : pack_rgba8 (Y0, U, Y1, V);
+      }
+      return;
+    }
+  }
+}
+
+}  // namespace metal
+}  // namespace vfhip

@@ -1,0 +1,179 @@
+"""vfhip.py — thin ctypes binding over libvfhip.so (include/vfhip.h) for tests, bench.py and Python users.
+
+It mirrors the reference's renderer objects one-to-one: a class per element with
+configure / process / cleanup, BOOL-style failures turned into VfHipError.  It contains NO compute:
+every pixel is produced by the HIP kernels in libvfhip.so, and importing this module fails loudly when
+the library is missing (there is no CPU fallback).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvfhip.so")
+
+FORMATS = {"BGRA": 0, "RGBA": 1, "NV12": 2, "I420": 3, "UYVY": 4, "YUY2": 5}
+MATRICES = {"bt601": 0, "bt709": 1, "bt2020": 2}
+CHROMA_SITES = {"jpeg": 0, "none": 0, "center": 0, "mpeg2": 1}
+METHODS = {"bilinear": 0, "nearest": 1}
+NUMERICS = {"gst-exact": 0, "metal": 1}
+FRAME_FLAG_TFF = 1
+
+
+class VfHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"vfhip error {code}: {msg}")
+        self.code = code
+
+
+class VideoInfo(C.Structure):
+    _fields_ = [("format", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("color_matrix", C.c_int32),
+                ("chroma_site", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class Frame(C.Structure):
+    _fields_ = [("info", VideoInfo), ("data", C.c_void_p * 4), ("stride", C.c_int32 * 4), ("flags", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make -C {_HERE}` (or __graft_entry__.build()); "
+                          "vfhip has no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    lib.vfhip_last_error_string.restype = C.c_char_p
+    for n in ("vfhip_pinned_alloc", "vfhip_device_malloc", "vfhip_convertscale_new"):
+        getattr(lib, n).restype = C.c_void_p
+    lib.vfhip_convertscale_kernel_name.restype = C.c_char_p
+    lib.vfhip_pinned_alloc.argtypes = [C.c_int, C.c_size_t]
+    lib.vfhip_pinned_free.argtypes = [C.c_void_p]
+    lib.vfhip_device_malloc.argtypes = [C.c_int, C.c_size_t]
+    lib.vfhip_device_free.argtypes = [C.c_int, C.c_void_p]
+    lib.vfhip_memcpy_h2d.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.vfhip_memcpy_d2h.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.vfhip_convertscale_configure.argtypes = [C.c_void_p, C.POINTER(VideoInfo), C.POINTER(VideoInfo), C.c_int, C.c_int,
+                                                 C.c_uint32, C.c_int]
+    lib.vfhip_convertscale_process.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(Frame)]
+    lib.vfhip_convertscale_process_device.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(Frame), C.c_void_p]
+    lib.vfhip_convertscale_process_device_batch.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(Frame), C.c_size_t,
+                                                            C.c_size_t, C.c_int, C.c_void_p]
+    for n in ("vfhip_convertscale_cleanup", "vfhip_convertscale_free", "vfhip_convertscale_kernel_name"):
+        getattr(lib, n).argtypes = [C.c_void_p]
+    return lib
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc < 0:
+        raise VfHipError(rc, lib.vfhip_last_error_string().decode(errors="replace"))
+    return rc
+
+
+def device_count():
+    return check(lib.vfhip_device_count())
+
+
+def device_name(device=0):
+    buf = C.create_string_buffer(256)
+    check(lib.vfhip_device_name(device, buf, 256))
+    return buf.value.decode()
+
+
+def make_info(fmt, w, h, colorimetry="bt601", chroma_site="jpeg"):
+    return VideoInfo(FORMATS[fmt], w, h, MATRICES[colorimetry], CHROMA_SITES[chroma_site])
+
+
+def r4(x):
+    return (x + 3) // 4 * 4
+
+
+def plane_layout(fmt, w, h):
+    """GstVideoInfo default layout -> [(offset, stride, rows)], total size."""
+    hp = (h + 1) // 2 * 2
+    if fmt in ("BGRA", "RGBA"):
+        return [(0, 4 * w, h)], 4 * w * h
+    if fmt in ("UYVY", "YUY2"):
+        s = r4(2 * w)
+        return [(0, s, h)], s * h
+    if fmt == "NV12":
+        s = r4(w)
+        return [(0, s, h), (s * hp, s, hp // 2)], s * hp + s * (hp // 2)
+    if fmt == "I420":
+        s, cs = r4(w), r4((w + 1) // 2)
+        uo = s * hp
+        vo = uo + cs * (hp // 2)
+        return [(0, s, h), (uo, cs, hp // 2), (vo, cs, hp // 2)], vo + cs * (hp // 2)
+    raise ValueError(fmt)
+
+
+def frame_from_base(info, fmt, w, h, base_ptr, flags=0, layout=None):
+    """Frame whose planes live at base_ptr + GstVideoInfo-default offsets (host or device pointer)."""
+    f = Frame()
+    f.info = info
+    f.flags = flags
+    pl, _ = layout or plane_layout(fmt, w, h)
+    for i, (off, stride, _rows) in enumerate(pl):
+        f.data[i] = base_ptr + off
+        f.stride[i] = stride
+    return f
+
+
+class ConvertScale:
+    """MetalConvertScaleRenderer equivalent (reference convertscale/metalconvertscalerenderer.h:35-50)."""
+
+    def __init__(self, device=-1):
+        self.h = lib.vfhip_convertscale_new(device)
+        if not self.h:
+            raise VfHipError(-6, lib.vfhip_last_error_string().decode(errors="replace"))
+        self.cfg = None
+
+    def configure(self, in_fmt, in_w, in_h, out_fmt, out_w, out_h, method="bilinear", add_borders=False,
+                  border_color=0xFF000000, numerics="gst-exact", colorimetry="bt601", chroma_site="jpeg",
+                  out_colorimetry=None):
+        self.in_info = make_info(in_fmt, in_w, in_h, colorimetry, chroma_site)
+        self.out_info = make_info(out_fmt, out_w, out_h, out_colorimetry or colorimetry, chroma_site)
+        check(lib.vfhip_convertscale_configure(self.h, C.byref(self.in_info), C.byref(self.out_info), METHODS[method],
+                                               int(add_borders), border_color, NUMERICS[numerics]))
+        self.cfg = (in_fmt, in_w, in_h, out_fmt, out_w, out_h)
+        return self
+
+    @property
+    def kernel_name(self):
+        return lib.vfhip_convertscale_kernel_name(self.h).decode()
+
+    def process(self, raw_in):
+        """raw_in: uint8 array in GstVideoInfo default layout (host). Returns the raw output frame (host)."""
+        in_fmt, in_w, in_h, out_fmt, out_w, out_h = self.cfg
+        raw_in = np.ascontiguousarray(raw_in, dtype=np.uint8)
+        _, in_size = plane_layout(in_fmt, in_w, in_h)
+        assert raw_in.size >= in_size, (raw_in.size, in_size)
+        _, out_size = plane_layout(out_fmt, out_w, out_h)
+        out = np.zeros(out_size, np.uint8)
+        fi = frame_from_base(self.in_info, in_fmt, in_w, in_h, raw_in.ctypes.data)
+        fo = frame_from_base(self.out_info, out_fmt, out_w, out_h, out.ctypes.data)
+        check(lib.vfhip_convertscale_process(self.h, C.byref(fi), C.byref(fo)))
+        return out
+
+    def process_device(self, in_ptr, out_ptr, stream=None, n_frames=1, in_pitch=0, out_pitch=0, in_layout=None, out_layout=None):
+        in_fmt, in_w, in_h, out_fmt, out_w, out_h = self.cfg
+        fi = frame_from_base(self.in_info, in_fmt, in_w, in_h, in_ptr, layout=in_layout)
+        fo = frame_from_base(self.out_info, out_fmt, out_w, out_h, out_ptr, layout=out_layout)
+        check(lib.vfhip_convertscale_process_device_batch(self.h, C.byref(fi), C.byref(fo), in_pitch, out_pitch, n_frames,
+                                                          stream))
+
+    def cleanup(self):
+        lib.vfhip_convertscale_cleanup(self.h)
+
+    def close(self):
+        if self.h:
+            lib.vfhip_convertscale_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

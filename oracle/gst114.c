@@ -7,7 +7,7 @@
  * on Linux, and its own tests pin no pixel values.
  *
  * PINNED: every rule below was checked byte-for-byte against the real GStreamer 1.14.0 elements in
- * the build container (tools/gen_goldens.py regenerates tests/golden/*.npz from them; the not-gpu
+ * the build container (tools/gen_goldens.py regenerates tests/golden npz files from them; the not-gpu
  * test-suite replays those fixtures through this file).  Rules (SURVEY.md §8c "Pinned arithmetic"):
  *   1. chroma 4:2:0 -> 4:4:4: horizontal then vertical, edge replicated, integer shifts;
  *   2. ORC AYUV->ARGB matrix with mulhs() on byte-splatted int16 samples;
@@ -75,6 +75,7 @@ int gst114_yuv420_to_rgb (const uint8_t *yp, int ys, const uint8_t *up, int us, 
   int ro = out_format == GST114_RGBA ? 0 : 2, bo = 2 - ro;
   uint8_t *hu = malloc ((size_t) ch * w), *hv = malloc ((size_t) ch * w);
   if (!hu || !hv) { free (hu); free (hv); return -2; }
+#pragma omp parallel for schedule(static)
   for (int j = 0; j < ch; j++) {
     if (planar) {
       for (int x = 0; x < w; x++) { hu[(size_t) j * w + x] = up[(size_t) j * us + (x >> 1)]; hv[(size_t) j * w + x] = vp[(size_t) j * vs + (x >> 1)]; }
@@ -83,6 +84,7 @@ int gst114_yuv420_to_rgb (const uint8_t *yp, int ys, const uint8_t *up, int us, 
       upsample_h (up + (size_t) j * us + 1, 2, cw, w, cosited, hv + (size_t) j * w);
     }
   }
+#pragma omp parallel for schedule(static)
   for (int y = 0; y < h; y++) {
     int j = y >> 1;
     int jn = (y & 1) ? clampi (j + 1, 0, ch - 1) : clampi (j - 1, 0, ch - 1);
@@ -128,6 +130,7 @@ int gst114_nearest_index (int in, int out, int j)
 
 static void vscale (const uint8_t *in, int is, int w, int h, uint8_t *out, int os, int oh)
 {
+#pragma omp parallel for schedule(static)
   for (int y = 0; y < oh; y++) {
     int i0, i1, wt; gst114_vtaps (h, oh, y, &i0, &i1, &wt);
     const uint8_t *s1 = in + (size_t) i0 * is, *s2 = in + (size_t) i1 * is;
@@ -139,6 +142,7 @@ static void vscale (const uint8_t *in, int is, int w, int h, uint8_t *out, int o
 static void hscale (const uint8_t *in, int is, int w, int h, uint8_t *out, int os, int ow)
 {
   uint32_t inc = gst114_hinc (w, ow);
+#pragma omp parallel for schedule(static)
   for (int y = 0; y < h; y++) {
     const uint8_t *s = in + (size_t) y * is; uint8_t *o = out + (size_t) y * os;
     for (int x = 0; x < ow; x++) {
@@ -153,6 +157,7 @@ int gst114_scale_4u8 (const uint8_t *in, int is, int w, int h, uint8_t *out, int
 {
   if (w <= 0 || h <= 0 || ow <= 0 || oh <= 0) return -1;
   if (method == GST114_NEAREST) {
+#pragma omp parallel for schedule(static)
     for (int y = 0; y < oh; y++) {
       int sy = gst114_nearest_index (h, oh, y);
       for (int x = 0; x < ow; x++) {

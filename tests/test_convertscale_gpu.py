@@ -1,0 +1,168 @@
+"""GPU parity tests of vfhipconvertscale through the C ABI (libvfhip.so), gst-exact numerics.
+
+  * every golden vector made by the real GStreamer 1.14 elements (tests/golden, bit-exact);
+  * seeded random frames against the CPU oracle (oracle/gst114.c), incl. ragged / tiny / odd sizes;
+  * BASELINE sizes (2160p -> 1080p batches) through size-independent properties.
+Bar: bit-exact (integer path)."""
+import numpy as np
+import pytest
+
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+MANIFEST, Z = oracle_lib.load_golden()
+
+
+def run(vfhip, c_in_fmt, w, h, raw, col, site, method, ofmt, ow, oh, numerics="gst-exact"):
+    if col is None:
+        col, site = oracle_lib.default_colorimetry(h)
+    cs = vfhip.ConvertScale(0)
+    cs.configure(c_in_fmt, w, h, ofmt, ow, oh, method=method, colorimetry=col, chroma_site=site, numerics=numerics)
+    out = cs.process(raw)
+    name = cs.kernel_name
+    cs.close()
+    return out.reshape(oh, ow, 4), name
+
+
+@pytest.mark.parametrize("case", MANIFEST, ids=[c["name"] for c in MANIFEST])
+def test_golden_gstreamer_vectors(vfhip, case):
+    c = case
+    got, kname = run(vfhip, c["in_format"], c["w"], c["h"], Z[c["name"] + "_in"], c["colorimetry"], c["chroma_site"],
+                     c["method"], c["out_format"], c["ow"], c["oh"])
+    want = Z[c["name"] + "_out"].reshape(c["oh"], c["ow"], 4)
+    assert np.array_equal(got, want), f"{kname}: max diff {np.abs(got.astype(int) - want.astype(int)).max()}"
+    if c["name"] == "c2_vts_2160_to_1080":
+        assert kname == "k_cs_nv12_half"          # the headline config must take the fast path
+
+
+HALF_CASES = [(64, 36), (8, 6), (16, 8), (1024, 40), (200, 72), (3840, 64), (520, 34)]
+
+
+@pytest.mark.parametrize("w,h", HALF_CASES)
+@pytest.mark.parametrize("col,site", [("bt601", "jpeg"), ("bt709", "mpeg2"), ("bt2020", "mpeg2"), ("bt2020", "jpeg")])
+@pytest.mark.parametrize("ofmt", ["BGRA", "RGBA"])
+def test_half_kernel_vs_oracle(vfhip, oracle, w, h, col, site, ofmt):
+    rng = np.random.default_rng(w * 1000 + h)
+    _, size = vfhip.plane_layout("NV12", w, h)
+    raw = rng.integers(0, 256, size, dtype=np.uint8)
+    got, kname = run(vfhip, "NV12", w, h, raw, col, site, "bilinear", ofmt, w // 2, h // 2)
+    assert kname == "k_cs_nv12_half"
+    want = oracle.convertscale("NV12", w, h, raw, col, site, "bilinear", ofmt, w // 2, h // 2)
+    assert np.array_equal(got, want), f"max diff {np.abs(got.astype(int) - want.astype(int)).max()}"
+
+
+def test_extreme_values_half_kernel(vfhip, oracle):
+    """saturation paths of the ORC matrix: all-0, all-255 and alternating extremes"""
+    w, h = 64, 16
+    _, size = vfhip.plane_layout("NV12", w, h)
+    for fill in (0, 255, None):
+        raw = np.full(size, fill, np.uint8) if fill is not None else np.tile(np.array([0, 255, 255, 0, 16, 235, 240, 1], np.uint8), size // 8 + 1)[:size]
+        for col in ("bt601", "bt709", "bt2020"):
+            got, _ = run(vfhip, "NV12", w, h, raw, col, "mpeg2", "bilinear", "BGRA", w // 2, h // 2)
+            want = oracle.convertscale("NV12", w, h, raw, col, "mpeg2", "bilinear", "BGRA", w // 2, h // 2)
+            assert np.array_equal(got, want)
+
+
+def test_yuv_cube_sweep(vfhip, oracle):
+    """every (Y, U, V) on a 16-step lattice + the limits, same-size conversion (generic kernel)"""
+    vals = np.array(sorted(set(list(range(0, 256, 15)) + [16, 128, 235, 240, 255])), np.uint8)
+    n = len(vals)
+    w, h = 2 * n * n, 2 * n          # chroma sample (j,k): U=vals[k%n], V=vals[k//n]; luma row pair j: Y=vals[j]
+    ys, hp = vfhip.r4(w), h
+    raw = np.zeros(ys * hp + ys * (hp // 2), np.uint8)
+    y = raw[:ys * h].reshape(h, ys)
+    uv = raw[ys * hp:].reshape(hp // 2, ys)
+    for j in range(n):
+        y[2 * j:2 * j + 2, :w] = vals[j]
+        uv[j, 0:w:2] = np.tile(vals, n)
+        uv[j, 1:w:2] = np.repeat(vals, n)
+    for col in ("bt601", "bt709", "bt2020"):
+        for fmt in ("NV12",):
+            got, _ = run(vfhip, fmt, w, h, raw, col, "jpeg", "bilinear", "BGRA", w, h)
+            want = oracle.convertscale(fmt, w, h, raw, col, "jpeg", "bilinear", "BGRA", w, h)
+            assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_sizes_vs_oracle(vfhip, oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    fmt = ["NV12", "I420"][seed % 2]
+    w, h, ow, oh = (int(v) for v in rng.integers(1, 200, 4))
+    w, h = max(w, 2), max(h, 2)
+    col = ["bt601", "bt709", "bt2020"][seed % 3]
+    site = ["jpeg", "mpeg2"][(seed // 3) % 2]
+    method = "nearest" if seed % 5 == 4 else "bilinear"
+    _, size = vfhip.plane_layout(fmt, w, h)
+    raw = rng.integers(0, 256, size, dtype=np.uint8)
+    got, _ = run(vfhip, fmt, w, h, raw, col, site, method, "BGRA", ow, oh)
+    want = oracle.convertscale(fmt, w, h, raw, col, site, method, "BGRA", ow, oh)
+    assert np.array_equal(got, want), (fmt, w, h, ow, oh, col, site, method)
+
+
+def test_rgb_to_rgb_scale_and_swizzle(vfhip, oracle):
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    for (w, h, ow, oh, method) in [(48, 40, 20, 37, "bilinear"), (48, 40, 96, 38, "bilinear"), (200, 8, 100, 4, "nearest"), (33, 17, 33, 17, "bilinear")]:
+        src = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        want = np.zeros((oh, ow, 4), np.uint8)
+        rc = oracle.lib.gst114_scale_4u8(C.c_void_p(src.ctypes.data), 4 * w, w, h, C.c_void_p(want.ctypes.data), 4 * ow, ow, oh,
+                                         1 if method == "nearest" else 0)
+        assert rc == 0
+        got, _ = run(vfhip, "BGRA", w, h, src.reshape(-1), "bt601", "jpeg", method, "BGRA", ow, oh)
+        assert np.array_equal(got, want)
+        got, _ = run(vfhip, "BGRA", w, h, src.reshape(-1), "bt601", "jpeg", method, "RGBA", ow, oh)
+        assert np.array_equal(got, want[..., [2, 1, 0, 3]])
+
+
+def test_full_size_batch_properties(vfhip, oracle):
+    """BASELINE config 1 shape (2160p -> 1080p), a batch of device-resident frames:
+    (1) frame k of a batch == the same frame processed alone; (2) a constant frame maps to a constant frame equal
+    to the oracle's single-pixel answer; (3) rows 0..63 of a random frame match the oracle run on the top slice
+    (the scale is local: output row y depends on source rows 2y, 2y+1 and chroma rows y-1..y+1)."""
+    import torch
+    w, h, ow, oh, n = 3840, 2160, 1920, 1080, 3
+    lay, size = vfhip.plane_layout("NV12", w, h)
+    pitch = (size + 255) // 256 * 256
+    opitch = ow * oh * 4
+    g = torch.Generator(device="cpu").manual_seed(7)
+    host = torch.randint(0, 256, (n, pitch), dtype=torch.uint8, generator=g)
+    host[1, :size] = 77                      # constant frame
+    dev_in = host.cuda()
+    dev_out = torch.zeros((n, opitch), dtype=torch.uint8, device="cuda")
+    cs = vfhip.ConvertScale(0)
+    cs.configure("NV12", w, h, "BGRA", ow, oh, colorimetry="bt2020", chroma_site="mpeg2")
+    assert cs.kernel_name == "k_cs_nv12_half"
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        cs.process_device(dev_in.data_ptr(), dev_out.data_ptr(), stream=s.cuda_stream, n_frames=n, in_pitch=pitch, out_pitch=opitch)
+    s.synchronize()
+    out = dev_out.cpu().numpy().reshape(n, oh, ow, 4)
+    # (1)
+    single = cs.process(host[2, :size].numpy()).reshape(oh, ow, 4)
+    assert np.array_equal(single, out[2])
+    # (2)
+    const_raw = np.full(vfhip.plane_layout("NV12", 8, 8)[1], 77, np.uint8)
+    px = oracle.convertscale("NV12", 8, 8, const_raw, "bt2020", "mpeg2", "bilinear", "BGRA", 4, 4)[0, 0]
+    assert (out[1] == px).all()
+    # (3) top slice: 136 source rows -> 68 output rows; compare the first 64 (the slice's bottom edge clamps differently)
+    hs = 136
+    ys = lay[0][1]
+    top = np.concatenate([host[0, :ys * hs].numpy(), host[0, lay[1][0]: lay[1][0] + ys * (hs // 2)].numpy()])
+    want = oracle.convertscale("NV12", w, hs, top, "bt2020", "mpeg2", "bilinear", "BGRA", ow, hs // 2)
+    assert np.array_equal(out[0, :64], want[:64])
+    cs.close()
+
+
+def test_error_behaviour(vfhip):
+    import ctypes as C
+    cs = vfhip.ConvertScale(0)
+    fi, fo = vfhip.Frame(), vfhip.Frame()
+    assert vfhip.lib.vfhip_convertscale_process(cs.h, C.byref(fi), C.byref(fo)) == -3      # NOT_CONFIGURED
+    with pytest.raises(vfhip.VfHipError):
+        cs.configure("NV12", 0, 10, "BGRA", 10, 10)
+    cs.configure("NV12", 16, 16, "BGRA", 8, 8)
+    bad = vfhip.frame_from_base(vfhip.make_info("NV12", 32, 16), "NV12", 32, 16, 0)
+    assert vfhip.lib.vfhip_convertscale_process(cs.h, C.byref(bad), C.byref(fo)) == -1        # caps mismatch
+    cs.cleanup()
+    assert vfhip.lib.vfhip_convertscale_process(cs.h, C.byref(fi), C.byref(fo)) == -3
+    cs.close()
