@@ -38,6 +38,13 @@ class Frame(C.Structure):
 
 
 def _load():
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7; two HIP runtimes in one process do not share
+    # devices ("No HIP GPUs are available").  Import torch first (when present) so that libvfhip binds to the
+    # runtime already loaded; stand-alone users (the GStreamer plugin) get /opt/rocm's via RUNPATH.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `make -C {_HERE}` (or __graft_entry__.build()); "
                           "vfhip has no CPU fallback")
