@@ -122,23 +122,27 @@ __device__ __forceinline__ CRow load_crow (const uint8_t *row, int cg, int cgpr)
   return c;
 }
 
-template <bool RGBA>
-__device__ __forceinline__ void half_row_pixels (uint2 y, uint32_t e01, uint32_t e23, uint32_t o01, uint32_t o23,
-    const int *c, int bias, uint32_t px_even[4], uint32_t px_odd[4])
+// v_dot4_u32_u8 through the builtin, NOT inline asm: DOT results need 3 wait states before a different VALU
+// reads them on gfx940/gfx950, and hipcc pads hazards only for instructions it models (an asm dot4 followed by
+// v_perm returned stale bytes — found by the parity tests).
+__device__ __forceinline__ uint32_t dot4_u8 (uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4 (a, b, c, false); }
+
+// One output pixel's two source pixels of one source row: even column (chroma `uve`) and odd column (`uvo`);
+// `ys` = [ye ye yo yo] byte-splatted luma (already ^0x80), uve/uvo = [U U V V] (already ^0x80).
+// Produces planar byte pairs [X_even, X_odd] per channel (low 16 bits), saturated to u8.
+__device__ __forceinline__ void orc_pair (uint32_t ys, uint32_t uve, uint32_t uvo, const int *c, int bias,
+    uint32_t &bb, uint32_t &gg, uint32_t &rr)
 {
-  const uint32_t yx0 = y.x ^ 0x80808080u, yx1 = y.y ^ 0x80808080u;
-  const uint32_t ys0 = perm_b32 (0u, yx0, 0x01010000u), ys1 = perm_b32 (0u, yx0, 0x03030202u);   // cols 0,1 | 2,3
-  const uint32_t ys2 = perm_b32 (0u, yx1, 0x01010000u), ys3 = perm_b32 (0u, yx1, 0x03030202u);   // cols 4,5 | 6,7
-  e01 ^= 0x80808080u; e23 ^= 0x80808080u; o01 ^= 0x80808080u; o23 ^= 0x80808080u;
-  // output pixel n uses source columns 2n (even, chroma e) and 2n+1 (odd, chroma o)
-  px_even[0] = orc_pixel<0, RGBA> (ys0, perm_b32 (0u, e01, 0x01010000u), c[0], c[1], c[2], c[3], c[4], bias);
-  px_odd[0]  = orc_pixel<1, RGBA> (ys0, perm_b32 (0u, o01, 0x01010000u), c[0], c[1], c[2], c[3], c[4], bias);
-  px_even[1] = orc_pixel<0, RGBA> (ys1, perm_b32 (0u, e01, 0x03030202u), c[0], c[1], c[2], c[3], c[4], bias);
-  px_odd[1]  = orc_pixel<1, RGBA> (ys1, perm_b32 (0u, o01, 0x03030202u), c[0], c[1], c[2], c[3], c[4], bias);
-  px_even[2] = orc_pixel<0, RGBA> (ys2, perm_b32 (0u, e23, 0x01010000u), c[0], c[1], c[2], c[3], c[4], bias);
-  px_odd[2]  = orc_pixel<1, RGBA> (ys2, perm_b32 (0u, o23, 0x01010000u), c[0], c[1], c[2], c[3], c[4], bias);
-  px_even[3] = orc_pixel<0, RGBA> (ys3, perm_b32 (0u, e23, 0x03030202u), c[0], c[1], c[2], c[3], c[4], bias);
-  px_odd[3]  = orc_pixel<1, RGBA> (ys3, perm_b32 (0u, o23, 0x03030202u), c[0], c[1], c[2], c[3], c[4], bias);
+  const int wye = mad_i32_i16<0> (ys, c[0], bias) & (int) 0xffff0000;
+  const int wyo = mad_i32_i16<1> (ys, c[0], bias) & (int) 0xffff0000;
+  const int tre = mad_i32_i16<1> (uve, c[1], wye), tro = mad_i32_i16<1> (uvo, c[1], wyo);
+  const int tbe = mad_i32_i16<0> (uve, c[2], wye), tbo = mad_i32_i16<0> (uvo, c[2], wyo);
+  const int tge = mad_i32_i16<1> (uve, c[4], mad_i32_i16<0> (uve, c[3], wye) & (int) 0xffff0000);
+  const int tgo = mad_i32_i16<1> (uvo, c[4], mad_i32_i16<0> (uvo, c[3], wyo) & (int) 0xffff0000);
+  // [even.hi16 | odd.hi16] -> saturate both int16 to u8 -> bytes [even, odd]
+  bb = sat_pk_u8_i16 (perm_b32 ((uint32_t) tbo, (uint32_t) tbe, 0x07060302u));
+  gg = sat_pk_u8_i16 (perm_b32 ((uint32_t) tgo, (uint32_t) tge, 0x07060302u));
+  rr = sat_pk_u8_i16 (perm_b32 ((uint32_t) tro, (uint32_t) tre, 0x07060302u));
 }
 
 // grid: x = ceil(cgpr * strips / 256), y = frames.  cgpr = out_w / 4 column groups per row.
@@ -158,35 +162,51 @@ __global__ __launch_bounds__ (256) void k_cs_nv12_half (const CsParams p)
   const int c[5] = { p.c[0], p.c[1], p.c[2], p.c[3], p.c[4] };
   const int bias = 128 << 16;
 
-  // horizontal tap weights of this lane's 4 output pixels (row independent)
-  uint32_t f2[4], wf2[4];
+  // horizontal tap weights of this lane's 4 output pixels (row independent): bytes [255-f, f, 0, 0]
+  uint32_t wgt[4];
 #pragma unroll
   for (int n = 0; n < 4; n++) {
-    uint32_t tt = (uint32_t) (cg * 4 + n) * p.hinc;
-    uint32_t f = (tt >> 8) & 0xffu;
-    f2[n] = f | (f << 16);
-    wf2[n] = 0x01000100u - f2[n];
+    const uint32_t tt = (uint32_t) (cg * 4 + n) * p.hinc;
+    const uint32_t f = (tt >> 8) & 0xffu;
+    wgt[n] = (255u - f) | (f << 8);
   }
 
   CRow hm = load_crow<COSITED> (uvp + (size_t) max (y0 - 1, 0) * p.is[1], cg, cgpr);
   CRow hc = load_crow<COSITED> (uvp + (size_t) y0 * p.is[1], cg, cgpr);
+  // floor-average of chroma rows (j-1, j): the inner half of (3a+b+2)>>2; the (j, j+1) one is reused next row
+  CRow mid_up = { lerp_u8 (hc.e01, hm.e01, 0u), lerp_u8 (hc.e23, hm.e23, 0u), lerp_u8 (hc.o01, hm.o01, 0u), lerp_u8 (hc.o23, hm.o23, 0u) };
   const int yend = min (y0 + ROWS, p.out_h);
   for (int y = y0; y < yend; y++) {
     const CRow hn = load_crow<COSITED> (uvp + (size_t) min (y + 1, ch - 1) * p.is[1], cg, cgpr);
     const uint2 yt = *reinterpret_cast<const uint2 *> (yp + (size_t) (2 * y) * p.is[0] + 8 * (size_t) cg);
     const uint2 yb = *reinterpret_cast<const uint2 *> (yp + (size_t) (2 * y + 1) * p.is[0] + 8 * (size_t) cg);
-    uint32_t te[4], to[4], be[4], bo[4];
-    // vertical chroma filter: source row 2y leans on chroma row y-1, row 2y+1 on chroma row y+1
-    half_row_pixels<RGBA> (yt, filt31_u8 (hc.e01, hm.e01), filt31_u8 (hc.e23, hm.e23), filt31_u8 (hc.o01, hm.o01), filt31_u8 (hc.o23, hm.o23), c, bias, te, to);
-    half_row_pixels<RGBA> (yb, filt31_u8 (hc.e01, hn.e01), filt31_u8 (hc.e23, hn.e23), filt31_u8 (hc.o01, hn.o01), filt31_u8 (hc.o23, hn.o23), c, bias, be, bo);
-    uint4 o;
-    // vertical 2-tap with w = 128: s1 + (((s2-s1)*128+128)>>8) == (s1+s2+1)>>1; then the horizontal 2-tap
-    o.x = hlerp_px (avg_rnd_u8 (te[0], be[0]), avg_rnd_u8 (to[0], bo[0]), f2[0], wf2[0]);
-    o.y = hlerp_px (avg_rnd_u8 (te[1], be[1]), avg_rnd_u8 (to[1], bo[1]), f2[1], wf2[1]);
-    o.z = hlerp_px (avg_rnd_u8 (te[2], be[2]), avg_rnd_u8 (to[2], bo[2]), f2[2], wf2[2]);
-    o.w = hlerp_px (avg_rnd_u8 (te[3], be[3]), avg_rnd_u8 (to[3], bo[3]), f2[3], wf2[3]);
-    *reinterpret_cast<uint4 *> (op + (size_t) y * p.os + 16 * (size_t) cg) = o;
-    hm = hc; hc = hn;
+    const CRow mid_dn = { lerp_u8 (hc.e01, hn.e01, 0u), lerp_u8 (hc.e23, hn.e23, 0u), lerp_u8 (hc.o01, hn.o01, 0u), lerp_u8 (hc.o23, hn.o23, 0u) };
+    const uint32_t K1 = 0x01010101u, X = 0x80808080u;
+    // vertical chroma filter (3a+b+2)>>2: source row 2y leans on chroma row y-1, row 2y+1 on chroma row y+1
+    const uint32_t te01 = lerp_u8 (hc.e01, mid_up.e01, K1) ^ X, te23 = lerp_u8 (hc.e23, mid_up.e23, K1) ^ X;
+    const uint32_t to01 = lerp_u8 (hc.o01, mid_up.o01, K1) ^ X, to23 = lerp_u8 (hc.o23, mid_up.o23, K1) ^ X;
+    const uint32_t be01 = lerp_u8 (hc.e01, mid_dn.e01, K1) ^ X, be23 = lerp_u8 (hc.e23, mid_dn.e23, K1) ^ X;
+    const uint32_t bo01 = lerp_u8 (hc.o01, mid_dn.o01, K1) ^ X, bo23 = lerp_u8 (hc.o23, mid_dn.o23, K1) ^ X;
+    const uint32_t yt0 = yt.x ^ X, yt1 = yt.y ^ X, yb0 = yb.x ^ X, yb1 = yb.y ^ X;
+    uint32_t out[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+      const uint32_t sy = (n & 1) ? 0x03030202u : 0x01010000u;       // luma bytes (2n, 2n+1) of the row's 8
+      const uint32_t su = (n & 1) ? 0x03030202u : 0x01010000u;       // chroma pair n within its dword
+      const uint32_t ytn = n < 2 ? yt0 : yt1, ybn = n < 2 ? yb0 : yb1;
+      const uint32_t ten = n < 2 ? te01 : te23, ton = n < 2 ? to01 : to23, ben = n < 2 ? be01 : be23, bon = n < 2 ? bo01 : bo23;
+      uint32_t bt, gt, rt, bbm, gbm, rbm;
+      orc_pair (perm_b32 (0u, ytn, sy), perm_b32 (0u, ten, su), perm_b32 (0u, ton, su), c, bias, bt, gt, rt);
+      orc_pair (perm_b32 (0u, ybn, sy), perm_b32 (0u, ben, su), perm_b32 (0u, bon, su), c, bias, bbm, gbm, rbm);
+      // vertical 2-tap, w = 128: s1 + (((s2-s1)*128+128)>>8) == (s1+s2+1)>>1 on the [even, odd] byte pairs
+      const uint32_t vb = avg_rnd_u8 (bt, bbm), vg = avg_rnd_u8 (gt, gbm), vr = avg_rnd_u8 (rt, rbm);
+      // horizontal 2-tap: (e*(256-f) + o*f) >> 8 = (e*(255-f) + o*f + e) >> 8
+      const uint32_t hb = dot4_u8 (vb, wgt[n], vb & 0xffu), hg = dot4_u8 (vg, wgt[n], vg & 0xffu), hr = dot4_u8 (vr, wgt[n], vr & 0xffu);
+      const uint32_t lo = RGBA ? perm_b32 (hg, hr, 0x0c0c0501u) : perm_b32 (hg, hb, 0x0c0c0501u);      // [X>>8, G>>8, -, -]
+      out[n] = perm_b32 (RGBA ? hb : hr, lo, 0x0d050100u);                                               // [X, G, Z, 0xff]
+    }
+    *reinterpret_cast<uint4 *> (op + (size_t) y * p.os + 16 * (size_t) cg) = make_uint4 (out[0], out[1], out[2], out[3]);
+    hm = hc; hc = hn; mid_up = mid_dn;
   }
 }
 
