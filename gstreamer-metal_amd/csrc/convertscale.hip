@@ -8,6 +8,7 @@
 #include "convertscale_kernels.h"
 #include "convertscale_metal_kernels.h"
 #include <cmath>
+#include <cstdlib>
 
 using namespace vfhip;
 
@@ -220,8 +221,10 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
     const size_t waves16 = (size_t) (p.out_w / 4) * ((p.out_h + 15) / 16) * n_frames / 64;
     const size_t waves8 = (size_t) (p.out_w / 4) * ((p.out_h + 7) / 8) * n_frames / 64;
     const size_t want = (size_t) h->dev->n_cu * 16;
-    if (waves16 >= want) launch_half<16> (p, n_frames, s);
-    else if (waves8 >= want) launch_half<8> (p, n_frames, s);
+    int rows = waves16 >= want ? 16 : (waves8 >= want ? 8 : 4);
+    if (const char *e = getenv ("VFHIP_HALF_ROWS")) { const int r = atoi (e); if (r == 4 || r == 8 || r == 16) rows = r; }   // tuning knob
+    if (rows == 16) launch_half<16> (p, n_frames, s);
+    else if (rows == 8) launch_half<8> (p, n_frames, s);
     else launch_half<4> (p, n_frames, s);
   } else {
     dim3 grid ((unsigned) ((p.out_w + 63) / 64), (unsigned) ((p.out_h + 3) / 4), (unsigned) n_frames);

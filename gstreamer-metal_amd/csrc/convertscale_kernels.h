@@ -101,21 +101,35 @@ __device__ __forceinline__ uint32_t hlerp_px (uint32_t a, uint32_t b, uint32_t f
 // ------------------------------------------------------------------------------------------------
 struct CRow { uint32_t e01, e23, o01, o23; };   // horizontally up-sampled chroma of 8 source columns: even / odd columns
 
+struct CRaw { uint2 v; uint32_t right, left; };      // raw chroma bytes of one row: 4 samples + right / left neighbour pair
+
 template <bool COSITED>
-__device__ __forceinline__ CRow load_crow (const uint8_t *row, int cg, int cgpr)
+__device__ __forceinline__ CRaw load_craw (const uint8_t *row, int cg, int cgpr)
 {
-  const uint2 v = *reinterpret_cast<const uint2 *> (row + 8 * (size_t) cg);      // [U0V0U1V1][U2V2U3V3]
-  uint32_t right = (cg == cgpr - 1) ? (v.y >> 16) : *reinterpret_cast<const uint16_t *> (row + 8 * (size_t) cg + 8);
-  uint32_t r01 = alignbyte (v.y, v.x, 2);          // [U1V1U2V2]
-  uint32_t r23 = alignbyte (right, v.y, 2);        // [U3V3U4V4]
+  CRaw r;
+  r.v = *reinterpret_cast<const uint2 *> (row + 8 * (size_t) cg);                 // [U0V0U1V1][U2V2U3V3]
+  // neighbour chroma pairs, edge-replicated WITHOUT a branch (a divergent branch here forces vmcnt(0) and
+  // serialises the software pipeline): the last / first lane of a row re-reads its own outer pair
+  r.right = *reinterpret_cast<const uint16_t *> (row + 8 * (size_t) cg + (cg == cgpr - 1 ? 6 : 8));
+  r.left = 0;
+  if (!COSITED) r.left = *reinterpret_cast<const uint16_t *> (row + 8 * (size_t) cg - (cg == 0 ? 0 : 2));
+  return r;
+}
+
+// horizontal chroma up-sampling of one row (GStreamer: horizontal first, then vertical)
+template <bool COSITED>
+__device__ __forceinline__ CRow hfilter (const CRaw &r)
+{
+  const uint2 v = r.v;
+  const uint32_t r01 = alignbyte (v.y, v.x, 2);          // [U1V1U2V2]
+  const uint32_t r23 = alignbyte (r.right, v.y, 2);      // [U3V3U4V4]
   CRow c;
   if (COSITED) {
     c.e01 = v.x; c.e23 = v.y;
     c.o01 = avg_rnd_u8 (v.x, r01); c.o23 = avg_rnd_u8 (v.y, r23);
   } else {
-    uint32_t left = (cg == 0) ? (v.x & 0xffffu) : *reinterpret_cast<const uint16_t *> (row + 8 * (size_t) cg - 2);
-    uint32_t l01 = (v.x << 16) | left;             // [U-1V-1U0V0]
-    uint32_t l23 = alignbyte (v.y, v.x, 2);        // [U1V1U2V2]
+    const uint32_t l01 = (v.x << 16) | r.left;           // [U-1V-1U0V0]
+    const uint32_t l23 = r01;                            // [U1V1U2V2]
     c.e01 = filt31_u8 (v.x, l01); c.e23 = filt31_u8 (v.y, l23);
     c.o01 = filt31_u8 (v.x, r01); c.o23 = filt31_u8 (v.y, r23);
   }
@@ -147,7 +161,7 @@ __device__ __forceinline__ void orc_pair (uint32_t ys, uint32_t uve, uint32_t uv
 
 // grid: x = ceil(cgpr * strips / 256), y = frames.  cgpr = out_w / 4 column groups per row.
 template <int ROWS, bool COSITED, bool RGBA>
-__global__ __launch_bounds__ (256) void k_cs_nv12_half (const CsParams p)
+__global__ __launch_bounds__ (256, 8) void k_cs_nv12_half (const CsParams p)
 {
   const int cgpr = p.out_w >> 2;
   const int strips = (p.out_h + ROWS - 1) / ROWS;
@@ -171,15 +185,25 @@ __global__ __launch_bounds__ (256) void k_cs_nv12_half (const CsParams p)
     wgt[n] = (255u - f) | (f << 8);
   }
 
-  CRow hm = load_crow<COSITED> (uvp + (size_t) max (y0 - 1, 0) * p.is[1], cg, cgpr);
-  CRow hc = load_crow<COSITED> (uvp + (size_t) y0 * p.is[1], cg, cgpr);
+  const int yend = min (y0 + ROWS, p.out_h);
+  CRow hm = hfilter<COSITED> (load_craw<COSITED> (uvp + (size_t) max (y0 - 1, 0) * p.is[1], cg, cgpr));
+  CRow hc = hfilter<COSITED> (load_craw<COSITED> (uvp + (size_t) y0 * p.is[1], cg, cgpr));
   // floor-average of chroma rows (j-1, j): the inner half of (3a+b+2)>>2; the (j, j+1) one is reused next row
   CRow mid_up = { lerp_u8 (hc.e01, hm.e01, 0u), lerp_u8 (hc.e23, hm.e23, 0u), lerp_u8 (hc.o01, hm.o01, 0u), lerp_u8 (hc.o23, hm.o23, 0u) };
-  const int yend = min (y0 + ROWS, p.out_h);
+  // software pipeline: the loads of row y+1 are issued before row y is computed (registers as the double buffer)
+  CRaw nraw = load_craw<COSITED> (uvp + (size_t) min (y0 + 1, ch - 1) * p.is[1], cg, cgpr);
+  uint2 nyt = *reinterpret_cast<const uint2 *> (yp + (size_t) (2 * y0) * p.is[0] + 8 * (size_t) cg);
+  uint2 nyb = *reinterpret_cast<const uint2 *> (yp + (size_t) (2 * y0 + 1) * p.is[0] + 8 * (size_t) cg);
   for (int y = y0; y < yend; y++) {
-    const CRow hn = load_crow<COSITED> (uvp + (size_t) min (y + 1, ch - 1) * p.is[1], cg, cgpr);
-    const uint2 yt = *reinterpret_cast<const uint2 *> (yp + (size_t) (2 * y) * p.is[0] + 8 * (size_t) cg);
-    const uint2 yb = *reinterpret_cast<const uint2 *> (yp + (size_t) (2 * y + 1) * p.is[0] + 8 * (size_t) cg);
+    const CRaw craw = nraw;
+    const uint2 yt = nyt, yb = nyb;
+    {
+      const int yn = min (y + 1, yend - 1);              // last iteration re-reads its own rows (never out of bounds)
+      nraw = load_craw<COSITED> (uvp + (size_t) min (yn + 1, ch - 1) * p.is[1], cg, cgpr);
+      nyt = *reinterpret_cast<const uint2 *> (yp + (size_t) (2 * yn) * p.is[0] + 8 * (size_t) cg);
+      nyb = *reinterpret_cast<const uint2 *> (yp + (size_t) (2 * yn + 1) * p.is[0] + 8 * (size_t) cg);
+    }
+    const CRow hn = hfilter<COSITED> (craw);
     const CRow mid_dn = { lerp_u8 (hc.e01, hn.e01, 0u), lerp_u8 (hc.e23, hn.e23, 0u), lerp_u8 (hc.o01, hn.o01, 0u), lerp_u8 (hc.o23, hn.o23, 0u) };
     const uint32_t K1 = 0x01010101u, X = 0x80808080u;
     // vertical chroma filter (3a+b+2)>>2: source row 2y leans on chroma row y-1, row 2y+1 on chroma row y+1
