@@ -1,0 +1,221 @@
+// csrc/compositor.hip — vfhip_compositor_* : N-input alpha / z-order compositor.
+// Mirrors MetalCompositorRenderer (reference compositor/metalcomprenderer.{h,m}) and restates compositorVertex /
+// compositorFragment{,NV12,I420} / checkerFragment (:39-122) and the fixed-function SOURCE / OVER / ADD blend
+// states (:199-239) in `metal` numerics (float on unorm8, premultiplied source, the 8-bit target requantised
+// after every layer).
+//
+// The reference clears the target, then draws N quads with ROP read-modify-write, then runs RGBA->YUV and reads
+// back (metalcomprenderer.m:356-542): every covered output pixel is read and written once per layer.  Here one
+// kernel walks the layers in z-order per output pixel with the running colour in a register, so each output
+// pixel is written once and each covered input texel is read once; the per-layer 8-bit requantisation of the
+// target is kept (it is part of the reference's arithmetic), it just happens in registers.
+#include "vfhip_internal.h"
+#include "metal_common.h"
+
+using namespace vfhip;
+
+namespace vfhip {
+
+constexpr int COMP_MAX_LAYERS = 16;     // per launch; more pads chain through an RGBA8 scratch target
+
+struct CompLayer {
+  metal::Img img;
+  int xpos, ypos, width, height;
+  float alpha;
+  int blend;
+};
+struct CompParams {
+  CompLayer layer[COMP_MAX_LAYERS];
+  int n;
+  int background;                       // VfHipBackground, or -1: start from `prev` (logical RGBA8 of an earlier pass)
+  const uint32_t *prev; int prev_stride;
+  metal::OutImg out;
+  uint32_t *scratch; int scratch_stride;   // != nullptr: write logical RGBA8 here instead of `out`
+};
+
+using metal::F4;
+
+__device__ __forceinline__ uint32_t comp_pixel (const CompParams &p, int x, int y)
+{
+  uint32_t q;
+  if (p.background < 0) q = p.prev[(size_t) y * p.prev_stride + x];
+  else if (p.background == VFHIP_BG_BLACK) q = 0xff000000u;
+  else if (p.background == VFHIP_BG_WHITE) q = 0xffffffffu;
+  else if (p.background == VFHIP_BG_TRANSPARENT) q = 0u;
+  else {      // checker: pos = int2(texcoord * size), 8x8 cells, grey 0.75 / 0.5 (metalcomprenderer.m:113-121)
+    const float tu = ((float) x + 0.5f) / (float) p.out.w, tv = ((float) y + 0.5f) / (float) p.out.h;
+    const int px = (int) (tu * (float) p.out.w), py = (int) (tv * (float) p.out.h);
+    const float gray = ((px / 8) + (py / 8)) % 2 ? 0.75f : 0.5f;
+    F4 c; c.r = c.g = c.b = gray; c.a = 1.0f;
+    q = metal::quant_rgba8 (c);
+  }
+  for (int k = 0; k < p.n; k++) {
+    const CompLayer &L = p.layer[k];
+    // a pixel is covered when its centre lies inside the quad [xpos, xpos+width) x [ypos, ypos+height)
+    if (x < L.xpos || x >= L.xpos + L.width || y < L.ypos || y >= L.ypos + L.height) continue;
+    const float tu = (((float) x + 0.5f) - (float) L.xpos) / (float) L.width;
+    const float tv = (((float) y + 0.5f) - (float) L.ypos) / (float) L.height;
+    F4 s = metal::sample_rgba (L.img, tu, tv, true);
+    s.a *= L.alpha; s.r *= s.a; s.g *= s.a; s.b *= s.a;            // premultiply (compositorFragment, :58-59)
+    const F4 d = metal::unpack_rgba8 (q);
+    F4 o;
+    if (L.blend == VFHIP_BLEND_SOURCE) o = s;
+    else if (L.blend == VFHIP_BLEND_ADD) { o.r = s.r + d.r; o.g = s.g + d.g; o.b = s.b + d.b; o.a = s.a + d.a; }
+    else { const float k1 = 1.0f - s.a; o.r = s.r + d.r * k1; o.g = s.g + d.g * k1; o.b = s.b + d.b * k1; o.a = s.a + d.a * k1; }
+    q = metal::quant_rgba8 (o);
+  }
+  return q;
+}
+
+__global__ __launch_bounds__ (256) void k_compositor (const CompParams p)
+{
+  const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
+  if (2 * bx >= p.out.w || 2 * by >= p.out.h) return;
+  uint32_t q[2][2];
+#pragma unroll
+  for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+    for (int dx = 0; dx < 2; dx++)
+      q[dy][dx] = comp_pixel (p, min (2 * bx + dx, p.out.w - 1), min (2 * by + dy, p.out.h - 1));
+  if (p.scratch) {
+#pragma unroll
+    for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+      for (int dx = 0; dx < 2; dx++)
+        if (2 * bx + dx < p.out.w && 2 * by + dy < p.out.h) p.scratch[(size_t) (2 * by + dy) * p.scratch_stride + 2 * bx + dx] = q[dy][dx];
+    return;
+  }
+  metal::store_block (p.out, bx, by, q);
+}
+
+}  // namespace vfhip
+
+struct VfHipCompositor {
+  std::mutex mu;
+  Device *dev = nullptr;
+  Staging st;
+  bool configured = false;
+  VfHipVideoInfo out {};
+  uint32_t *scratch[2] = { nullptr, nullptr };   // only for > COMP_MAX_LAYERS pads
+};
+
+static int comp_launch (VfHipCompositor *h, const VfHipPadInput *pads, int count, int background, VfHipFrame *out, hipStream_t s)
+{
+  const int w = h->out.width, hh = h->out.height;
+  const int bw = (w + 1) / 2, bh = (hh + 1) / 2;
+  dim3 grid ((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4));
+  const int passes = count <= COMP_MAX_LAYERS ? 1 : (count + COMP_MAX_LAYERS - 1) / COMP_MAX_LAYERS;
+  if (passes > 1)
+    for (int k = 0; k < 2; k++)
+      if (!h->scratch[k]) VFHIP_CHECK_HIP (hipMalloc (&h->scratch[k], (size_t) w * hh * 4));
+  for (int pass = 0; pass < passes; pass++) {
+    CompParams p {};
+    const int first = pass * COMP_MAX_LAYERS, n = count - first < COMP_MAX_LAYERS ? count - first : COMP_MAX_LAYERS;
+    p.n = 0;
+    for (int k = 0; k < n; k++) {
+      const VfHipPadInput &in = pads[first + k];
+      if (in.width <= 0 || in.height <= 0) continue;
+      CompLayer &L = p.layer[p.n++];
+      L.img = metal::make_img (&in.frame);
+      L.xpos = in.xpos; L.ypos = in.ypos; L.width = in.width; L.height = in.height;
+      L.alpha = (float) in.alpha; L.blend = in.blend_mode;
+    }
+    p.background = pass == 0 ? background : -1;
+    p.prev = pass == 0 ? nullptr : h->scratch[(pass - 1) & 1]; p.prev_stride = w;
+    p.out = metal::make_out (out);
+    p.scratch = pass == passes - 1 ? nullptr : h->scratch[pass & 1]; p.scratch_stride = w;
+    hipLaunchKernelGGL (k_compositor, grid, dim3 (64, 4), 0, s, p);
+    VFHIP_CHECK_HIP (hipGetLastError ());
+  }
+  return VFHIP_OK;
+}
+
+static int comp_check (VfHipCompositor *h, const VfHipPadInput *pads, int count, int background, const VfHipFrame *out)
+{
+  if (!h || (count > 0 && !pads)) return set_error (VFHIP_ERR_INVALID, "null argument");
+  if (!h->configured) return set_error (VFHIP_ERR_NOT_CONFIGURED, "compositor: composite before configure");
+  if (count < 0 || count > 4096) return set_error (VFHIP_ERR_INVALID, "bad pad count %d", count);
+  if (background < VFHIP_BG_CHECKER || background > VFHIP_BG_TRANSPARENT) return set_error (VFHIP_ERR_INVALID, "bad background %d", background);
+  for (int k = 0; k < count; k++) {
+    int rc = check_frame (&pads[k].frame, nullptr, "pad");
+    if (rc) return rc;
+    if (pads[k].frame.info.format > VFHIP_FORMAT_I420) return set_error (VFHIP_ERR_UNSUPPORTED, "pad %d: format not supported", k);
+    if (pads[k].blend_mode < VFHIP_BLEND_SOURCE || pads[k].blend_mode > VFHIP_BLEND_ADD) return set_error (VFHIP_ERR_INVALID, "pad %d: bad blend mode", k);
+  }
+  return check_frame (out, &h->out, "output");
+}
+
+extern "C" {
+
+VfHipCompositor *vfhip_compositor_new (int device)
+{
+  Device *d = get_device (device);
+  if (!d) return nullptr;
+  VfHipCompositor *h = new (std::nothrow) VfHipCompositor ();
+  if (!h) { set_error (VFHIP_ERR_NOMEM, "out of memory"); return nullptr; }
+  h->dev = d;
+  if (h->st.init (d) != VFHIP_OK) { delete h; return nullptr; }
+  return h;
+}
+
+int vfhip_compositor_configure (VfHipCompositor *h, const VfHipVideoInfo *out)
+{
+  if (!h || !out) return set_error (VFHIP_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk (h->mu);
+  if (out->width <= 0 || out->height <= 0 || out->width > 32768 || out->height > 32768)
+    return set_error (VFHIP_ERR_INVALID, "bad output size %dx%d", out->width, out->height);
+  if (out->format < VFHIP_FORMAT_BGRA || out->format > VFHIP_FORMAT_I420)
+    return set_error (VFHIP_ERR_UNSUPPORTED, "compositor: output format not supported");
+  (void) hipSetDevice (h->dev->ordinal);
+  for (int k = 0; k < 2; k++) { if (h->scratch[k]) (void) hipFree (h->scratch[k]); h->scratch[k] = nullptr; }
+  h->out = *out; h->configured = true;
+  return VFHIP_OK;
+}
+
+int vfhip_compositor_composite_device (VfHipCompositor *h, const VfHipPadInput *pads, int count, int background,
+    VfHipFrame *out, void *stream)
+{
+  int rc = comp_check (h, pads, count, background, out);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk (h->mu);
+  VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
+  return comp_launch (h, pads, count, background, out, stream ? (hipStream_t) stream : h->st.s_compute);
+}
+
+int vfhip_compositor_composite (VfHipCompositor *h, const VfHipPadInput *pads, int count, int background, VfHipFrame *out)
+{
+  int rc = comp_check (h, pads, count, background, out);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk (h->mu);
+  VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
+  std::vector<VfHipPadInput> dpads (pads, pads + count);
+  for (int k = 0; k < count; k++)                     // slot k + 1 per pad (slot-indexed like the reference's texture cache)
+    if ((rc = upload_frame (h->st, (size_t) k + 1, &pads[k].frame, &dpads[k].frame))) return rc;
+  VfHipFrame dout;
+  if ((rc = alloc_device_frame (h->st, 0, &h->out, &dout))) return rc;
+  if (count > 0) VFHIP_CHECK_HIP (hipStreamWaitEvent (h->st.s_compute, h->st.ev_h2d, 0));
+  if ((rc = comp_launch (h, dpads.data (), count, background, &dout, h->st.s_compute))) return rc;
+  VFHIP_CHECK_HIP (hipEventRecord (h->st.ev_compute, h->st.s_compute));
+  return download_frame (h->st, 0, &dout, out);
+}
+
+void vfhip_compositor_cleanup (VfHipCompositor *h)
+{
+  if (!h) return;
+  std::lock_guard<std::mutex> lk (h->mu);
+  (void) hipSetDevice (h->dev->ordinal);
+  for (int k = 0; k < 2; k++) { if (h->scratch[k]) (void) hipFree (h->scratch[k]); h->scratch[k] = nullptr; }
+  for (auto &b : h->st.slots) { if (b.host) (void) hipHostFree (b.host); if (b.devp) (void) hipFree (b.devp); }
+  h->st.slots.clear ();
+  h->configured = false;
+}
+
+void vfhip_compositor_free (VfHipCompositor *h)
+{
+  if (!h) return;
+  vfhip_compositor_cleanup (h);
+  h->st.destroy ();
+  delete h;
+}
+
+}  // extern "C"

@@ -68,26 +68,29 @@ __device__ __forceinline__ void rgb_to_yuv (float r, float g, float b, int m709,
 
 // ---- texture sampling ---------------------------------------------------
 struct Taps { int i0, i1; float f; };
-__device__ __forceinline__ Taps lin_taps (int n, float coord)          // coord normalised 0..1
+__device__ __forceinline__ Taps lin_taps_px (int n, float x)           // x in texel units, already minus .5
 {
-  const float x = coord * (float) n - 0.5f;
   const float fl = floorf (x);
   Taps t; t.f = x - fl;
   const int i = (int) fl;
   t.i0 = iclamp (i, 0, n - 1); t.i1 = iclamp (i + 1, 0, n - 1);
   return t;
 }
+__device__ __forceinline__ Taps lin_taps (int n, float coord) { return lin_taps_px (n, coord * (float) n - 0.5f); }   // coord normalised 0..1
 __device__ __forceinline__ int near_tap (int n, float coord) { return iclamp ((int) floorf (coord * (float) n), 0, n - 1); }
 __device__ __forceinline__ float lerp2 (float a, float b, float f) { return a + (b - a) * f; }
 
 // one channel of a plane with `bpt` bytes per texel
-__device__ __forceinline__ float plane_linear (const uint8_t *p, int stride, int bpt, int ch, int W, int H, float u, float v)
+__device__ __forceinline__ float plane_taps (const uint8_t *p, int stride, int bpt, int ch, Taps tx, Taps ty)
 {
-  const Taps tx = lin_taps (W, u), ty = lin_taps (H, v);
   const uint8_t *r0 = p + (size_t) ty.i0 * stride, *r1 = p + (size_t) ty.i1 * stride;
   const float a = lerp2 (un8 (r0[tx.i0 * bpt + ch]), un8 (r0[tx.i1 * bpt + ch]), tx.f);
   const float b = lerp2 (un8 (r1[tx.i0 * bpt + ch]), un8 (r1[tx.i1 * bpt + ch]), tx.f);
   return lerp2 (a, b, ty.f);
+}
+__device__ __forceinline__ float plane_linear (const uint8_t *p, int stride, int bpt, int ch, int W, int H, float u, float v)
+{
+  return plane_taps (p, stride, bpt, ch, lin_taps (W, u), lin_taps (H, v));
 }
 __device__ __forceinline__ float plane_nearest (const uint8_t *p, int stride, int bpt, int ch, int W, int H, float u, float v)
 {
@@ -141,8 +144,36 @@ __device__ __forceinline__ F4 sample_rgba (const Img &im, float u, float v, bool
   }
 }
 
-// exact-texel fetch at integer (x, y) (clamped) -> logical RGBA float; NV12/I420 chroma texel floor(x/2), floor(y/2)
-// (a 1:1 sample with a linear or nearest sampler lands exactly on the texel; chroma: see *_chroma_linear below)
+// 1:1 fetch at pixel (x, y) of an image whose full-resolution planes match the output grid (filter, deinterlace,
+// unscaled compositor pads): exact luma / RGBA texel; 4:2:0 chroma either bilinear at texel coordinate
+// 0.5*x - 0.25 (what a linear sampler sees at texcoord (x+.5)/W on the half-size plane) or the nearest texel x/2
+// (the deinterlace input pass, filter::nearest).  SURVEY.md Appendix B item 2.
+__device__ __forceinline__ F4 fetch_1to1 (const Img &im, int x, int y, bool chroma_linear)
+{
+  x = iclamp (x, 0, im.w - 1); y = iclamp (y, 0, im.h - 1);
+  if (im.fmt == VFHIP_FORMAT_BGRA || im.fmt == VFHIP_FORMAT_RGBA) {
+    const uint32_t t = *reinterpret_cast<const uint32_t *> (im.p[0] + (size_t) y * im.s[0] + 4 * x);
+    F4 o;
+    o.g = un8 ((t >> 8) & 0xff); o.a = un8 (t >> 24);
+    if (im.fmt == VFHIP_FORMAT_RGBA) { o.r = un8 (t & 0xff); o.b = un8 ((t >> 16) & 0xff); }
+    else { o.b = un8 (t & 0xff); o.r = un8 ((t >> 16) & 0xff); }
+    return o;
+  }
+  const int cw = (im.w + 1) / 2, chh = (im.h + 1) / 2;
+  const float Y = un8 (im.p[0][(size_t) y * im.s[0] + x]);
+  float cb, cr;
+  if (chroma_linear) {
+    const Taps tx = lin_taps_px (cw, 0.5f * (float) x - 0.25f), ty = lin_taps_px (chh, 0.5f * (float) y - 0.25f);
+    if (im.fmt == VFHIP_FORMAT_NV12) { cb = plane_taps (im.p[1], im.s[1], 2, 0, tx, ty); cr = plane_taps (im.p[1], im.s[1], 2, 1, tx, ty); }
+    else { cb = plane_taps (im.p[1], im.s[1], 1, 0, tx, ty); cr = plane_taps (im.p[2], im.s[2], 1, 0, tx, ty); }
+  } else {
+    const int cx = iclamp (x >> 1, 0, cw - 1), cy = iclamp (y >> 1, 0, chh - 1);
+    if (im.fmt == VFHIP_FORMAT_NV12) { cb = un8 (im.p[1][(size_t) cy * im.s[1] + 2 * cx]); cr = un8 (im.p[1][(size_t) cy * im.s[1] + 2 * cx + 1]); }
+    else { cb = un8 (im.p[1][(size_t) cy * im.s[1] + cx]); cr = un8 (im.p[2][(size_t) cy * im.s[2] + cx]); }
+  }
+  return yuv_to_rgb (Y, cb, cr, im.m709);
+}
+
 __device__ __forceinline__ uint32_t pack_rgba8 (uint32_t r, uint32_t g, uint32_t b, uint32_t a) { return r | (g << 8) | (b << 16) | (a << 24); }
 __device__ __forceinline__ uint32_t quant_rgba8 (F4 c) { return pack_rgba8 (quant8 (c.r), quant8 (c.g), quant8 (c.b), quant8 (c.a)); }
 __device__ __forceinline__ F4 unpack_rgba8 (uint32_t q)
@@ -215,6 +246,22 @@ __device__ __forceinline__ void store_block (const OutImg &o, int bx, int by, co
       return;
     }
   }
+}
+
+// host helpers: VfHipFrame -> device image descriptors
+static inline Img make_img (const VfHipFrame *f)
+{
+  Img im {};
+  for (int k = 0; k < 3; k++) { im.p[k] = (const uint8_t *) f->data[k]; im.s[k] = f->stride[k]; }
+  im.w = f->info.width; im.h = f->info.height; im.fmt = f->info.format; im.m709 = f->info.color_matrix == VFHIP_MATRIX_BT709;
+  return im;
+}
+static inline OutImg make_out (const VfHipFrame *f)
+{
+  OutImg im {};
+  for (int k = 0; k < 3; k++) { im.p[k] = (uint8_t *) f->data[k]; im.s[k] = f->stride[k]; }
+  im.w = f->info.width; im.h = f->info.height; im.fmt = f->info.format; im.m709 = f->info.color_matrix == VFHIP_MATRIX_BT709;
+  return im;
 }
 
 }  // namespace metal

@@ -319,3 +319,19 @@ int vfhip_plane_width_bytes (int format, int plane, int width) { return plane_wi
 int vfhip_plane_height (int format, int plane, int height) { return plane_height (format, plane, height); }
 
 }  // extern "C"
+
+namespace vfhip {
+int check_frame (const VfHipFrame *f, const VfHipVideoInfo *want, const char *what)
+{
+  if (!f) return set_error (VFHIP_ERR_INVALID, "%s frame is NULL", what);
+  if (want && (f->info.format != want->format || f->info.width != want->width || f->info.height != want->height))
+    return set_error (VFHIP_ERR_INVALID, "%s frame does not match the configured caps", what);
+  const int np = format_n_planes (f->info.format);
+  if (np < 0) return np;
+  if (f->info.width <= 0 || f->info.height <= 0) return set_error (VFHIP_ERR_INVALID, "%s frame has no size", what);
+  for (int p = 0; p < np; p++)
+    if (!f->data[p] || f->stride[p] < plane_width_bytes (f->info.format, p, f->info.width))
+      return set_error (VFHIP_ERR_INVALID, "%s plane %d: null pointer or short stride", what, p);
+  return VFHIP_OK;
+}
+}  // namespace vfhip

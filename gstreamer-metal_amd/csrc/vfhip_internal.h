@@ -60,3 +60,8 @@ int alloc_device_frame (Staging &st, size_t slot, const VfHipVideoInfo *info, Vf
 int download_frame (Staging &st, size_t slot, const VfHipFrame *dev_frame, VfHipFrame *host);
 
 }  // namespace vfhip
+
+namespace vfhip {
+// shared argument checks of the element entry points
+int check_frame (const VfHipFrame *f, const VfHipVideoInfo *want, const char *what);
+}  // namespace vfhip

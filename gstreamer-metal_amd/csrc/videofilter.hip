@@ -1,0 +1,418 @@
+// csrc/videofilter.hip — vfhip_videofilter_* : the 15-property single-pass video filter.
+// Mirrors MetalVideoFilterRenderer (reference videofilter/metalvideofilterrenderer.{h,m}) and restates
+// applyColorAdjustments / hash12 / rgbToHsv / hsvToRgb / filterFragment* / blurHorizontal / blurVertical /
+// unsharpMask of videofilter/metalvideofilter_shaders.h:63-328 (`metal` numerics).
+//
+// The reference runs 1 render pass + (sharpness != 0) 3 compute passes + 1 RGBA->YUV pass, every one a full
+// trip through an 8-bit texture (metalvideofilterrenderer.m:523-681).  Here:
+//   k_vf_point : sharpness == 0 — one kernel, each lane owns a 2x2 block (needed by the 4:2:0 store epilogue);
+//   k_vf_sharp : sharpness != 0 — one kernel, a 64x16 output tile per workgroup; the colour-adjusted tile plus
+//                its 4-pixel halo is quantised to 8 bits into LDS exactly where the reference wrote its render
+//                target, the 9-tap horizontal and vertical Gaussians and the unsharp mask run out of LDS (with the
+//                reference's 8-bit requantisation between passes), and only the final frame goes to HBM.
+#include "vfhip_internal.h"
+#include "metal_common.h"
+#include <cctype>
+#include <cmath>
+#include <cstdlib>
+#include <string>
+
+using namespace vfhip;
+
+namespace vfhip {
+
+struct VfParams {
+  metal::Img in;
+  metal::OutImg out;
+  VfHipVideoFilterParams u;
+  const float4 *lut;
+  int lut_size;
+};
+
+using metal::F4;
+using metal::clamp01;
+
+__device__ __forceinline__ float fractf_ (float x) { return x - floorf (x); }
+__device__ __forceinline__ float mixf (float a, float b, float t) { return a + (b - a) * t; }
+__device__ __forceinline__ float stepf (float e, float x) { return x < e ? 0.0f : 1.0f; }
+__device__ __forceinline__ float smoothstepf (float e0, float e1, float x)
+{
+  if (!(e0 < e1)) return stepf (e0, x);          // MSL leaves e0 >= e1 undefined (smoothness = 0): defined as step
+  const float t = clamp01 ((x - e0) / (e1 - e0));
+  return t * t * (3.0f - 2.0f * t);
+}
+__device__ __forceinline__ float hash12 (float px, float py, uint32_t frame)
+{
+  const float fo = (float) frame * 0.00137f;
+  float x = fractf_ (px * 0.1031f + fo), y = fractf_ (py * 0.1031f + fo), z = fractf_ (px * 0.1031f + fo);
+  const float d = x * (y + 33.33f) + y * (z + 33.33f) + z * (x + 33.33f);
+  x += d; y += d; z += d;
+  return fractf_ ((x + y) * z);
+}
+__device__ __forceinline__ void rgb_to_hsv (float r, float g, float b, float *h, float *s, float *v)
+{
+  const float Kx = 0.0f, Ky = -1.0f / 3.0f, Kz = 2.0f / 3.0f, Kw = -1.0f;
+  const float t1 = stepf (b, g);
+  const float px = mixf (b, g, t1), py = mixf (g, b, t1), pz = mixf (Kw, Kx, t1), pw = mixf (Kz, Ky, t1);
+  const float t2 = stepf (px, r);
+  const float qx = mixf (px, r, t2), qy = mixf (py, py, t2), qz = mixf (pw, pz, t2), qw = mixf (r, px, t2);
+  const float d = qx - fminf (qw, qy);
+  const float e = 1.0e-10f;
+  *h = fabsf (qz + (qw - qy) / (6.0f * d + e));
+  *s = d / (qx + e);
+  *v = qx;
+}
+__device__ __forceinline__ void hsv_to_rgb (float h, float s, float v, float *r, float *g, float *b)
+{
+  const float pr = fabsf (fractf_ (h + 1.0f) * 6.0f - 3.0f);
+  const float pg = fabsf (fractf_ (h + 2.0f / 3.0f) * 6.0f - 3.0f);
+  const float pb = fabsf (fractf_ (h + 1.0f / 3.0f) * 6.0f - 3.0f);
+  *r = v * mixf (1.0f, clamp01 (pr - 1.0f), s);
+  *g = v * mixf (1.0f, clamp01 (pg - 1.0f), s);
+  *b = v * mixf (1.0f, clamp01 (pb - 1.0f), s);
+}
+
+// applyColorAdjustments (metalvideofilter_shaders.h:92-155), fixed order
+__device__ __forceinline__ F4 color_adjust (F4 c, const VfHipVideoFilterParams &u, float tu, float tv, int W, int H)
+{
+  float r = c.r, g = c.g, b = c.b, a = c.a;
+  r += u.brightness; g += u.brightness; b += u.brightness;
+  r = (r - 0.5f) * u.contrast + 0.5f; g = (g - 0.5f) * u.contrast + 0.5f; b = (b - 0.5f) * u.contrast + 0.5f;
+  const float lum = r * 0.2126f + g * 0.7152f + b * 0.0722f;
+  r = mixf (lum, r, u.saturation); g = mixf (lum, g, u.saturation); b = mixf (lum, b, u.saturation);
+  if (fabsf (u.hue) > 0.001f) {
+    float h, s, v;
+    rgb_to_hsv (clamp01 (r), clamp01 (g), clamp01 (b), &h, &s, &v);
+    h = fractf_ (h + u.hue / (2.0f * 3.14159265358979323846f));
+    hsv_to_rgb (h, s, v, &r, &g, &b);
+  }
+  const float ig = 1.0f / u.gamma;
+  r = powf (fminf (fmaxf (r, 0.0001f), 1.0f), ig); g = powf (fminf (fmaxf (g, 0.0001f), 1.0f), ig); b = powf (fminf (fmaxf (b, 0.0001f), 1.0f), ig);
+  if (u.sepia > 0.001f) {
+    const float sr = r * 0.393f + g * 0.769f + b * 0.189f;
+    const float sg = r * 0.349f + g * 0.686f + b * 0.168f;
+    const float sb = r * 0.272f + g * 0.534f + b * 0.131f;
+    r = mixf (r, sr, u.sepia); g = mixf (g, sg, u.sepia); b = mixf (b, sb, u.sepia);
+  }
+  if (u.invert) { r = 1.0f - r; g = 1.0f - g; b = 1.0f - b; }
+  if (u.chroma_key_enabled) {
+    const float dr = r - u.chroma_key_r, dg = g - u.chroma_key_g, db = b - u.chroma_key_b;
+    const float dist = sqrtf (dr * dr + dg * dg + db * db);
+    a *= smoothstepf (u.chroma_key_tolerance, u.chroma_key_tolerance + u.chroma_key_smoothness, dist);
+  }
+  if (u.vignette > 0.001f) {
+    const float cx = tu - 0.5f, cy = tv - 0.5f;
+    const float dist = sqrtf (cx * cx + cy * cy) * 1.414f;
+    const float vig = 1.0f - smoothstepf (0.5f, 1.0f, dist) * u.vignette;
+    r *= vig; g *= vig; b *= vig;
+  }
+  if (u.noise > 0.001f) {
+    float n = hash12 (tu * (float) W, tv * (float) H, u.frame_index);
+    n = (n - 0.5f) * u.noise * 0.5f;
+    r += n; g += n; b += n;
+  }
+  F4 o; o.r = clamp01 (r); o.g = clamp01 (g); o.b = clamp01 (b); o.a = a;
+  return o;
+}
+
+// trilinear 3D LUT, coordinate c*(N-1)/N + .5/N (metalvideofilter_shaders.h:188-194); memory index (b*N+g)*N+r
+__device__ __forceinline__ void lut_sample (const float4 *lut, int N, F4 &c)
+{
+  const float scale = (float) (N - 1) / (float) N, offset = 0.5f / (float) N;
+  const metal::Taps tx = metal::lin_taps (N, c.r * scale + offset), ty = metal::lin_taps (N, c.g * scale + offset),
+                    tz = metal::lin_taps (N, c.b * scale + offset);
+#define L(x, y, z) lut[((size_t) (z) * N + (y)) * N + (x)]
+  const float4 a000 = L (tx.i0, ty.i0, tz.i0), a100 = L (tx.i1, ty.i0, tz.i0), a010 = L (tx.i0, ty.i1, tz.i0), a110 = L (tx.i1, ty.i1, tz.i0);
+  const float4 a001 = L (tx.i0, ty.i0, tz.i1), a101 = L (tx.i1, ty.i0, tz.i1), a011 = L (tx.i0, ty.i1, tz.i1), a111 = L (tx.i1, ty.i1, tz.i1);
+#undef L
+  using metal::lerp2;
+  c.r = lerp2 (lerp2 (lerp2 (a000.x, a100.x, tx.f), lerp2 (a010.x, a110.x, tx.f), ty.f), lerp2 (lerp2 (a001.x, a101.x, tx.f), lerp2 (a011.x, a111.x, tx.f), ty.f), tz.f);
+  c.g = lerp2 (lerp2 (lerp2 (a000.y, a100.y, tx.f), lerp2 (a010.y, a110.y, tx.f), ty.f), lerp2 (lerp2 (a001.y, a101.y, tx.f), lerp2 (a011.y, a111.y, tx.f), ty.f), tz.f);
+  c.b = lerp2 (lerp2 (lerp2 (a000.z, a100.z, tx.f), lerp2 (a010.z, a110.z, tx.f), ty.f), lerp2 (lerp2 (a001.z, a101.z, tx.f), lerp2 (a011.z, a111.z, tx.f), ty.f), tz.f);
+}
+
+// pass 1 of the reference for one pixel: sample (exact texel, linear chroma) -> adjustments -> LUT -> 8-bit target
+__device__ __forceinline__ uint32_t vf_pass1 (const VfParams &p, int x, int y)
+{
+  x = metal::iclamp (x, 0, p.out.w - 1); y = metal::iclamp (y, 0, p.out.h - 1);
+  const float tu = ((float) x + 0.5f) / (float) p.out.w, tv = ((float) y + 0.5f) / (float) p.out.h;
+  F4 c = metal::fetch_1to1 (p.in, x, y, true);
+  c = color_adjust (c, p.u, tu, tv, p.out.w, p.out.h);
+  if (p.lut) lut_sample (p.lut, p.lut_size, c);
+  return metal::quant_rgba8 (c);
+}
+
+__global__ __launch_bounds__ (256) void k_vf_point (const VfParams p)
+{
+  const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
+  if (2 * bx >= p.out.w || 2 * by >= p.out.h) return;
+  uint32_t q[2][2];
+#pragma unroll
+  for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+    for (int dx = 0; dx < 2; dx++) q[dy][dx] = vf_pass1 (p, 2 * bx + dx, 2 * by + dy);
+  metal::store_block (p.out, bx, by, q);
+}
+
+constexpr int VF_TW = 64, VF_TH = 16, VF_HALO = 4;
+constexpr int VF_RW = VF_TW + 2 * VF_HALO, VF_RH = VF_TH + 2 * VF_HALO;
+__constant__ float kBlurW[9] = { 0.028532f, 0.067234f, 0.124009f, 0.179044f, 0.20236f, 0.179044f, 0.124009f, 0.067234f, 0.028532f };
+
+__global__ __launch_bounds__ (256) void k_vf_sharp (const VfParams p)
+{
+  __shared__ uint32_t rt[VF_RH][VF_RW];       // pass-1 render target, tile + halo (clamped to the image like the blur's reads)
+  __shared__ uint32_t hb[VF_RH][VF_TW];       // horizontal blur (8-bit, like _blurTemp)
+  __shared__ uint32_t fin[VF_TH][VF_TW];      // unsharp result (8-bit)
+  const int x0 = blockIdx.x * VF_TW, y0 = blockIdx.y * VF_TH;
+  const int tid = threadIdx.x;
+  const int w = p.out.w, h = p.out.h;
+  for (int i = tid; i < VF_RW * VF_RH; i += 256) {
+    const int rx = i % VF_RW, ry = i / VF_RW;
+    rt[ry][rx] = vf_pass1 (p, x0 - VF_HALO + rx, y0 - VF_HALO + ry);
+  }
+  __syncthreads ();
+  // horizontal 9-tap on every row of the region, for the tile's columns.  Reads clamp to the IMAGE (not the region):
+  // region column rx holds image column clamp(x0-4+rx), so an unclamped region read is the clamped image read,
+  // except that columns right of the image edge inside the tile must not be produced at all.
+  for (int i = tid; i < VF_TW * VF_RH; i += 256) {
+    const int tx = i % VF_TW, ry = i / VF_TW;
+    F4 s; s.r = s.g = s.b = s.a = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      const F4 c = metal::unpack_rgba8 (rt[ry][tx + k]);
+      s.r += c.r * kBlurW[k]; s.g += c.g * kBlurW[k]; s.b += c.b * kBlurW[k]; s.a += c.a * kBlurW[k];
+    }
+    hb[ry][tx] = metal::quant_rgba8 (s);
+  }
+  __syncthreads ();
+  const float amount = p.u.sharpness;
+  for (int i = tid; i < VF_TW * VF_TH; i += 256) {
+    const int tx = i % VF_TW, ty = i / VF_TW;
+    F4 s; s.r = s.g = s.b = s.a = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      const F4 c = metal::unpack_rgba8 (hb[ty + k][tx]);
+      s.r += c.r * kBlurW[k]; s.g += c.g * kBlurW[k]; s.b += c.b * kBlurW[k]; s.a += c.a * kBlurW[k];
+    }
+    const F4 b = metal::unpack_rgba8 (metal::quant_rgba8 (s));          // _blurResult is 8-bit as well
+    const F4 o = metal::unpack_rgba8 (rt[ty + VF_HALO][tx + VF_HALO]);
+    F4 r;
+    if (amount > 0.0f) {
+      r.r = clamp01 (o.r + (o.r - b.r) * amount); r.g = clamp01 (o.g + (o.g - b.g) * amount); r.b = clamp01 (o.b + (o.b - b.b) * amount);
+    } else {
+      const float t = fabsf (amount);
+      r.r = mixf (o.r, b.r, t); r.g = mixf (o.g, b.g, t); r.b = mixf (o.b, b.b, t);
+    }
+    r.a = o.a;
+    fin[ty][tx] = metal::quant_rgba8 (r);
+  }
+  __syncthreads ();
+  // store epilogue: 2x2 blocks of the tile (512 blocks, two per lane)
+  for (int i = tid; i < (VF_TW / 2) * (VF_TH / 2); i += 256) {
+    const int lbx = i % (VF_TW / 2), lby = i / (VF_TW / 2);
+    const int gx = x0 + 2 * lbx, gy = y0 + 2 * lby;
+    if (gx >= w || gy >= h) continue;
+    uint32_t q[2][2];
+#pragma unroll
+    for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+      for (int dx = 0; dx < 2; dx++) {
+        const int lx = min (gx + dx, w - 1) - x0, ly = min (gy + dy, h - 1) - y0;      // edge-clamped duplicates
+        q[dy][dx] = fin[ly][lx];
+      }
+    metal::store_block (p.out, gx / 2, gy / 2, q);
+  }
+}
+
+}  // namespace vfhip
+
+struct VfHipVideoFilter {
+  std::mutex mu;
+  Device *dev = nullptr;
+  Staging st;
+  bool configured = false;
+  VfHipVideoInfo in {}, out {};
+  float4 *d_lut = nullptr;
+  int lut_size = 0;
+};
+
+static int vf_launch (VfHipVideoFilter *h, const VfHipFrame *in, VfHipFrame *out, const VfHipVideoFilterParams *prm, hipStream_t s)
+{
+  VfParams p {};
+  p.in = metal::make_img (in); p.out = metal::make_out (out);
+  p.u = *prm; p.lut = h->d_lut; p.lut_size = h->lut_size;
+  const int w = h->out.width, hh = h->out.height;
+  if (prm->sharpness < -0.001f || prm->sharpness > 0.001f) {
+    dim3 grid ((unsigned) ((w + VF_TW - 1) / VF_TW), (unsigned) ((hh + VF_TH - 1) / VF_TH));
+    hipLaunchKernelGGL (k_vf_sharp, grid, dim3 (256), 0, s, p);
+  } else {
+    const int bw = (w + 1) / 2, bh = (hh + 1) / 2;
+    dim3 grid ((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4));
+    hipLaunchKernelGGL (k_vf_point, grid, dim3 (64, 4), 0, s, p);
+  }
+  VFHIP_CHECK_HIP (hipGetLastError ());
+  return VFHIP_OK;
+}
+
+static int vf_check (VfHipVideoFilter *h, const VfHipFrame *in, const VfHipFrame *out, const VfHipVideoFilterParams *prm)
+{
+  if (!h || !prm) return set_error (VFHIP_ERR_INVALID, "null argument");
+  if (!h->configured) return set_error (VFHIP_ERR_NOT_CONFIGURED, "videofilter: process before configure");
+  if (!(prm->gamma > 0.0f)) return set_error (VFHIP_ERR_INVALID, "gamma must be > 0");
+  int rc = check_frame (in, &h->in, "input");
+  if (rc) return rc;
+  return check_frame (out, &h->out, "output");
+}
+
+static int vf_upload_lut (VfHipVideoFilter *h, const float *rgba, int size)
+{
+  if (size < 2 || size > 64) return set_error (VFHIP_ERR_INVALID, "LUT size %d outside 2..64", size);
+  VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
+  const size_t bytes = (size_t) size * size * size * sizeof (float4);
+  float4 *d = nullptr;
+  VFHIP_CHECK_HIP (hipMalloc (&d, bytes));
+  hipError_t e = hipMemcpy (d, rgba, bytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void) hipFree (d); return set_error (VFHIP_ERR_HIP, "LUT upload failed: %s", hipGetErrorString (e)); }
+  // swap after the device is idle for this handle's streams: a frame in flight may still read the old table
+  (void) hipStreamSynchronize (h->st.s_compute);
+  if (h->d_lut) (void) hipFree (h->d_lut);
+  h->d_lut = d; h->lut_size = size;
+  return VFHIP_OK;
+}
+
+extern "C" {
+
+VfHipVideoFilter *vfhip_videofilter_new (int device)
+{
+  Device *d = get_device (device);
+  if (!d) return nullptr;
+  VfHipVideoFilter *h = new (std::nothrow) VfHipVideoFilter ();
+  if (!h) { set_error (VFHIP_ERR_NOMEM, "out of memory"); return nullptr; }
+  h->dev = d;
+  if (h->st.init (d) != VFHIP_OK) { delete h; return nullptr; }
+  return h;
+}
+
+int vfhip_videofilter_configure (VfHipVideoFilter *h, const VfHipVideoInfo *in, const VfHipVideoInfo *out)
+{
+  if (!h || !in || !out) return set_error (VFHIP_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk (h->mu);
+  if (in->width <= 0 || in->height <= 0 || in->width > 32768 || in->height > 32768)
+    return set_error (VFHIP_ERR_INVALID, "bad frame size %dx%d", in->width, in->height);
+  if (in->width != out->width || in->height != out->height)
+    return set_error (VFHIP_ERR_INVALID, "videofilter does not scale (%dx%d -> %dx%d)", in->width, in->height, out->width, out->height);
+  // pad templates of the reference: BGRA, RGBA, NV12, I420 (videofilter/gstvfmetalvideofilter.m:53-65)
+  if (in->format < VFHIP_FORMAT_BGRA || in->format > VFHIP_FORMAT_I420 || out->format < VFHIP_FORMAT_BGRA || out->format > VFHIP_FORMAT_I420)
+    return set_error (VFHIP_ERR_UNSUPPORTED, "videofilter: format not supported");
+  h->in = *in; h->out = *out; h->configured = true;
+  return VFHIP_OK;
+}
+
+int vfhip_videofilter_process (VfHipVideoFilter *h, const VfHipFrame *in, VfHipFrame *out, const VfHipVideoFilterParams *prm)
+{
+  int rc = vf_check (h, in, out, prm);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk (h->mu);
+  VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
+  VfHipFrame din, dout;
+  if ((rc = upload_frame (h->st, 0, in, &din))) return rc;
+  if ((rc = alloc_device_frame (h->st, 1, &h->out, &dout))) return rc;
+  VFHIP_CHECK_HIP (hipStreamWaitEvent (h->st.s_compute, h->st.ev_h2d, 0));
+  if ((rc = vf_launch (h, &din, &dout, prm, h->st.s_compute))) return rc;
+  VFHIP_CHECK_HIP (hipEventRecord (h->st.ev_compute, h->st.s_compute));
+  return download_frame (h->st, 1, &dout, out);
+}
+
+int vfhip_videofilter_process_device (VfHipVideoFilter *h, const VfHipFrame *in, VfHipFrame *out,
+    const VfHipVideoFilterParams *prm, void *stream)
+{
+  int rc = vf_check (h, in, out, prm);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk (h->mu);
+  VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
+  return vf_launch (h, in, out, prm, stream ? (hipStream_t) stream : h->st.s_compute);
+}
+
+int vfhip_videofilter_set_lut (VfHipVideoFilter *h, const float *rgba, int size)
+{
+  if (!h || !rgba) return set_error (VFHIP_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk (h->mu);
+  return vf_upload_lut (h, rgba, size);
+}
+
+// .cube parser: LUT_3D_SIZE 2..64, RGB triplets with R fastest; TITLE / DOMAIN_* / LUT_1D_SIZE lines are skipped
+// (same acceptance rules as the reference's parse_cube_lut, videofilter/metalvideofilterrenderer.m:68-162).
+// PNG LUTs are out of scope: they need an image decoder.
+int vfhip_videofilter_load_lut (VfHipVideoFilter *h, const char *path)
+{
+  if (!h || !path) return set_error (VFHIP_ERR_INVALID, "null argument");
+  const size_t n = strlen (path);
+  if (n < 5 || strcasecmp (path + n - 5, ".cube") != 0)
+    return set_error (VFHIP_ERR_UNSUPPORTED, "only .cube LUT files are supported (got %s)", path);
+  FILE *fp = fopen (path, "r");
+  if (!fp) return set_error (VFHIP_ERR_IO, "cannot open LUT file %s", path);
+  int size = 0;
+  std::vector<float> data;
+  size_t count = 0, want = 0;
+  char line[512];
+  int rc = VFHIP_OK;
+  while (fgets (line, sizeof (line), fp)) {
+    const char *p = line;
+    while (*p && isspace ((unsigned char) *p)) p++;
+    if (*p == '#' || *p == '\0') continue;
+    if (strncmp (p, "LUT_3D_SIZE", 11) == 0) {
+      size = atoi (p + 11);
+      if (size < 2 || size > 64) { rc = set_error (VFHIP_ERR_IO, "invalid LUT_3D_SIZE %d in %s", size, path); break; }
+      want = (size_t) size * size * size;
+      data.assign (want * 4, 1.0f);
+      count = 0;
+      continue;
+    }
+    if (strncmp (p, "TITLE", 5) == 0 || strncmp (p, "DOMAIN_MIN", 10) == 0 || strncmp (p, "DOMAIN_MAX", 10) == 0 || strncmp (p, "LUT_1D_SIZE", 11) == 0)
+      continue;
+    float r, g, b;
+    if (size > 0 && count < want && sscanf (p, "%f %f %f", &r, &g, &b) == 3) {
+      data[count * 4 + 0] = r; data[count * 4 + 1] = g; data[count * 4 + 2] = b; data[count * 4 + 3] = 1.0f;
+      count++;
+    }
+  }
+  fclose (fp);
+  if (rc) return rc;
+  if (size == 0 || count != want) return set_error (VFHIP_ERR_IO, "incomplete .cube LUT %s: expected %zu entries, got %zu", path, want, count);
+  std::lock_guard<std::mutex> lk (h->mu);
+  return vf_upload_lut (h, data.data (), size);
+}
+
+void vfhip_videofilter_clear_lut (VfHipVideoFilter *h)
+{
+  if (!h) return;
+  std::lock_guard<std::mutex> lk (h->mu);
+  (void) hipSetDevice (h->dev->ordinal);
+  (void) hipStreamSynchronize (h->st.s_compute);
+  if (h->d_lut) (void) hipFree (h->d_lut);
+  h->d_lut = nullptr; h->lut_size = 0;
+}
+
+int vfhip_videofilter_lut_size (VfHipVideoFilter *h) { return h ? h->lut_size : 0; }
+
+void vfhip_videofilter_cleanup (VfHipVideoFilter *h)
+{
+  if (!h) return;
+  std::lock_guard<std::mutex> lk (h->mu);
+  (void) hipSetDevice (h->dev->ordinal);
+  for (auto &b : h->st.slots) { if (b.host) (void) hipHostFree (b.host); if (b.devp) (void) hipFree (b.devp); }
+  h->st.slots.clear ();
+  h->configured = false;              // the LUT survives cleanup like the reference's _lutTexture (a property, not a caps resource)
+}
+
+void vfhip_videofilter_free (VfHipVideoFilter *h)
+{
+  if (!h) return;
+  vfhip_videofilter_cleanup (h);
+  (void) hipSetDevice (h->dev->ordinal);
+  if (h->d_lut) (void) hipFree (h->d_lut);
+  h->st.destroy ();
+  delete h;
+}
+
+}  // extern "C"

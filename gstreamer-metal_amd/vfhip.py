@@ -50,7 +50,8 @@ def _load():
                           "vfhip has no CPU fallback")
     lib = C.CDLL(LIB_PATH)
     lib.vfhip_last_error_string.restype = C.c_char_p
-    for n in ("vfhip_pinned_alloc", "vfhip_device_malloc", "vfhip_convertscale_new"):
+    for n in ("vfhip_pinned_alloc", "vfhip_device_malloc", "vfhip_convertscale_new", "vfhip_deinterlace_new",
+              "vfhip_videofilter_new", "vfhip_compositor_new"):
         getattr(lib, n).restype = C.c_void_p
     lib.vfhip_convertscale_kernel_name.restype = C.c_char_p
     lib.vfhip_pinned_alloc.argtypes = [C.c_int, C.c_size_t]
@@ -67,7 +68,39 @@ def _load():
                                                             C.c_size_t, C.c_int, C.c_void_p]
     for n in ("vfhip_convertscale_cleanup", "vfhip_convertscale_free", "vfhip_convertscale_kernel_name"):
         getattr(lib, n).argtypes = [C.c_void_p]
+    lib.vfhip_deinterlace_configure.argtypes = [C.c_void_p, C.POINTER(VideoInfo)]
+    lib.vfhip_deinterlace_process.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(Frame), C.POINTER(DeinterlaceParams)]
+    lib.vfhip_deinterlace_process_device.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(Frame), C.POINTER(DeinterlaceParams), C.c_void_p]
+    lib.vfhip_videofilter_configure.argtypes = [C.c_void_p, C.POINTER(VideoInfo), C.POINTER(VideoInfo)]
+    lib.vfhip_videofilter_process.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(Frame), C.POINTER(VideoFilterParams)]
+    lib.vfhip_videofilter_process_device.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(Frame), C.POINTER(VideoFilterParams), C.c_void_p]
+    lib.vfhip_videofilter_load_lut.argtypes = [C.c_void_p, C.c_char_p]
+    lib.vfhip_videofilter_set_lut.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.vfhip_compositor_configure.argtypes = [C.c_void_p, C.POINTER(VideoInfo)]
+    lib.vfhip_compositor_composite.argtypes = [C.c_void_p, C.POINTER(PadInput), C.c_int, C.c_int, C.POINTER(Frame)]
+    lib.vfhip_compositor_composite_device.argtypes = [C.c_void_p, C.POINTER(PadInput), C.c_int, C.c_int, C.POINTER(Frame), C.c_void_p]
+    for n in ("vfhip_deinterlace_reset", "vfhip_deinterlace_cleanup", "vfhip_deinterlace_free", "vfhip_videofilter_clear_lut",
+              "vfhip_videofilter_lut_size", "vfhip_videofilter_cleanup", "vfhip_videofilter_free", "vfhip_compositor_cleanup",
+              "vfhip_compositor_free"):
+        getattr(lib, n).argtypes = [C.c_void_p]
     return lib
+
+
+class DeinterlaceParams(C.Structure):
+    _fields_ = [("method", C.c_int32), ("top_field_first", C.c_int32), ("motion_threshold", C.c_float), ("reserved", C.c_int32)]
+
+
+class VideoFilterParams(C.Structure):
+    _fields_ = [("brightness", C.c_float), ("contrast", C.c_float), ("saturation", C.c_float), ("hue", C.c_float),
+                ("gamma", C.c_float), ("sharpness", C.c_float), ("sepia", C.c_float), ("noise", C.c_float),
+                ("vignette", C.c_float), ("invert", C.c_int32), ("chroma_key_enabled", C.c_int32),
+                ("chroma_key_r", C.c_float), ("chroma_key_g", C.c_float), ("chroma_key_b", C.c_float),
+                ("chroma_key_tolerance", C.c_float), ("chroma_key_smoothness", C.c_float), ("frame_index", C.c_uint32)]
+
+
+class PadInput(C.Structure):
+    _fields_ = [("frame", Frame), ("xpos", C.c_int32), ("ypos", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("alpha", C.c_double), ("blend_mode", C.c_int32), ("reserved", C.c_int32)]
 
 
 lib = _load()
@@ -184,3 +217,156 @@ class ConvertScale:
             self.close()
         except Exception:
             pass
+
+
+DEINTERLACE_METHODS = {"bob": 0, "weave": 1, "linear": 2, "greedyh": 3}
+BLEND_MODES = {"source": 0, "over": 1, "add": 2}
+BACKGROUNDS = {"checker": 0, "black": 1, "white": 2, "transparent": 3}
+
+
+def filter_params(brightness=0.0, contrast=1.0, saturation=1.0, hue=0.0, gamma=1.0, sharpness=0.0, sepia=0.0, noise=0.0,
+                  vignette=0.0, invert=False, chroma_key=None, tolerance=0.2, smoothness=0.1, frame_index=0):
+    """Defaults = the element's property defaults (reference videofilter/gstvfmetalvideofilter.m:435-533).
+    hue is in radians here (the element multiplies its [-1,1] property by pi, :189)."""
+    p = VideoFilterParams(brightness, contrast, saturation, hue, gamma, sharpness, sepia, noise, vignette, int(invert),
+                          int(chroma_key is not None), 0.0, 0.0, 0.0, tolerance, smoothness, frame_index)
+    if chroma_key is not None:
+        p.chroma_key_r, p.chroma_key_g, p.chroma_key_b = chroma_key
+    return p
+
+
+class _Element:
+    _free = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            getattr(lib, self._free)(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Deinterlace(_Element):
+    """MetalDeinterlaceRenderer equivalent (reference deinterlace/metaldeinterlacerenderer.h:42-54)."""
+    _free = "vfhip_deinterlace_free"
+
+    def __init__(self, device=-1):
+        self.h = lib.vfhip_deinterlace_new(device)
+        if not self.h:
+            raise VfHipError(-6, lib.vfhip_last_error_string().decode(errors="replace"))
+
+    def configure(self, fmt, w, h, colorimetry="bt601"):
+        self.fmt, self.w, self.hh = fmt, w, h
+        self.info = make_info(fmt, w, h, colorimetry)
+        check(lib.vfhip_deinterlace_configure(self.h, C.byref(self.info)))
+        return self
+
+    def process(self, raw_in, method="bob", tff=True, threshold=0.1):
+        raw_in = np.ascontiguousarray(raw_in, dtype=np.uint8)
+        _, size = plane_layout(self.fmt, self.w, self.hh)
+        out = np.zeros(size, np.uint8)
+        fi = frame_from_base(self.info, self.fmt, self.w, self.hh, raw_in.ctypes.data)
+        fo = frame_from_base(self.info, self.fmt, self.w, self.hh, out.ctypes.data)
+        prm = DeinterlaceParams(DEINTERLACE_METHODS[method], int(tff), threshold, 0)
+        check(lib.vfhip_deinterlace_process(self.h, C.byref(fi), C.byref(fo), C.byref(prm)))
+        return out
+
+    def process_device(self, in_ptr, out_ptr, method="bob", tff=True, threshold=0.1, stream=None):
+        fi = frame_from_base(self.info, self.fmt, self.w, self.hh, in_ptr)
+        fo = frame_from_base(self.info, self.fmt, self.w, self.hh, out_ptr)
+        prm = DeinterlaceParams(DEINTERLACE_METHODS[method], int(tff), threshold, 0)
+        check(lib.vfhip_deinterlace_process_device(self.h, C.byref(fi), C.byref(fo), C.byref(prm), stream))
+
+    def reset(self):
+        check(lib.vfhip_deinterlace_reset(self.h))
+
+
+class VideoFilter(_Element):
+    """MetalVideoFilterRenderer equivalent (reference videofilter/metalvideofilterrenderer.h:48-70)."""
+    _free = "vfhip_videofilter_free"
+
+    def __init__(self, device=-1):
+        self.h = lib.vfhip_videofilter_new(device)
+        if not self.h:
+            raise VfHipError(-6, lib.vfhip_last_error_string().decode(errors="replace"))
+
+    def configure(self, in_fmt, w, h, out_fmt=None, colorimetry="bt601"):
+        self.in_fmt, self.out_fmt, self.w, self.hh = in_fmt, out_fmt or in_fmt, w, h
+        self.in_info = make_info(in_fmt, w, h, colorimetry)
+        self.out_info = make_info(self.out_fmt, w, h, colorimetry)
+        check(lib.vfhip_videofilter_configure(self.h, C.byref(self.in_info), C.byref(self.out_info)))
+        return self
+
+    def process(self, raw_in, params):
+        raw_in = np.ascontiguousarray(raw_in, dtype=np.uint8)
+        _, size = plane_layout(self.out_fmt, self.w, self.hh)
+        out = np.zeros(size, np.uint8)
+        fi = frame_from_base(self.in_info, self.in_fmt, self.w, self.hh, raw_in.ctypes.data)
+        fo = frame_from_base(self.out_info, self.out_fmt, self.w, self.hh, out.ctypes.data)
+        check(lib.vfhip_videofilter_process(self.h, C.byref(fi), C.byref(fo), C.byref(params)))
+        return out
+
+    def process_device(self, in_ptr, out_ptr, params, stream=None):
+        fi = frame_from_base(self.in_info, self.in_fmt, self.w, self.hh, in_ptr)
+        fo = frame_from_base(self.out_info, self.out_fmt, self.w, self.hh, out_ptr)
+        check(lib.vfhip_videofilter_process_device(self.h, C.byref(fi), C.byref(fo), C.byref(params), stream))
+
+    def load_lut(self, path):
+        check(lib.vfhip_videofilter_load_lut(self.h, path.encode()))
+
+    def set_lut(self, rgba):
+        rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+        size = int(round((rgba.size // 4) ** (1 / 3)))
+        assert size ** 3 * 4 == rgba.size
+        check(lib.vfhip_videofilter_set_lut(self.h, rgba.ctypes.data, size))
+
+    def clear_lut(self):
+        lib.vfhip_videofilter_clear_lut(self.h)
+
+    @property
+    def lut_size(self):
+        return lib.vfhip_videofilter_lut_size(self.h)
+
+
+class Compositor(_Element):
+    """MetalCompositorRenderer equivalent (reference compositor/metalcomprenderer.h:51-63)."""
+    _free = "vfhip_compositor_free"
+
+    def __init__(self, device=-1):
+        self.h = lib.vfhip_compositor_new(device)
+        if not self.h:
+            raise VfHipError(-6, lib.vfhip_last_error_string().decode(errors="replace"))
+
+    def configure(self, fmt, w, h, colorimetry="bt601"):
+        self.fmt, self.w, self.hh = fmt, w, h
+        self.info = make_info(fmt, w, h, colorimetry)
+        check(lib.vfhip_compositor_configure(self.h, C.byref(self.info)))
+        return self
+
+    @staticmethod
+    def pad(fmt, w, h, base_ptr, xpos, ypos, width, height, alpha=1.0, blend="over", colorimetry="bt601"):
+        p = PadInput()
+        p.frame = frame_from_base(make_info(fmt, w, h, colorimetry), fmt, w, h, base_ptr)
+        p.xpos, p.ypos, p.width, p.height, p.alpha, p.blend_mode = xpos, ypos, width, height, alpha, BLEND_MODES[blend]
+        return p
+
+    def composite(self, pads, background="checker"):
+        """pads: list of (fmt, w, h, raw ndarray, xpos, ypos, width, height, alpha, blend[, colorimetry])."""
+        keep = [np.ascontiguousarray(p[3], dtype=np.uint8) for p in pads]
+        arr = (PadInput * max(len(pads), 1))()
+        for i, p in enumerate(pads):
+            arr[i] = self.pad(p[0], p[1], p[2], keep[i].ctypes.data, *p[4:])
+        _, size = plane_layout(self.fmt, self.w, self.hh)
+        out = np.zeros(size, np.uint8)
+        fo = frame_from_base(self.info, self.fmt, self.w, self.hh, out.ctypes.data)
+        check(lib.vfhip_compositor_composite(self.h, arr, len(pads), BACKGROUNDS[background], C.byref(fo)))
+        return out
+
+    def composite_device(self, pad_structs, out_ptr, background="checker", stream=None):
+        arr = (PadInput * max(len(pad_structs), 1))(*pad_structs)
+        fo = frame_from_base(self.info, self.fmt, self.w, self.hh, out_ptr)
+        check(lib.vfhip_compositor_composite_device(self.h, arr, len(pad_structs), BACKGROUNDS[background], C.byref(fo), stream))

@@ -144,6 +144,78 @@ const char *vfhip_convertscale_kernel_name (VfHipConvertScale *h);
 void vfhip_convertscale_cleanup (VfHipConvertScale *h);   /* -cleanup: drop GPU resources, keep the handle */
 void vfhip_convertscale_free (VfHipConvertScale *h);
 
+/* ---- deinterlace (reference: MetalDeinterlaceRenderer, deinterlace/metaldeinterlacerenderer.h:29-54) ------- */
+typedef enum {
+  VFHIP_DEINTERLACE_BOB = 0,       /* VF_METAL_DEINTERLACE_BOB */
+  VFHIP_DEINTERLACE_WEAVE = 1,
+  VFHIP_DEINTERLACE_LINEAR = 2,    /* identical to bob in the reference (metaldeinterlace_shaders.h:148) */
+  VFHIP_DEINTERLACE_GREEDYH = 3
+} VfHipDeinterlaceMethod;
+
+typedef struct {                   /* DeinterlaceParams, metaldeinterlacerenderer.h:36-40 */
+  int32_t method;
+  int32_t top_field_first;
+  float motion_threshold;          /* greedyh: RGB euclidean distance in unorm units */
+  int32_t reserved;
+} VfHipDeinterlaceParams;
+
+typedef struct VfHipDeinterlace VfHipDeinterlace;
+VfHipDeinterlace *vfhip_deinterlace_new (int device);
+int vfhip_deinterlace_configure (VfHipDeinterlace *h, const VfHipVideoInfo *info);            /* -configureWithInfo: (resets history) */
+int vfhip_deinterlace_process (VfHipDeinterlace *h, const VfHipFrame *in, VfHipFrame *out, const VfHipDeinterlaceParams *params);
+/* device frames, asynchronous; the previous input frame is kept in an internal device buffer (stream-ordered copy) */
+int vfhip_deinterlace_process_device (VfHipDeinterlace *h, const VfHipFrame *in, VfHipFrame *out,
+    const VfHipDeinterlaceParams *params, void *stream);
+int vfhip_deinterlace_reset (VfHipDeinterlace *h);                                            /* drop the 1-frame history */
+void vfhip_deinterlace_cleanup (VfHipDeinterlace *h);
+void vfhip_deinterlace_free (VfHipDeinterlace *h);
+
+/* ---- videofilter (reference: MetalVideoFilterRenderer, videofilter/metalvideofilterrenderer.h:30-70) -------- */
+typedef struct {                   /* VideoFilterParams, metalvideofilterrenderer.h:30-46 */
+  float brightness, contrast, saturation;
+  float hue;                       /* radians */
+  float gamma, sharpness, sepia, noise, vignette;
+  int32_t invert;
+  int32_t chroma_key_enabled;
+  float chroma_key_r, chroma_key_g, chroma_key_b;
+  float chroma_key_tolerance, chroma_key_smoothness;
+  uint32_t frame_index;
+} VfHipVideoFilterParams;
+
+typedef struct VfHipVideoFilter VfHipVideoFilter;
+VfHipVideoFilter *vfhip_videofilter_new (int device);
+int vfhip_videofilter_configure (VfHipVideoFilter *h, const VfHipVideoInfo *in, const VfHipVideoInfo *out);
+int vfhip_videofilter_process (VfHipVideoFilter *h, const VfHipFrame *in, VfHipFrame *out, const VfHipVideoFilterParams *params);
+int vfhip_videofilter_process_device (VfHipVideoFilter *h, const VfHipFrame *in, VfHipFrame *out,
+    const VfHipVideoFilterParams *params, void *stream);
+int vfhip_videofilter_load_lut (VfHipVideoFilter *h, const char *path);                       /* -loadLUTFromFile: (.cube only) */
+int vfhip_videofilter_set_lut (VfHipVideoFilter *h, const float *rgba, int size);             /* size^3 RGBA32F, R fastest */
+void vfhip_videofilter_clear_lut (VfHipVideoFilter *h);
+int vfhip_videofilter_lut_size (VfHipVideoFilter *h);
+void vfhip_videofilter_cleanup (VfHipVideoFilter *h);
+void vfhip_videofilter_free (VfHipVideoFilter *h);
+
+/* ---- compositor (reference: MetalCompositorRenderer, compositor/metalcomprenderer.h:29-63) ------------------ */
+typedef enum { VFHIP_BLEND_SOURCE = 0, VFHIP_BLEND_OVER = 1, VFHIP_BLEND_ADD = 2 } VfHipBlendMode;
+typedef enum { VFHIP_BG_CHECKER = 0, VFHIP_BG_BLACK = 1, VFHIP_BG_WHITE = 2, VFHIP_BG_TRANSPARENT = 3 } VfHipBackground;
+
+typedef struct {                   /* MetalPadInput, metalcomprenderer.h:43-49 */
+  VfHipFrame frame;
+  int32_t xpos, ypos, width, height;
+  double alpha;
+  int32_t blend_mode;
+  int32_t reserved;
+} VfHipPadInput;
+
+typedef struct VfHipCompositor VfHipCompositor;
+VfHipCompositor *vfhip_compositor_new (int device);
+int vfhip_compositor_configure (VfHipCompositor *h, const VfHipVideoInfo *out);               /* -configureWithWidth:height:format: */
+int vfhip_compositor_composite (VfHipCompositor *h, const VfHipPadInput *inputs, int count, int background, VfHipFrame *out);
+int vfhip_compositor_composite_device (VfHipCompositor *h, const VfHipPadInput *inputs, int count, int background,
+    VfHipFrame *out, void *stream);
+void vfhip_compositor_cleanup (VfHipCompositor *h);
+void vfhip_compositor_free (VfHipCompositor *h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,3 +23,9 @@ def oracle():
 def vfhip():
     import vfhip as m
     return m
+
+
+@pytest.fixture(scope="session")
+def metalref():
+    import oracle_lib
+    return oracle_lib.load_metalref()

@@ -89,3 +89,115 @@ def load_golden(name="convertscale_gst114.npz"):
     z = np.load(os.path.join(ROOT, "tests", "golden", name), allow_pickle=False)
     manifest = json.loads(bytes(z["manifest"]).decode())
     return manifest, z
+
+
+# ---- metalref (oracle/metalref.c): float restatement of the reference's Metal shaders ---------------------------
+FMT = {"BGRA": 0, "RGBA": 1, "NV12": 2, "I420": 3, "UYVY": 4, "YUY2": 5}
+
+
+class MrImg(C.Structure):
+    _fields_ = [("p", C.c_void_p * 3), ("s", C.c_int32 * 3), ("w", C.c_int32), ("h", C.c_int32), ("fmt", C.c_int32),
+                ("m709", C.c_int32)]
+
+
+class MrFilterParams(C.Structure):
+    _fields_ = [("brightness", C.c_float), ("contrast", C.c_float), ("saturation", C.c_float), ("hue", C.c_float),
+                ("gamma", C.c_float), ("sharpness", C.c_float), ("sepia", C.c_float), ("noise", C.c_float),
+                ("vignette", C.c_float), ("invert", C.c_int32), ("chroma_key_enabled", C.c_int32), ("key_r", C.c_float),
+                ("key_g", C.c_float), ("key_b", C.c_float), ("key_tolerance", C.c_float), ("key_smoothness", C.c_float),
+                ("frame_index", C.c_uint32)]
+
+
+class MrPad(C.Structure):
+    _fields_ = [("img", MrImg), ("xpos", C.c_int32), ("ypos", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("alpha", C.c_double), ("blend", C.c_int32)]
+
+
+def raw_layout(fmt, w, h):
+    """GstVideoInfo default layout: [(offset, stride)], size."""
+    hp = (h + 1) // 2 * 2
+    if fmt in ("BGRA", "RGBA"):
+        return [(0, 4 * w)], 4 * w * h
+    if fmt in ("UYVY", "YUY2"):
+        s = r4(2 * w)
+        return [(0, s)], s * h
+    if fmt == "NV12":
+        s = r4(w)
+        return [(0, s), (s * hp, s)], s * hp + s * (hp // 2)
+    s, cs = r4(w), r4((w + 1) // 2)
+    uo = s * hp
+    vo = uo + cs * (hp // 2)
+    return [(0, s), (uo, cs), (vo, cs)], vo + cs * (hp // 2)
+
+
+def mr_img(fmt, w, h, raw, m709=False):
+    im = MrImg()
+    pl, size = raw_layout(fmt, w, h)
+    assert raw.size >= size and raw.dtype == np.uint8 and raw.flags["C_CONTIGUOUS"]
+    for i, (off, stride) in enumerate(pl):
+        im.p[i] = raw.ctypes.data + off
+        im.s[i] = stride
+    im.w, im.h, im.fmt, im.m709 = w, h, FMT[fmt], int(m709)
+    return im
+
+
+class MetalRef:
+    def __init__(self, lib):
+        self.lib = lib
+
+    def convertscale(self, in_fmt, w, h, raw, out_fmt, ow, oh, linear=True, add_borders=False, border=0xFF000000,
+                     m709_in=False, m709_out=False):
+        raw = np.ascontiguousarray(raw, np.uint8)
+        out = np.zeros(raw_layout(out_fmt, ow, oh)[1], np.uint8)
+        i, o = mr_img(in_fmt, w, h, raw, m709_in), mr_img(out_fmt, ow, oh, out, m709_out)
+        assert self.lib.metalref_convertscale(C.byref(i), C.byref(o), int(linear), int(add_borders), C.c_uint32(border)) == 0
+        return out
+
+    def deinterlace(self, fmt, w, h, cur, prev, method, tff=True, threshold=0.1, m709=False):
+        cur = np.ascontiguousarray(cur, np.uint8)
+        out = np.zeros(raw_layout(fmt, w, h)[1], np.uint8)
+        c, o = mr_img(fmt, w, h, cur, m709), mr_img(fmt, w, h, out, m709)
+        pp = None
+        if prev is not None:
+            prev = np.ascontiguousarray(prev, np.uint8)
+            pimg = mr_img(fmt, w, h, prev, m709)
+            pp = C.byref(pimg)
+        assert self.lib.metalref_deinterlace(C.byref(c), pp, C.byref(o), method, int(tff), C.c_float(threshold)) == 0
+        return out
+
+    def videofilter(self, in_fmt, w, h, raw, out_fmt, params, lut=None, m709=False):
+        raw = np.ascontiguousarray(raw, np.uint8)
+        out = np.zeros(raw_layout(out_fmt, w, h)[1], np.uint8)
+        i, o = mr_img(in_fmt, w, h, raw, m709), mr_img(out_fmt, w, h, out, m709)
+        lp, n = None, 0
+        if lut is not None:
+            lut = np.ascontiguousarray(lut, np.float32)
+            n = int(round((lut.size // 4) ** (1 / 3)))
+            lp = lut.ctypes.data_as(C.c_void_p)
+        assert self.lib.metalref_videofilter(C.byref(i), C.byref(o), C.byref(params), lp, n) == 0
+        return out
+
+    def compositor(self, out_fmt, ow, oh, pads, background, m709_out=False):
+        """pads: list of (fmt, w, h, raw, xpos, ypos, width, height, alpha, blend_int[, m709])."""
+        out = np.zeros(raw_layout(out_fmt, ow, oh)[1], np.uint8)
+        o = mr_img(out_fmt, ow, oh, out, m709_out)
+        keep = [np.ascontiguousarray(p[3], np.uint8) for p in pads]
+        arr = (MrPad * max(len(pads), 1))()
+        for k, p in enumerate(pads):
+            arr[k].img = mr_img(p[0], p[1], p[2], keep[k], p[10] if len(p) > 10 else False)
+            arr[k].xpos, arr[k].ypos, arr[k].width, arr[k].height, arr[k].alpha, arr[k].blend = p[4], p[5], p[6], p[7], p[8], p[9]
+        assert self.lib.metalref_compositor(arr, len(pads), background, C.byref(o)) == 0
+        return out
+
+
+def load_metalref():
+    build()
+    lib = C.CDLL(LIB)
+    for n in ("metalref_convertscale", "metalref_deinterlace", "metalref_videofilter", "metalref_compositor"):
+        getattr(lib, n).restype = C.c_int
+    return MetalRef(lib)
+
+
+def mr_filter_params(p):
+    """vfhip.VideoFilterParams -> MrFilterParams (same field order)."""
+    return MrFilterParams(*[getattr(p, f[0]) for f in p._fields_])

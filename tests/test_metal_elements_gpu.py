@@ -1,0 +1,312 @@
+"""GPU parity of the `metal`-numerics kernels (convertscale metal path, deinterlace, videofilter, compositor) through
+the C ABI against the float oracle oracle/metalref.c.  Tolerance: +-1 LSB per byte (north_star), written below as TOL;
+in practice both sides evaluate identical expressions with -ffp-contract=off, so almost every byte is identical and the
+tests also bound the fraction of off-by-one bytes.  PARITY UNPINNED vs real Metal (see oracle/metalref.c header)."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+TOL = 1
+
+
+def rnd(fmt, w, h, seed=0):
+    return np.random.default_rng(seed).integers(0, 256, ol.raw_layout(fmt, w, h)[1], dtype=np.uint8)
+
+
+def smooth(fmt, w, h, seed=0):
+    """low-frequency content (so that bilinear / blur paths see realistic gradients) + a little noise"""
+    rng = np.random.default_rng(seed)
+    raw = np.zeros(ol.raw_layout(fmt, w, h)[1], np.uint8)
+    pl, _ = ol.raw_layout(fmt, w, h)
+    for i, (off, stride) in enumerate(pl):
+        rows = h if i == 0 or fmt not in ("NV12", "I420") else (h + 1) // 2
+        yy, xx = np.mgrid[0:rows, 0:stride]
+        v = 128 + 90 * np.sin(xx / (7.0 + i)) * np.cos(yy / (5.0 + 2 * i)) + rng.integers(-6, 7, (rows, stride))
+        raw[off:off + rows * stride] = np.clip(v, 0, 255).astype(np.uint8).reshape(-1)
+    return raw
+
+
+def close(got, want, what="", max_off_by_one=0.02):
+    d = np.abs(got.astype(int) - want.astype(int))
+    assert d.max() <= TOL, f"{what}: max diff {d.max()} at {np.argmax(d)} ({(d > TOL).sum()} bytes beyond tolerance)"
+    assert (d > 0).mean() <= max_off_by_one, f"{what}: {(d > 0).mean():.4f} of bytes differ by 1"
+
+
+FORMATS6 = ["BGRA", "RGBA", "NV12", "I420", "UYVY", "YUY2"]
+
+
+@pytest.mark.parametrize("ifmt", FORMATS6)
+@pytest.mark.parametrize("ofmt", FORMATS6)
+def test_convertscale_metal_matrix(vfhip, metalref, ifmt, ofmt):
+    """the reference's full 6x6 format matrix (tests/test-convertscale.sh:62-99 shapes), metal numerics, with scaling"""
+    for (w, h, ow, oh, method) in [(64, 36, 40, 30, "bilinear"), (33, 17, 66, 35, "nearest"), (48, 32, 48, 32, "bilinear")]:
+        raw = smooth(ifmt, w, h, 3)
+        cs = vfhip.ConvertScale(0)
+        cs.configure(ifmt, w, h, ofmt, ow, oh, method=method, numerics="metal", colorimetry="bt709")
+        assert cs.kernel_name == "k_cs_metal"
+        got = cs.process(raw)
+        cs.close()
+        want = metalref.convertscale(ifmt, w, h, raw, ofmt, ow, oh, linear=(method == "bilinear"), m709_in=True, m709_out=True)
+        close(got, want, f"{ifmt}->{ofmt} {w}x{h}->{ow}x{oh} {method}")
+
+
+def test_convertscale_gst_exact_falls_back_to_metal_for_unpinned_cells(vfhip, metalref):
+    raw = smooth("UYVY", 64, 32, 1)
+    cs = vfhip.ConvertScale(0)
+    cs.configure("UYVY", 64, 32, "NV12", 32, 16, numerics="gst-exact")
+    assert cs.kernel_name == "k_cs_metal"
+    close(cs.process(raw), metalref.convertscale("UYVY", 64, 32, raw, "NV12", 32, 16), "UYVY->NV12")
+    cs.close()
+
+
+@pytest.mark.parametrize("w,h,ow,oh", [(64, 16, 32, 32), (16, 64, 32, 32), (40, 30, 64, 64), (64, 36, 64, 36)])
+def test_convertscale_letterbox(vfhip, metalref, w, h, ow, oh):
+    raw = smooth("BGRA", w, h, 2)
+    cs = vfhip.ConvertScale(0)
+    cs.configure("BGRA", w, h, "BGRA", ow, oh, add_borders=True, border_color=0x80FF2010, numerics="metal")
+    close(cs.process(raw), metalref.convertscale("BGRA", w, h, raw, "BGRA", ow, oh, add_borders=True, border=0x80FF2010), "letterbox")
+    cs.close()
+
+
+@pytest.mark.parametrize("fmt", ["BGRA", "RGBA", "NV12", "I420"])
+@pytest.mark.parametrize("method", ["bob", "weave", "linear", "greedyh"])
+def test_deinterlace_methods(vfhip, metalref, fmt, method):
+    """4 methods x 4 formats (reference tests/test-deinterlace.sh), 3 frames so that the history path is exercised;
+    odd and even sizes; both field orders."""
+    for (w, h, tff) in [(64, 36, True), (33, 19, False)]:
+        frames = [smooth(fmt, w, h, 10 + k) for k in range(3)]
+        frames[2] = frames[1].copy()                       # a static frame: greedyh must weave
+        d = vfhip.Deinterlace(0)
+        d.configure(fmt, w, h, colorimetry="bt709")
+        prev = None
+        for k, f in enumerate(frames):
+            got = d.process(f, method=method, tff=tff, threshold=0.08)
+            want = metalref.deinterlace(fmt, w, h, f, prev, vfhip.DEINTERLACE_METHODS[method], tff=tff, threshold=0.08, m709=True)
+            close(got, want, f"{fmt} {method} frame {k} {w}x{h}")
+            prev = f
+        d.reset()                                          # history dropped: weave / greedyh fall back to bob
+        got = d.process(frames[0], method=method, tff=tff)
+        want = metalref.deinterlace(fmt, w, h, frames[0], None, vfhip.DEINTERLACE_METHODS[method], tff=tff, m709=True)
+        close(got, want, f"{fmt} {method} after reset")
+        d.close()
+
+
+def test_deinterlace_device_path_history(vfhip, metalref):
+    import torch
+    fmt, w, h = "NV12", 128, 72
+    size = ol.raw_layout(fmt, w, h)[1]
+    frames = [smooth(fmt, w, h, 20 + k) for k in range(3)]
+    d = vfhip.Deinterlace(0)
+    d.configure(fmt, w, h)
+    s = torch.cuda.Stream()
+    prev = None
+    for f in frames:
+        din = torch.from_numpy(f).cuda()
+        dout = torch.zeros(size, dtype=torch.uint8, device="cuda")
+        s.wait_stream(torch.cuda.current_stream())
+        d.process_device(din.data_ptr(), dout.data_ptr(), method="greedyh", tff=True, threshold=0.05, stream=s.cuda_stream)
+        s.synchronize()
+        close(dout.cpu().numpy(), metalref.deinterlace(fmt, w, h, f, prev, 3, threshold=0.05), "device greedyh")
+        prev = f
+    d.close()
+
+
+SINGLE = [dict(brightness=0.3), dict(brightness=-0.4), dict(contrast=1.7), dict(contrast=0.3), dict(saturation=0.0), dict(saturation=1.8),
+          dict(hue=1.0), dict(hue=-2.5), dict(gamma=2.2), dict(gamma=0.45), dict(sepia=0.8), dict(invert=True), dict(vignette=0.9),
+          dict(chroma_key=(0.0, 1.0, 0.0), tolerance=0.3, smoothness=0.1), dict(chroma_key=(0.5, 0.5, 0.5), tolerance=0.2, smoothness=0.0),
+          dict(sharpness=0.8), dict(sharpness=-0.6)]
+# the reference's "all colour adjustments" set (tests/test-videofilter.sh:198-201) + invert + chroma key (:183-186)
+ALL15 = dict(brightness=0.1, contrast=1.2, saturation=0.8, hue=0.3 * np.pi, gamma=1.5, sharpness=0.5, sepia=0.2, vignette=0.3,
+             invert=True, chroma_key=(0.0, 1.0, 0.0), tolerance=0.3, smoothness=0.1)
+
+
+@pytest.mark.parametrize("kw", SINGLE, ids=[",".join(k) for k in SINGLE])
+def test_videofilter_single_properties(vfhip, metalref, kw):
+    w, h = 96, 40
+    raw = smooth("BGRA", w, h, 5)
+    vf = vfhip.VideoFilter(0)
+    vf.configure("BGRA", w, h)
+    prm = vfhip.filter_params(**kw)
+    # pow / hue paths go through libm vs OCML: allow more off-by-one bytes, never more than 1 LSB
+    close(vf.process(raw, prm), metalref.videofilter("BGRA", w, h, raw, "BGRA", ol.mr_filter_params(prm)), str(kw), max_off_by_one=0.05)
+    vf.close()
+
+
+@pytest.mark.parametrize("ifmt,ofmt", [("BGRA", "BGRA"), ("RGBA", "BGRA"), ("NV12", "NV12"), ("I420", "I420"), ("NV12", "BGRA"), ("BGRA", "I420")])
+@pytest.mark.parametrize("w,h", [(96, 40), (71, 37)])
+def test_videofilter_all_effects_and_formats(vfhip, metalref, ifmt, ofmt, w, h):
+    raw = smooth(ifmt, w, h, 6)
+    n = 9
+    g = np.linspace(0, 1, n, dtype=np.float32)
+    lut = np.ones((n, n, n, 4), np.float32)
+    lut[..., 0] = g[None, None, :] ** 1.1
+    lut[..., 1] = g[None, :, None] * 0.9
+    lut[..., 2] = 1.0 - g[:, None, None]
+    vf = vfhip.VideoFilter(0)
+    vf.configure(ifmt, w, h, ofmt, colorimetry="bt709")
+    vf.set_lut(lut)
+    assert vf.lut_size == n
+    prm = vfhip.filter_params(**ALL15)
+    close(vf.process(raw, prm), metalref.videofilter(ifmt, w, h, raw, ofmt, ol.mr_filter_params(prm), lut=lut, m709=True),
+          f"all15 {ifmt}->{ofmt}", max_off_by_one=0.08)
+    vf.clear_lut()
+    assert vf.lut_size == 0
+    close(vf.process(raw, prm), metalref.videofilter(ifmt, w, h, raw, ofmt, ol.mr_filter_params(prm), m709=True), "all15 no lut", max_off_by_one=0.08)
+    vf.close()
+
+
+def test_videofilter_noise_statistics(vfhip, metalref):
+    """float32 fract chains amplify ULP differences: compare statistically"""
+    w, h = 128, 64
+    raw = np.full(ol.raw_layout("BGRA", w, h)[1], 128, np.uint8)
+    vf = vfhip.VideoFilter(0)
+    vf.configure("BGRA", w, h)
+    outs = []
+    for frame in (0, 1):
+        prm = vfhip.filter_params(noise=0.5, frame_index=frame)
+        got = vf.process(raw, prm).reshape(h, w, 4)[..., :3].astype(float)
+        want = metalref.videofilter("BGRA", w, h, raw, "BGRA", ol.mr_filter_params(prm)).reshape(h, w, 4)[..., :3].astype(float)
+        assert abs(got.mean() - want.mean()) < 1.0 and abs(got.std() - want.std()) < 1.0
+        assert (np.abs(got - want) <= 1).mean() > 0.98          # the hash is well conditioned almost everywhere
+        assert got.std() > 10                                    # noise=.5 -> +-0.125 uniform -> sigma ~ 18 LSB
+        outs.append(got)
+    assert np.corrcoef(outs[0].ravel(), outs[1].ravel())[0, 1] < 0.2   # per-frame decorrelation
+    vf.close()
+
+
+def test_videofilter_cube_lut_file(vfhip, metalref, tmp_path):
+    n = 5
+    path = tmp_path / "t.cube"
+    rows = ["# comment", "TITLE \"t\"", f"LUT_3D_SIZE {n}", "DOMAIN_MIN 0 0 0", "DOMAIN_MAX 1 1 1"]
+    lut = np.ones((n, n, n, 4), np.float32)
+    for b in range(n):
+        for g in range(n):
+            for r in range(n):
+                v = (r / (n - 1) * 0.5, g / (n - 1), 1 - b / (n - 1))
+                lut[b, g, r, :3] = v
+                rows.append("%.6f %.6f %.6f" % v)
+    path.write_text("\n".join(rows) + "\n")
+    w, h = 48, 24
+    raw = smooth("RGBA", w, h, 8)
+    vf = vfhip.VideoFilter(0)
+    vf.configure("RGBA", w, h)
+    vf.load_lut(str(path))
+    assert vf.lut_size == n
+    prm = vfhip.filter_params()
+    lut = np.float32(np.round(lut, 6))
+    close(vf.process(raw, prm), metalref.videofilter("RGBA", w, h, raw, "RGBA", ol.mr_filter_params(prm), lut=lut), "cube", max_off_by_one=0.05)
+    with pytest.raises(vfhip.VfHipError) as e:
+        vf.load_lut(str(tmp_path / "missing.cube"))
+    assert e.value.code == -7
+    with pytest.raises(vfhip.VfHipError) as e:
+        vf.load_lut(str(tmp_path / "lut.png"))
+    assert e.value.code == -2
+    (tmp_path / "bad.cube").write_text("LUT_3D_SIZE 3\n0 0 0\n")
+    with pytest.raises(vfhip.VfHipError):
+        vf.load_lut(str(tmp_path / "bad.cube"))
+    assert vf.lut_size == n                                       # a failed load leaves the old LUT in place
+    vf.close()
+
+
+def test_videofilter_1080p_c3_config(vfhip, metalref):
+    """BASELINE config 2 shape: BGRA 1920x1080, all 15 properties; a 256-row band is checked against the oracle
+    (the kernel is local: 4-pixel blur halo), the whole frame for determinism."""
+    w, h = 1920, 1080
+    raw = smooth("BGRA", w, h, 9)
+    prm = vfhip.filter_params(**ALL15)
+    vf = vfhip.VideoFilter(0)
+    vf.configure("BGRA", w, h)
+    a = vf.process(raw, prm)
+    b = vf.process(raw, prm)
+    assert np.array_equal(a, b)
+    hb = 264
+    band = raw[: 4 * w * hb]
+    # vignette / texcoord depend on the full frame size, so the oracle must see the full frame: run it on the full
+    # frame but only for this test (about 2 s on the CPU)
+    want = metalref.videofilter("BGRA", w, h, raw, "BGRA", ol.mr_filter_params(prm))
+    close(a, want, "C3 1080p", max_off_by_one=0.08)
+    assert band.size
+    vf.close()
+
+
+def pads_case(w, h, seed=0):
+    a = smooth("BGRA", 64, 48, seed)
+    a.reshape(-1, 4)[:, 3] = np.random.default_rng(seed).integers(0, 256, 64 * 48)
+    b = smooth("NV12", 40, 30, seed + 1)
+    c = smooth("I420", 33, 21, seed + 2)
+    d = smooth("RGBA", 16, 16, seed + 3)
+    return [("BGRA", 64, 48, a, 4, 6, 64, 48, 0.9, 1),            # unscaled
+            ("NV12", 40, 30, b, 30, 10, 60, 45, 0.7, 1, True),    # upscaled, bt709
+            ("I420", 33, 21, c, -10, 40, 50, 30, 1.0, 2),         # partly off-screen, ADD
+            ("RGBA", 16, 16, d, w - 20, h - 12, 32, 24, 0.5, 0)]  # hangs over the corner, SOURCE
+
+
+def to_vf(vfhip, pads):
+    inv = {0: "source", 1: "over", 2: "add"}
+    return [(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], inv[p[9]], "bt709" if len(p) > 10 and p[10] else "bt601") for p in pads]
+
+
+@pytest.mark.parametrize("bg", ["checker", "black", "white", "transparent"])
+@pytest.mark.parametrize("ofmt", ["BGRA", "RGBA", "NV12", "I420"])
+def test_compositor_backgrounds_formats(vfhip, metalref, bg, ofmt):
+    w, h = 100, 75
+    pads = pads_case(w, h, 4)
+    comp = vfhip.Compositor(0)
+    comp.configure(ofmt, w, h, colorimetry="bt709")
+    got = comp.composite(to_vf(vfhip, pads), background=bg)
+    want = metalref.compositor(ofmt, w, h, pads, vfhip.BACKGROUNDS[bg], m709_out=True)
+    close(got, want, f"compositor {bg} {ofmt}")
+    comp.close()
+
+
+def test_compositor_no_pads_and_many_pads(vfhip, metalref):
+    w, h = 64, 40
+    comp = vfhip.Compositor(0)
+    comp.configure("BGRA", w, h)
+    assert np.array_equal(comp.composite([], background="checker"), metalref.compositor("BGRA", w, h, [], 0))
+    rng = np.random.default_rng(1)
+    pads = []
+    for k in range(37):                                        # > 16 layers: chained passes through the RGBA8 scratch
+        pw, ph = int(rng.integers(4, 30)), int(rng.integers(4, 30))
+        raw = rnd("BGRA", pw, ph, 100 + k)
+        pads.append(("BGRA", pw, ph, raw, int(rng.integers(-8, w)), int(rng.integers(-8, h)), int(rng.integers(4, 40)), int(rng.integers(4, 40)),
+                     float(rng.uniform(0.2, 1.0)), int(rng.integers(0, 3))))
+    got = comp.composite(to_vf(vfhip, pads), background="black")
+    close(got, metalref.compositor("BGRA", w, h, pads, 1), "37 pads", max_off_by_one=0.05)
+    comp.close()
+
+
+def test_compositor_c4_config(vfhip, metalref):
+    """BASELINE config 3: 4 x BGRA 1080p quadrants (alpha .9, over, z 0-3) + NV12 720p centred (alpha .7, z 4) -> 2160p,
+    background black.  Whole frame vs oracle."""
+    w, h = 3840, 2160
+    quads = [smooth("BGRA", 1920, 1080, 30 + k) for k in range(4)]
+    nv = smooth("NV12", 1280, 720, 40)
+    pads = [("BGRA", 1920, 1080, quads[k], (k % 2) * 1920, (k // 2) * 1080, 1920, 1080, 0.9, 1) for k in range(4)]
+    pads.append(("NV12", 1280, 720, nv, (w - 1280) // 2, (h - 720) // 2, 1280, 720, 0.7, 1, True))
+    comp = vfhip.Compositor(0)
+    comp.configure("BGRA", w, h)
+    got = comp.composite(to_vf(vfhip, pads), background="black")
+    close(got, metalref.compositor("BGRA", w, h, pads, 1), "C4")
+    comp.close()
+
+
+def test_metal_element_errors(vfhip):
+    import ctypes as C
+    d = vfhip.Deinterlace(0)
+    fi, fo, prm = vfhip.Frame(), vfhip.Frame(), vfhip.DeinterlaceParams(0, 1, 0.1, 0)
+    assert vfhip.lib.vfhip_deinterlace_process(d.h, C.byref(fi), C.byref(fo), C.byref(prm)) == -3
+    with pytest.raises(vfhip.VfHipError):
+        d.configure("UYVY", 16, 16)
+    d.close()
+    vf = vfhip.VideoFilter(0)
+    with pytest.raises(vfhip.VfHipError):
+        vf.in_fmt = vf.out_fmt = "BGRA"
+        a, b = vfhip.make_info("BGRA", 16, 16), vfhip.make_info("BGRA", 32, 16)
+        vfhip.check(vfhip.lib.vfhip_videofilter_configure(vf.h, C.byref(a), C.byref(b)))
+    vf.close()
+    c = vfhip.Compositor(0)
+    assert vfhip.lib.vfhip_compositor_composite(c.h, None, 0, 0, C.byref(fo)) == -3
+    c.close()
