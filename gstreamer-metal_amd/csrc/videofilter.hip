@@ -72,6 +72,29 @@ __device__ __forceinline__ void hsv_to_rgb (float h, float s, float v, float *r,
   *b = v * mixf (1.0f, clamp01 (pb - 1.0f), s);
 }
 
+
+// pow(x, y) for x in [1e-4, 1], y > 0 (gamma stage): the same fixed sequence of IEEE single-precision operations as
+// oracle/metalref.c vf_powf — atanh-series log2 on the reduced mantissa, degree-7 exp2 — so both sides agree bit for
+// bit (libm and OCML powf do not, and MSL's fast-math pow is not correctly rounded anyway: SURVEY.md Appendix B item 8).
+__device__ __forceinline__ float vf_powf (float x, float y)
+{
+  const uint32_t ux = __float_as_uint (x);
+  int e = (int) (ux >> 23) - 127;
+  float m = __uint_as_float ((ux & 0x007fffffu) | 0x3f800000u);
+  if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+  const float t = (m - 1.0f) / (m + 1.0f), t2 = t * t;
+  float p = 0.11111111f;
+  p = p * t2 + 0.14285714f; p = p * t2 + 0.2f; p = p * t2 + 0.33333333f; p = p * t2 + 1.0f;
+  const float l2 = (float) e + (t * p) * 2.88539008f;
+  const float z = y * l2;
+  if (z < -126.0f) return 0.0f;
+  const float zi = floorf (z + 0.5f), f = (z - zi) * 0.69314718f;
+  float q = 1.98412698e-4f;
+  q = q * f + 1.38888889e-3f; q = q * f + 8.33333333e-3f; q = q * f + 4.16666667e-2f; q = q * f + 0.16666667f;
+  q = q * f + 0.5f; q = q * f + 1.0f; q = q * f + 1.0f;
+  return __uint_as_float (__float_as_uint (q) + (uint32_t) ((int) zi << 23));
+}
+
 // applyColorAdjustments (metalvideofilter_shaders.h:92-155), fixed order
 __device__ __forceinline__ F4 color_adjust (F4 c, const VfHipVideoFilterParams &u, float tu, float tv, int W, int H)
 {
@@ -87,7 +110,7 @@ __device__ __forceinline__ F4 color_adjust (F4 c, const VfHipVideoFilterParams &
     hsv_to_rgb (h, s, v, &r, &g, &b);
   }
   const float ig = 1.0f / u.gamma;
-  r = powf (fminf (fmaxf (r, 0.0001f), 1.0f), ig); g = powf (fminf (fmaxf (g, 0.0001f), 1.0f), ig); b = powf (fminf (fmaxf (b, 0.0001f), 1.0f), ig);
+  r = vf_powf (fminf (fmaxf (r, 0.0001f), 1.0f), ig); g = vf_powf (fminf (fmaxf (g, 0.0001f), 1.0f), ig); b = vf_powf (fminf (fmaxf (b, 0.0001f), 1.0f), ig);
   if (u.sepia > 0.001f) {
     const float sr = r * 0.393f + g * 0.769f + b * 0.189f;
     const float sg = r * 0.349f + g * 0.686f + b * 0.168f;

@@ -11,7 +11,7 @@
  * PARITY UNPINNED: the reference cannot be built or run on Linux (Objective-C + Metal.framework), its tests hold
  * no pixel values, and GStreamer's CPU compositor/deinterlace are absent from this container.
  * Sampler weights, unorm rounding and fast-math builtins live in Apple's driver; this file fixes them as
- * Appendix B states (float weights, round-to-nearest-even unorm8 writes, IEEE libm).  The HIP kernels are checked
+ * Appendix B states (float weights, round-to-nearest-even unorm8 writes, IEEE sqrt / divide, own pow: vf_powf).  The HIP kernels are checked
  * against THIS file to +-1 LSB; nothing here has been compared with real Metal output.
  *
  * Built with -ffp-contract=off so that every expression rounds exactly as written (the HIP side does the same).
@@ -315,6 +315,35 @@ static void hsv_to_rgb (float h, float s, float v, float *r, float *g, float *b)
   *b = v * mixf (1.0f, clamp01 (pb - 1.0f), s);
 }
 
+
+/* pow(x, y) for x in [1e-4, 1], y > 0 — the gamma stage.  MSL's fast-math pow is not correctly rounded and neither
+ * libm nor OCML agree with it or with each other bit for bit, so the restatement defines its own: log2 by an atanh
+ * series on the mantissa reduced to [sqrt(.5), sqrt(2)), exp2 by a degree-7 polynomial on [-.5, .5], both in plain
+ * IEEE single-precision operations in a fixed order (relative error ~2e-7, far below 1/255).  The HIP kernel
+ * evaluates the identical sequence, so the two sides agree bit for bit. */
+static inline float vf_powf (float x, float y)
+{
+  uint32_t ux; memcpy (&ux, &x, 4);
+  int e = (int) (ux >> 23) - 127;
+  uint32_t um = (ux & 0x007fffffu) | 0x3f800000u;
+  float m; memcpy (&m, &um, 4);
+  if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+  const float t = (m - 1.0f) / (m + 1.0f), t2 = t * t;
+  float p = 0.11111111f;
+  p = p * t2 + 0.14285714f; p = p * t2 + 0.2f; p = p * t2 + 0.33333333f; p = p * t2 + 1.0f;
+  const float l2 = (float) e + (t * p) * 2.88539008f;        /* 2 / ln 2 */
+  const float z = y * l2;
+  if (z < -126.0f) return 0.0f;
+  const float zi = floorf (z + 0.5f), f = (z - zi) * 0.69314718f;
+  float q = 1.98412698e-4f;
+  q = q * f + 1.38888889e-3f; q = q * f + 8.33333333e-3f; q = q * f + 4.16666667e-2f; q = q * f + 0.16666667f;
+  q = q * f + 0.5f; q = q * f + 1.0f; q = q * f + 1.0f;
+  uint32_t uq; memcpy (&uq, &q, 4);
+  uq += (uint32_t) ((int) zi << 23);
+  float r; memcpy (&r, &uq, 4);
+  return r;
+}
+
 static F4 color_adjust (F4 c, const MrFilterParams *u, float tu, float tv, int W, int H)
 {
   float r = c.r, g = c.g, b = c.b, a = c.a;
@@ -329,7 +358,7 @@ static F4 color_adjust (F4 c, const MrFilterParams *u, float tu, float tv, int W
     hsv_to_rgb (h, s, v, &r, &g, &b);
   }
   const float ig = 1.0f / u->gamma;
-  r = powf (fminf (fmaxf (r, 0.0001f), 1.0f), ig); g = powf (fminf (fmaxf (g, 0.0001f), 1.0f), ig); b = powf (fminf (fmaxf (b, 0.0001f), 1.0f), ig);
+  r = vf_powf (fminf (fmaxf (r, 0.0001f), 1.0f), ig); g = vf_powf (fminf (fmaxf (g, 0.0001f), 1.0f), ig); b = vf_powf (fminf (fmaxf (b, 0.0001f), 1.0f), ig);
   if (u->sepia > 0.001f) {
     const float sr = r * 0.393f + g * 0.769f + b * 0.189f;
     const float sg = r * 0.349f + g * 0.686f + b * 0.168f;
