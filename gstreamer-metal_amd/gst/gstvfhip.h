@@ -1,0 +1,75 @@
+/* gst/gstvfhip.h — glue shared by the vfhip* element shells: GstVideoInfo / GstVideoFrame -> the C-ABI PODs of
+ * include/vfhip.h, the plugin-wide debug category, and the small compatibility layer that lets the same sources
+ * build against GStreamer 1.14 (this container) and >= 1.20 (what the reference requires, README.md:158).
+ *
+ * The shells keep the reference's element classes, pad templates, property names, nicks, ranges and defaults
+ * (SURVEY.md §8b "Element-level API that must stay identical"); everything below `void *renderer` is libvfhip. */
+#ifndef GST_VFHIP_H
+#define GST_VFHIP_H
+
+#include <gst/gst.h>
+#include <gst/video/video.h>
+#include "../../include/vfhip.h"
+
+G_BEGIN_DECLS
+
+GST_DEBUG_CATEGORY_EXTERN (gst_vfhip_debug);
+
+/* element registration without GST_ELEMENT_REGISTER_* (absent before 1.20) */
+gboolean gst_vfhip_convertscale_register (GstPlugin * plugin);
+gboolean gst_vfhip_videofilter_register (GstPlugin * plugin);
+gboolean gst_vfhip_deinterlace_register (GstPlugin * plugin);
+gboolean gst_vfhip_compositor_register (GstPlugin * plugin);
+
+/* new, additive properties every vfhip element has */
+#define GST_VFHIP_DEFAULT_DEVICE_ID (-1)       /* -1: $VFHIP_DEVICE, else GPU 0 */
+
+static inline gint
+gst_vfhip_format (GstVideoFormat f)
+{
+  switch (f) {
+    case GST_VIDEO_FORMAT_BGRA: return VFHIP_FORMAT_BGRA;
+    case GST_VIDEO_FORMAT_RGBA: return VFHIP_FORMAT_RGBA;
+    case GST_VIDEO_FORMAT_NV12: return VFHIP_FORMAT_NV12;
+    case GST_VIDEO_FORMAT_I420: return VFHIP_FORMAT_I420;
+    case GST_VIDEO_FORMAT_UYVY: return VFHIP_FORMAT_UYVY;
+    case GST_VIDEO_FORMAT_YUY2: return VFHIP_FORMAT_YUY2;
+    default: return -1;
+  }
+}
+
+/* matrix AND chroma siting come from the negotiated GstVideoInfo (SURVEY.md §8c rule 1): caps without
+ * colorimetry got GStreamer's by-height default when the info was parsed */
+static inline void
+gst_vfhip_info (const GstVideoInfo * gi, VfHipVideoInfo * vi)
+{
+  memset (vi, 0, sizeof (*vi));
+  vi->format = gst_vfhip_format (GST_VIDEO_INFO_FORMAT (gi));
+  vi->width = GST_VIDEO_INFO_WIDTH (gi);
+  vi->height = GST_VIDEO_INFO_HEIGHT (gi);
+  switch (gi->colorimetry.matrix) {
+    case GST_VIDEO_COLOR_MATRIX_BT709: vi->color_matrix = VFHIP_MATRIX_BT709; break;
+    case GST_VIDEO_COLOR_MATRIX_BT2020: vi->color_matrix = VFHIP_MATRIX_BT2020; break;
+    default: vi->color_matrix = VFHIP_MATRIX_BT601; break;
+  }
+  vi->chroma_site = ((gi->chroma_site & GST_VIDEO_CHROMA_SITE_H_COSITED) && !(gi->chroma_site & GST_VIDEO_CHROMA_SITE_V_COSITED))
+      ? VFHIP_CHROMA_SITE_H_COSITED : VFHIP_CHROMA_SITE_CENTER;
+}
+
+/* frames are borrowed: the caller (base class or shell) maps before and unmaps after the libvfhip call */
+static inline void
+gst_vfhip_frame (GstVideoFrame * gf, VfHipFrame * vf)
+{
+  guint p;
+  memset (vf, 0, sizeof (*vf));
+  gst_vfhip_info (&gf->info, &vf->info);
+  for (p = 0; p < GST_VIDEO_FRAME_N_PLANES (gf) && p < VFHIP_MAX_PLANES; p++) {
+    vf->data[p] = GST_VIDEO_FRAME_PLANE_DATA (gf, p);
+    vf->stride[p] = GST_VIDEO_FRAME_PLANE_STRIDE (gf, p);
+  }
+  if (gf->buffer && GST_BUFFER_FLAG_IS_SET (gf->buffer, GST_VIDEO_BUFFER_FLAG_TFF))
+    vf->flags |= VFHIP_FRAME_FLAG_TFF;
+}
+
+G_END_DECLS
+#endif

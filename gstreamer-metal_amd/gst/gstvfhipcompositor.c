@@ -1,0 +1,542 @@
+/* gst/gstvfhipcompositor.c — `vfhipcompositor`: N-input alpha / z-order compositor on an MI355X.
+ *
+ * Drop-in for the reference's vfmetalcompositor (compositor/gstvfmetalcompositor.{h,m}, gstvfmetalcompositorpad.m):
+ * GstVideoAggregator + GstChildProxy, rank PRIMARY + 2 (:177-178), request pads sink_%u { BGRA, RGBA, NV12, I420 }
+ * and the same src template (:65-78), element properties background {checker, black, white, transparent} and
+ * zero-size-is-unscaled (:1035-1051), pad properties xpos, ypos, width, height, alpha, operator {source, over, add},
+ * sizing-policy {none, keep-aspect-ratio} (gstvfmetalcompositorpad.m:282-315; zorder is GstVideoAggregatorPad's own).
+ * Inputs keep their own sizes (update_caps does not intersect pad sizes, :394-458); the output size is the bounding
+ * box of the positioned pads, BGRA preferred, highest input frame rate (:460-540).
+ *
+ * GstVideoAggregator moved into gst-plugins-base in 1.16; this container only has 1.14 headers, so this file is
+ * compiled to a stub here (the element is not registered) and the real code below is NOT compile-checked in this
+ * build environment — DESIGN.md lists it as such.  Not carried over from the reference: navigation-event forwarding
+ * and the obscured-pad culling optimisation (output is identical without it). */
+#ifdef HAVE_CONFIG_H
+#include "config.h"
+#endif
+#include "gstvfhip.h"
+
+#define GST_CAT_DEFAULT gst_vfhip_debug
+
+#if GST_CHECK_VERSION (1, 16, 0)
+#include <gst/video/gstvideoaggregator.h>
+
+#define VFHIP_COMP_FORMATS "{ BGRA, RGBA, NV12, I420 }"
+enum { SIZING_NONE = 0, SIZING_KEEP_ASPECT = 1 };
+
+/* ---- pad ------------------------------------------------------------------------------------------------ */
+typedef struct
+{
+  GstVideoAggregatorPad parent;
+  gint xpos, ypos, width, height;
+  gdouble alpha;
+  gint op, sizing_policy;
+} GstVfHipCompositorPad;
+typedef struct
+{
+  GstVideoAggregatorPadClass parent_class;
+} GstVfHipCompositorPadClass;
+
+enum { PAD_PROP_0, PAD_PROP_XPOS, PAD_PROP_YPOS, PAD_PROP_WIDTH, PAD_PROP_HEIGHT, PAD_PROP_ALPHA, PAD_PROP_OPERATOR, PAD_PROP_SIZING_POLICY };
+
+static GType
+comp_operator_type (void)
+{
+  static gsize t = 0;
+  static const GEnumValue v[] = {
+    {VFHIP_BLEND_SOURCE, "Source", "source"}, {VFHIP_BLEND_OVER, "Over", "over"}, {VFHIP_BLEND_ADD, "Add", "add"}, {0, NULL, NULL}
+  };
+  if (g_once_init_enter (&t))
+    g_once_init_leave (&t, g_enum_register_static ("GstVfHipCompositorOperator", v));
+  return (GType) t;
+}
+
+static GType
+comp_sizing_type (void)
+{
+  static gsize t = 0;
+  static const GEnumValue v[] = {
+    {SIZING_NONE, "None: image is scaled to fill configured destination rectangle without padding or keeping the aspect ratio", "none"},
+    {SIZING_KEEP_ASPECT, "Keep Aspect Ratio: image is scaled to fit destination rectangle with preserved aspect ratio", "keep-aspect-ratio"},
+    {0, NULL, NULL}
+  };
+  if (g_once_init_enter (&t))
+    g_once_init_leave (&t, g_enum_register_static ("GstVfHipCompositorSizingPolicy", v));
+  return (GType) t;
+}
+
+static GType
+comp_background_type (void)
+{
+  static gsize t = 0;
+  static const GEnumValue v[] = {
+    {VFHIP_BG_CHECKER, "Checker pattern", "checker"}, {VFHIP_BG_BLACK, "Black", "black"}, {VFHIP_BG_WHITE, "White", "white"},
+    {VFHIP_BG_TRANSPARENT, "Transparent Background to enable further compositing", "transparent"}, {0, NULL, NULL}
+  };
+  if (g_once_init_enter (&t))
+    g_once_init_leave (&t, g_enum_register_static ("GstVfHipCompositorBackground", v));
+  return (GType) t;
+}
+
+G_DEFINE_TYPE (GstVfHipCompositorPad, gst_vfhip_compositor_pad, GST_TYPE_VIDEO_AGGREGATOR_PAD);
+#define CPAD(o) ((GstVfHipCompositorPad *) (o))
+
+static void
+cpad_set_property (GObject * object, guint id, const GValue * value, GParamSpec * pspec)
+{
+  GstVfHipCompositorPad *pad = CPAD (object);
+  GST_OBJECT_LOCK (pad);
+  switch (id) {
+    case PAD_PROP_XPOS: pad->xpos = g_value_get_int (value); break;
+    case PAD_PROP_YPOS: pad->ypos = g_value_get_int (value); break;
+    case PAD_PROP_WIDTH: pad->width = g_value_get_int (value); break;
+    case PAD_PROP_HEIGHT: pad->height = g_value_get_int (value); break;
+    case PAD_PROP_ALPHA: pad->alpha = g_value_get_double (value); break;
+    case PAD_PROP_OPERATOR: pad->op = g_value_get_enum (value); break;
+    case PAD_PROP_SIZING_POLICY: pad->sizing_policy = g_value_get_enum (value); break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
+  }
+  GST_OBJECT_UNLOCK (pad);
+  if (id == PAD_PROP_WIDTH || id == PAD_PROP_HEIGHT || id == PAD_PROP_XPOS || id == PAD_PROP_YPOS || id == PAD_PROP_SIZING_POLICY) {
+    GstObject *agg = gst_object_get_parent (GST_OBJECT (pad));
+    if (agg) {
+      gst_pad_mark_reconfigure (GST_AGGREGATOR (agg)->srcpad);      /* the output bounding box may have changed */
+      gst_object_unref (agg);
+    }
+  }
+}
+
+static void
+cpad_get_property (GObject * object, guint id, GValue * value, GParamSpec * pspec)
+{
+  GstVfHipCompositorPad *pad = CPAD (object);
+  GST_OBJECT_LOCK (pad);
+  switch (id) {
+    case PAD_PROP_XPOS: g_value_set_int (value, pad->xpos); break;
+    case PAD_PROP_YPOS: g_value_set_int (value, pad->ypos); break;
+    case PAD_PROP_WIDTH: g_value_set_int (value, pad->width); break;
+    case PAD_PROP_HEIGHT: g_value_set_int (value, pad->height); break;
+    case PAD_PROP_ALPHA: g_value_set_double (value, pad->alpha); break;
+    case PAD_PROP_OPERATOR: g_value_set_enum (value, pad->op); break;
+    case PAD_PROP_SIZING_POLICY: g_value_set_enum (value, pad->sizing_policy); break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
+  }
+  GST_OBJECT_UNLOCK (pad);
+}
+
+static void
+gst_vfhip_compositor_pad_class_init (GstVfHipCompositorPadClass * klass)
+{
+  GObjectClass *oc = G_OBJECT_CLASS (klass);
+  const GParamFlags f = (GParamFlags) (G_PARAM_READWRITE | GST_PARAM_CONTROLLABLE | G_PARAM_STATIC_STRINGS);
+  oc->set_property = cpad_set_property;
+  oc->get_property = cpad_get_property;
+  g_object_class_install_property (oc, PAD_PROP_XPOS, g_param_spec_int ("xpos", "X Position", "X Position of the picture", G_MININT, G_MAXINT, 0, f));
+  g_object_class_install_property (oc, PAD_PROP_YPOS, g_param_spec_int ("ypos", "Y Position", "Y Position of the picture", G_MININT, G_MAXINT, 0, f));
+  g_object_class_install_property (oc, PAD_PROP_WIDTH, g_param_spec_int ("width", "Width", "Width of the picture", G_MININT, G_MAXINT, -1, f));
+  g_object_class_install_property (oc, PAD_PROP_HEIGHT, g_param_spec_int ("height", "Height", "Height of the picture", G_MININT, G_MAXINT, -1, f));
+  g_object_class_install_property (oc, PAD_PROP_ALPHA, g_param_spec_double ("alpha", "Alpha", "Alpha of the picture", 0.0, 1.0, 1.0, f));
+  g_object_class_install_property (oc, PAD_PROP_OPERATOR, g_param_spec_enum ("operator", "Operator",
+          "Blending operator to use for blending this pad over the previous ones", comp_operator_type (), VFHIP_BLEND_OVER, f));
+  g_object_class_install_property (oc, PAD_PROP_SIZING_POLICY, g_param_spec_enum ("sizing-policy", "Sizing policy",
+          "Sizing policy to use for image scaling", comp_sizing_type (), SIZING_NONE, f));
+}
+
+static void
+gst_vfhip_compositor_pad_init (GstVfHipCompositorPad * pad)
+{
+  pad->xpos = pad->ypos = 0;
+  pad->width = pad->height = -1;
+  pad->alpha = 1.0;
+  pad->op = VFHIP_BLEND_OVER;
+  pad->sizing_policy = SIZING_NONE;
+}
+
+/* ---- element --------------------------------------------------------------------------------------------- */
+typedef struct
+{
+  GstVideoAggregator parent;
+  VfHipCompositor *renderer;
+  gint device_id, background;
+  gboolean zero_size_is_unscaled;
+} GstVfHipCompositor;
+typedef struct
+{
+  GstVideoAggregatorClass parent_class;
+} GstVfHipCompositorClass;
+
+enum { PROP_0, PROP_BACKGROUND, PROP_ZERO_SIZE_IS_UNSCALED, PROP_DEVICE_ID };
+
+static GstStaticPadTemplate comp_src_template = GST_STATIC_PAD_TEMPLATE ("src", GST_PAD_SRC, GST_PAD_ALWAYS,
+    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE (VFHIP_COMP_FORMATS)));
+static GstStaticPadTemplate comp_sink_template = GST_STATIC_PAD_TEMPLATE ("sink_%u", GST_PAD_SINK, GST_PAD_REQUEST,
+    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE (VFHIP_COMP_FORMATS)));
+
+static void comp_child_proxy_init (gpointer g_iface, gpointer iface_data);
+G_DEFINE_TYPE_WITH_CODE (GstVfHipCompositor, gst_vfhip_compositor, GST_TYPE_VIDEO_AGGREGATOR,
+    G_IMPLEMENT_INTERFACE (GST_TYPE_CHILD_PROXY, comp_child_proxy_init));
+#define COMP(o) ((GstVfHipCompositor *) (o))
+
+/* where a pad lands in the output: its configured (or native) size, corrected for the pixel aspect ratios, and for
+ * keep-aspect-ratio the centred sub-rectangle that preserves the input's display aspect ratio */
+static void
+comp_pad_rect (GstVfHipCompositor * self, GstVfHipCompositorPad * cpad, gint out_par_n, gint out_par_d,
+    gint * w, gint * h, gint * xoff, gint * yoff)
+{
+  GstVideoAggregatorPad *vpad = GST_VIDEO_AGGREGATOR_PAD (cpad);
+  gint pw, ph;
+  guint dn, dd;
+  *w = *h = *xoff = *yoff = 0;
+  if (!vpad->info.finfo || GST_VIDEO_INFO_FORMAT (&vpad->info) == GST_VIDEO_FORMAT_UNKNOWN)
+    return;
+  if (self->zero_size_is_unscaled) {
+    pw = cpad->width <= 0 ? GST_VIDEO_INFO_WIDTH (&vpad->info) : cpad->width;
+    ph = cpad->height <= 0 ? GST_VIDEO_INFO_HEIGHT (&vpad->info) : cpad->height;
+  } else {
+    pw = cpad->width < 0 ? GST_VIDEO_INFO_WIDTH (&vpad->info) : cpad->width;
+    ph = cpad->height < 0 ? GST_VIDEO_INFO_HEIGHT (&vpad->info) : cpad->height;
+  }
+  if (pw == 0 || ph == 0)
+    return;
+  if (!gst_video_calculate_display_ratio (&dn, &dd, pw, ph, GST_VIDEO_INFO_PAR_N (&vpad->info), GST_VIDEO_INFO_PAR_D (&vpad->info), out_par_n, out_par_d))
+    return;
+  if (cpad->sizing_policy == SIZING_NONE) {
+    if (ph % dn == 0) pw = gst_util_uint64_scale_int (ph, dn, dd);
+    else if (pw % dd == 0) ph = gst_util_uint64_scale_int (pw, dd, dn);
+    else pw = gst_util_uint64_scale_int (ph, dn, dd);
+  } else {
+    gint fn, fd, tn, td, num, den;
+    if (!gst_util_fraction_multiply (GST_VIDEO_INFO_WIDTH (&vpad->info), GST_VIDEO_INFO_HEIGHT (&vpad->info),
+            GST_VIDEO_INFO_PAR_N (&vpad->info), GST_VIDEO_INFO_PAR_D (&vpad->info), &fn, &fd)) fn = fd = -1;
+    if (!gst_util_fraction_multiply (pw, ph, out_par_n, out_par_d, &tn, &td)) tn = td = -1;
+    if (fn != tn || fd != td) {
+      GstVideoRectangle src, dst, res;
+      if (fn == -1 || !gst_util_fraction_multiply (fn, fd, out_par_d, out_par_n, &num, &den))
+        return;
+      src.x = src.y = 0; src.w = pw; src.h = gst_util_uint64_scale_int (pw, den, num);
+      if (src.h == 0)
+        return;
+      dst.x = dst.y = 0; dst.w = pw; dst.h = ph;
+      gst_video_sink_center_rect (src, dst, &res, TRUE);
+      *xoff = res.x; *yoff = res.y; pw = res.w; ph = res.h;
+    }
+  }
+  *w = pw; *h = ph;
+}
+
+static GstCaps *
+comp_update_caps (GstVideoAggregator * vagg, GstCaps * caps)
+{
+  gint bw = -1, bh = -1;
+  GList *l;
+  GstCaps *ret, *tmpl, *tmp;
+  GST_OBJECT_LOCK (vagg);
+  for (l = GST_ELEMENT (vagg)->sinkpads; l; l = l->next) {
+    GstVideoAggregatorPad *vpad = l->data;
+    GstVfHipCompositorPad *cpad = CPAD (vpad);
+    gint w, h;
+    if (!vpad->info.finfo)
+      continue;
+    w = (cpad->width > 0 ? cpad->width : GST_VIDEO_INFO_WIDTH (&vpad->info)) + MAX (cpad->xpos, 0);
+    h = (cpad->height > 0 ? cpad->height : GST_VIDEO_INFO_HEIGHT (&vpad->info)) + MAX (cpad->ypos, 0);
+    bw = MAX (bw, w); bh = MAX (bh, h);
+  }
+  GST_OBJECT_UNLOCK (vagg);
+  if (bw <= 0 || bh <= 0)
+    return gst_caps_ref (caps);
+  ret = gst_caps_new_simple ("video/x-raw", "width", G_TYPE_INT, bw, "height", G_TYPE_INT, bh, NULL);
+  tmpl = gst_static_pad_template_get_caps (&comp_src_template);
+  tmp = gst_caps_intersect (ret, tmpl);
+  gst_caps_unref (ret); gst_caps_unref (tmpl);
+  ret = tmp;
+  if (caps) {
+    tmp = gst_caps_intersect (ret, caps);
+    gst_caps_unref (ret);
+    ret = tmp;
+  }
+  return ret;
+}
+
+static GstCaps *
+comp_fixate_src_caps (GstAggregator * agg, GstCaps * caps)
+{
+  GstVideoAggregator *vagg = GST_VIDEO_AGGREGATOR (agg);
+  GstCaps *ret = gst_caps_make_writable (caps);
+  GstStructure *s = gst_caps_get_structure (ret, 0);
+  gint bw = -1, bh = -1, fn = -1, fd = -1, par_n = 1, par_d = 1;
+  gdouble best = 0.0;
+  GList *l;
+  if (gst_structure_has_field (s, "pixel-aspect-ratio")) {
+    gst_structure_fixate_field_nearest_fraction (s, "pixel-aspect-ratio", 1, 1);
+    gst_structure_get_fraction (s, "pixel-aspect-ratio", &par_n, &par_d);
+  }
+  GST_OBJECT_LOCK (vagg);
+  for (l = GST_ELEMENT (vagg)->sinkpads; l; l = l->next) {
+    GstVideoAggregatorPad *vpad = l->data;
+    GstVfHipCompositorPad *cpad = CPAD (vpad);
+    gint w, h, xo, yo;
+    gdouble fps = 0.0;
+    comp_pad_rect (COMP (vagg), cpad, par_n, par_d, &w, &h, &xo, &yo);
+    if (w == 0 || h == 0)
+      continue;
+    bw = MAX (bw, w + MAX (cpad->xpos + 2 * xo, 0));
+    bh = MAX (bh, h + MAX (cpad->ypos + 2 * yo, 0));
+    if (GST_VIDEO_INFO_FPS_D (&vpad->info) != 0)
+      gst_util_fraction_to_double (GST_VIDEO_INFO_FPS_N (&vpad->info), GST_VIDEO_INFO_FPS_D (&vpad->info), &fps);
+    if (fps > best) { best = fps; fn = GST_VIDEO_INFO_FPS_N (&vpad->info); fd = GST_VIDEO_INFO_FPS_D (&vpad->info); }
+  }
+  GST_OBJECT_UNLOCK (vagg);
+  if (fn <= 0 || fd <= 0) { fn = 25; fd = 1; }
+  gst_structure_fixate_field_string (s, "format", "BGRA");
+  gst_structure_fixate_field_nearest_int (s, "width", bw);
+  gst_structure_fixate_field_nearest_int (s, "height", bh);
+  gst_structure_fixate_field_nearest_fraction (s, "framerate", fn, fd);
+  return gst_caps_fixate (ret);
+}
+
+static gboolean
+comp_negotiated_src_caps (GstAggregator * agg, GstCaps * caps)
+{
+  GstVfHipCompositor *self = COMP (agg);
+  GstVideoInfo gi;
+  VfHipVideoInfo out;
+  if (!gst_video_info_from_caps (&gi, caps))
+    return FALSE;
+  if (!self->renderer && !(self->renderer = vfhip_compositor_new (self->device_id))) {
+    GST_ERROR_OBJECT (self, "no HIP renderer: %s", vfhip_last_error_string ());
+    return FALSE;
+  }
+  gst_vfhip_info (&gi, &out);
+  if (vfhip_compositor_configure (self->renderer, &out) != VFHIP_OK) {
+    GST_ERROR_OBJECT (self, "configure failed: %s", vfhip_last_error_string ());
+    return FALSE;
+  }
+  return GST_AGGREGATOR_CLASS (gst_vfhip_compositor_parent_class)->negotiated_src_caps (agg, caps);
+}
+
+static GstFlowReturn
+comp_aggregate_frames (GstVideoAggregator * vagg, GstBuffer * outbuf)
+{
+  GstVfHipCompositor *self = COMP (vagg);
+  GstVideoFrame out;
+  VfHipFrame vout;
+  VfHipPadInput *pads;
+  guint n = 0, i = 0;
+  gboolean covered = FALSE;
+  gint bg, rc;
+  GList *l;
+  if (!self->renderer)
+    return GST_FLOW_ERROR;
+  if (!gst_video_frame_map (&out, &vagg->info, outbuf, GST_MAP_WRITE))
+    return GST_FLOW_ERROR;
+  GST_OBJECT_LOCK (vagg);
+  for (l = GST_ELEMENT (vagg)->sinkpads; l; l = l->next)
+    if (gst_video_aggregator_pad_get_prepared_frame (GST_VIDEO_AGGREGATOR_PAD (l->data)))
+      n++;
+  pads = g_new0 (VfHipPadInput, MAX (n, 1));
+  for (l = GST_ELEMENT (vagg)->sinkpads; l; l = l->next) {      /* sinkpads is kept in zorder by the base class */
+    GstVideoAggregatorPad *vpad = l->data;
+    GstVfHipCompositorPad *cpad = CPAD (vpad);
+    GstVideoFrame *f = gst_video_aggregator_pad_get_prepared_frame (vpad);
+    gint w, h, xo, yo;
+    if (!f)
+      continue;
+    comp_pad_rect (self, cpad, GST_VIDEO_INFO_PAR_N (&vagg->info), GST_VIDEO_INFO_PAR_D (&vagg->info), &w, &h, &xo, &yo);
+    gst_vfhip_frame (f, &pads[i].frame);
+    pads[i].xpos = cpad->xpos + xo; pads[i].ypos = cpad->ypos + yo; pads[i].width = w; pads[i].height = h;
+    pads[i].alpha = cpad->alpha; pads[i].blend_mode = cpad->op;
+    /* an opaque pad over the whole frame makes the background invisible: pass TRANSPARENT like the reference (:649-651) */
+    if (cpad->alpha == 1.0 && !GST_VIDEO_INFO_HAS_ALPHA (&vpad->info) && pads[i].xpos <= 0 && pads[i].ypos <= 0 &&
+        pads[i].xpos + w >= GST_VIDEO_INFO_WIDTH (&vagg->info) && pads[i].ypos + h >= GST_VIDEO_INFO_HEIGHT (&vagg->info))
+      covered = TRUE;
+    i++;
+  }
+  GST_OBJECT_UNLOCK (vagg);
+  bg = (covered && n > 0) ? VFHIP_BG_TRANSPARENT : self->background;
+  gst_vfhip_frame (&out, &vout);
+  rc = vfhip_compositor_composite (self->renderer, pads, (int) i, bg, &vout);
+  gst_video_frame_unmap (&out);
+  g_free (pads);
+  if (rc != VFHIP_OK) {
+    GST_ERROR_OBJECT (self, "HIP compositing failed: %s", vfhip_last_error_string ());
+    return GST_FLOW_ERROR;
+  }
+  return GST_FLOW_OK;
+}
+
+static gboolean
+comp_stop (GstAggregator * agg)
+{
+  GstVfHipCompositor *self = COMP (agg);
+  if (self->renderer)
+    vfhip_compositor_cleanup (self->renderer);
+  return GST_AGGREGATOR_CLASS (gst_vfhip_compositor_parent_class)->stop (agg);
+}
+
+/* every sink pad may carry its own size: answer caps queries with the template, not the negotiated output */
+static gboolean
+comp_sink_query (GstAggregator * agg, GstAggregatorPad * pad, GstQuery * query)
+{
+  if (GST_QUERY_TYPE (query) == GST_QUERY_CAPS) {
+    GstCaps *filter, *tmpl = gst_pad_get_pad_template_caps (GST_PAD (pad)), *res;
+    gst_query_parse_caps (query, &filter);
+    res = filter ? gst_caps_intersect_full (filter, tmpl, GST_CAPS_INTERSECT_FIRST) : gst_caps_ref (tmpl);
+    gst_query_set_caps_result (query, res);
+    gst_caps_unref (res); gst_caps_unref (tmpl);
+    return TRUE;
+  }
+  if (GST_QUERY_TYPE (query) == GST_QUERY_ACCEPT_CAPS) {
+    GstCaps *caps, *tmpl = gst_pad_get_pad_template_caps (GST_PAD (pad));
+    gst_query_parse_accept_caps (query, &caps);
+    gst_query_set_accept_caps_result (query, gst_caps_is_subset (caps, tmpl));
+    gst_caps_unref (tmpl);
+    return TRUE;
+  }
+  return GST_AGGREGATOR_CLASS (gst_vfhip_compositor_parent_class)->sink_query (agg, pad, query);
+}
+
+static void
+comp_set_property (GObject * object, guint id, const GValue * value, GParamSpec * pspec)
+{
+  GstVfHipCompositor *self = COMP (object);
+  switch (id) {
+    case PROP_BACKGROUND: self->background = g_value_get_enum (value); break;
+    case PROP_ZERO_SIZE_IS_UNSCALED: self->zero_size_is_unscaled = g_value_get_boolean (value); break;
+    case PROP_DEVICE_ID: self->device_id = g_value_get_int (value); break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
+  }
+}
+
+static void
+comp_get_property (GObject * object, guint id, GValue * value, GParamSpec * pspec)
+{
+  GstVfHipCompositor *self = COMP (object);
+  switch (id) {
+    case PROP_BACKGROUND: g_value_set_enum (value, self->background); break;
+    case PROP_ZERO_SIZE_IS_UNSCALED: g_value_set_boolean (value, self->zero_size_is_unscaled); break;
+    case PROP_DEVICE_ID: g_value_set_int (value, self->device_id); break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
+  }
+}
+
+static void
+comp_finalize (GObject * object)
+{
+  GstVfHipCompositor *self = COMP (object);
+  if (self->renderer)
+    vfhip_compositor_free (self->renderer);
+  self->renderer = NULL;
+  G_OBJECT_CLASS (gst_vfhip_compositor_parent_class)->finalize (object);
+}
+
+/* GstChildProxy: lets gst-launch address pads as sink_0::xpos=... */
+static GObject *
+comp_child_by_index (GstChildProxy * proxy, guint index)
+{
+  GObject *obj;
+  GST_OBJECT_LOCK (proxy);
+  obj = g_list_nth_data (GST_ELEMENT_CAST (proxy)->sinkpads, index);
+  if (obj)
+    gst_object_ref (obj);
+  GST_OBJECT_UNLOCK (proxy);
+  return obj;
+}
+
+static guint
+comp_children_count (GstChildProxy * proxy)
+{
+  guint n;
+  GST_OBJECT_LOCK (proxy);
+  n = GST_ELEMENT_CAST (proxy)->numsinkpads;
+  GST_OBJECT_UNLOCK (proxy);
+  return n;
+}
+
+static void
+comp_child_proxy_init (gpointer g_iface, gpointer iface_data)
+{
+  GstChildProxyInterface *iface = g_iface;
+  (void) iface_data;
+  iface->get_child_by_index = comp_child_by_index;
+  iface->get_children_count = comp_children_count;
+}
+
+static GstPad *
+comp_request_new_pad (GstElement * element, GstPadTemplate * templ, const gchar * name, const GstCaps * caps)
+{
+  GstPad *pad = GST_ELEMENT_CLASS (gst_vfhip_compositor_parent_class)->request_new_pad (element, templ, name, caps);
+  if (pad)
+    gst_child_proxy_child_added (GST_CHILD_PROXY (element), G_OBJECT (pad), GST_OBJECT_NAME (pad));
+  return pad;
+}
+
+static void
+comp_release_pad (GstElement * element, GstPad * pad)
+{
+  gst_child_proxy_child_removed (GST_CHILD_PROXY (element), G_OBJECT (pad), GST_OBJECT_NAME (pad));
+  GST_ELEMENT_CLASS (gst_vfhip_compositor_parent_class)->release_pad (element, pad);
+}
+
+static void
+gst_vfhip_compositor_class_init (GstVfHipCompositorClass * klass)
+{
+  GObjectClass *oc = G_OBJECT_CLASS (klass);
+  GstElementClass *ec = GST_ELEMENT_CLASS (klass);
+  GstAggregatorClass *ac = GST_AGGREGATOR_CLASS (klass);
+  GstVideoAggregatorClass *vc = GST_VIDEO_AGGREGATOR_CLASS (klass);
+  oc->set_property = comp_set_property;
+  oc->get_property = comp_get_property;
+  oc->finalize = comp_finalize;
+  ec->request_new_pad = GST_DEBUG_FUNCPTR (comp_request_new_pad);
+  ec->release_pad = GST_DEBUG_FUNCPTR (comp_release_pad);
+  ac->sink_query = GST_DEBUG_FUNCPTR (comp_sink_query);
+  ac->fixate_src_caps = GST_DEBUG_FUNCPTR (comp_fixate_src_caps);
+  ac->negotiated_src_caps = GST_DEBUG_FUNCPTR (comp_negotiated_src_caps);
+  ac->stop = GST_DEBUG_FUNCPTR (comp_stop);
+  vc->update_caps = GST_DEBUG_FUNCPTR (comp_update_caps);
+  vc->aggregate_frames = GST_DEBUG_FUNCPTR (comp_aggregate_frames);
+
+  g_object_class_install_property (oc, PROP_BACKGROUND, g_param_spec_enum ("background", "Background", "Background type",
+          comp_background_type (), VFHIP_BG_CHECKER, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_ZERO_SIZE_IS_UNSCALED, g_param_spec_boolean ("zero-size-is-unscaled", "Zero size is unscaled",
+          "If TRUE, then input video is unscaled in that dimension if width or height is 0 (for backwards compatibility)", TRUE,
+          G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_DEVICE_ID, g_param_spec_int ("device-id", "Device ID",
+          "GPU ordinal to run on (-1: $VFHIP_DEVICE, else 0)", -1, 63, GST_VFHIP_DEFAULT_DEVICE_ID, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+
+  gst_element_class_add_static_pad_template_with_gtype (ec, &comp_src_template, GST_TYPE_AGGREGATOR_PAD);
+  gst_element_class_add_static_pad_template_with_gtype (ec, &comp_sink_template, gst_vfhip_compositor_pad_get_type ());
+  gst_element_class_set_static_metadata (ec, "HIP Compositor", "Filter/Editor/Video/Compositor",
+      "MI355X-accelerated compositing of multiple video streams", "vfhip");
+}
+
+static void
+gst_vfhip_compositor_init (GstVfHipCompositor * self)
+{
+  self->background = VFHIP_BG_CHECKER;
+  self->zero_size_is_unscaled = TRUE;
+  self->device_id = GST_VFHIP_DEFAULT_DEVICE_ID;
+}
+
+gboolean
+gst_vfhip_compositor_register (GstPlugin * plugin)
+{
+  gboolean ok = gst_element_register (plugin, "vfhipcompositor", GST_RANK_PRIMARY + 2, gst_vfhip_compositor_get_type ());
+#ifdef VFHIP_REGISTER_VFMETAL_NAMES
+  ok &= gst_element_register (plugin, "vfmetalcompositor", GST_RANK_PRIMARY + 2, gst_vfhip_compositor_get_type ());
+#endif
+  return ok;
+}
+
+#else /* GStreamer < 1.16: no GstVideoAggregator in gst-plugins-base */
+
+gboolean
+gst_vfhip_compositor_register (GstPlugin * plugin)
+{
+  (void) plugin;
+  GST_INFO ("vfhipcompositor needs GStreamer >= 1.16 (GstVideoAggregator); not registered in this build");
+  return TRUE;
+}
+
+#endif

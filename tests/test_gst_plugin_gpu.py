@@ -1,0 +1,103 @@
+"""End-to-end drop-in tests on the GPU box: real gst-launch-1.0 pipelines through the vfhip elements.
+
+  * the reference's smoke matrix (tests/test-convertscale.sh, test-videofilter.sh, test-deinterlace.sh,
+    test-multi-element.sh) re-targeted to the vfhip* names: exit status only, like the reference;
+  * what the reference never had — pixel parity: the same videotestsrc frames through GStreamer's CPU
+    `videoconvert ! videoscale` and through `vfhipconvertscale`, compared byte for byte (BASELINE config[0]).
+Skipped when the box has no /opt/conda GStreamer."""
+import os
+
+import numpy as np
+import pytest
+
+import gst_env
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not gst_env.available(), reason="GStreamer 1.14 (/opt/conda) or libgstvfhip.so not present")]
+
+SRC = "videotestsrc num-buffers=3"
+
+
+def ok(pipeline):
+    r = gst_env.launch(pipeline)
+    assert r.returncode == 0, f"{pipeline}\n{r.stdout}\n{r.stderr}"
+
+
+def caps(fmt, w, h, extra=""):
+    return f"video/x-raw,format={fmt},width={w},height={h}{extra}"
+
+
+@pytest.mark.parametrize("fmt", ["BGRA", "RGBA", "NV12", "I420"])
+def test_convertscale_passthrough(fmt):
+    ok(f"{SRC} ! {caps(fmt, 320, 240)} ! vfhipconvertscale ! {caps(fmt, 320, 240)} ! fakesink")
+
+
+@pytest.mark.parametrize("ifmt", ["BGRA", "RGBA", "NV12", "I420", "UYVY", "YUY2"])
+@pytest.mark.parametrize("ofmt", ["BGRA", "NV12", "I420", "UYVY"])
+def test_convertscale_conversions(ifmt, ofmt):
+    ok(f"{SRC} ! {caps(ifmt, 320, 240)} ! vfhipconvertscale ! {caps(ofmt, 320, 240)} ! fakesink")
+
+
+@pytest.mark.parametrize("p", [
+    f"{caps('BGRA', 320, 240)} ! vfhipconvertscale ! {caps('BGRA', 640, 480)}",
+    f"{caps('BGRA', 640, 480)} ! vfhipconvertscale method=nearest ! {caps('BGRA', 160, 120)}",
+    f"{caps('NV12', 1920, 1080)} ! vfhipconvertscale ! {caps('BGRA', 640, 480)}",
+    f"{caps('I420', 1280, 720)} ! vfhipconvertscale numerics=metal ! {caps('NV12', 640, 360)}",
+    f"{caps('BGRA', 640, 360)} ! vfhipconvertscale add-borders=true border-color=0xFF102030 ! {caps('BGRA', 320, 320)}",
+    f"{caps('BGRA', 17, 13)} ! vfhipconvertscale ! {caps('BGRA', 33, 7)}",
+    f"{caps('NV12', 64, 36)} ! vfhipconvertscale ! video/x-raw,format=BGRA,width=32",        # height from the DAR
+])
+def test_convertscale_scaling(p):
+    ok(f"{SRC} ! {p} ! fakesink")
+
+
+@pytest.mark.parametrize("props", ["brightness=0.3", "contrast=1.5", "saturation=0.2", "hue=0.5", "gamma=2.2", "sharpness=0.8", "sharpness=-0.8",
+                                   "sepia=1.0", "invert=true", "noise=0.5", "vignette=0.8",
+                                   "chroma-key-enabled=true chroma-key-color=0xFF00FF00 chroma-key-tolerance=0.3 chroma-key-smoothness=0.1",
+                                   "brightness=0.1 contrast=1.2 saturation=0.8 hue=0.3 gamma=1.5 sharpness=0.5 sepia=0.2 noise=0.1 vignette=0.3", ""])
+def test_videofilter_properties(props):
+    ok(f"{SRC} ! {caps('BGRA', 320, 240)} ! vfhipvideofilter {props} ! fakesink")
+
+
+@pytest.mark.parametrize("fmt,size", [("NV12", (320, 240)), ("I420", (320, 240)), ("RGBA", (321, 241)), ("BGRA", (1920, 1080))])
+def test_videofilter_formats(fmt, size):
+    ok(f"{SRC} ! {caps(fmt, *size)} ! vfhipvideofilter brightness=0.2 sharpness=0.4 ! fakesink")
+
+
+def test_videofilter_lut_file(tmp_path):
+    n = 4
+    rows = [f"LUT_3D_SIZE {n}"] + ["%f %f %f" % (r / (n - 1), g / (n - 1), b / (n - 1)) for b in range(n) for g in range(n) for r in range(n)]
+    p = tmp_path / "id.cube"
+    p.write_text("\n".join(rows) + "\n")
+    ok(f"{SRC} ! {caps('BGRA', 320, 240)} ! vfhipvideofilter lut-file={p} ! fakesink")
+    ok(f"{SRC} ! {caps('BGRA', 320, 240)} ! vfhipvideofilter lut-file={tmp_path / 'missing.cube'} saturation=0.5 ! fakesink")   # warning, not an error
+
+
+@pytest.mark.parametrize("method", ["bob", "weave", "linear", "greedyh"])
+@pytest.mark.parametrize("fmt", ["BGRA", "NV12", "I420"])
+def test_deinterlace_methods(method, fmt):
+    ok(f"videotestsrc num-buffers=4 pattern=ball ! {caps(fmt, 320, 240)} ! vfhipdeinterlace method={method} field-layout=top-field-first ! fakesink")
+
+
+def test_deinterlace_field_layout_and_1080p():
+    ok(f"{SRC} ! {caps('NV12', 1920, 1080)} ! vfhipdeinterlace method=greedyh field-layout=bottom-field-first motion-threshold=0.05 ! fakesink")
+    ok(f"{SRC} ! {caps('BGRA', 321, 241)} ! vfhipdeinterlace method=weave ! fakesink")
+
+
+def test_multi_element_chains():
+    """several renderers (each with its own stream trio) in one process (reference tests/test-multi-element.sh:2-4)"""
+    ok(f"{SRC} ! {caps('NV12', 640, 480)} ! vfhipdeinterlace method=greedyh ! vfhipconvertscale ! {caps('BGRA', 320, 240)} ! vfhipvideofilter brightness=0.1 sepia=0.5 ! fakesink")
+    ok(f"{SRC} ! {caps('BGRA', 640, 480)} ! tee name=t t. ! queue ! vfhipconvertscale ! {caps('NV12', 320, 240)} ! fakesink "
+       f"t. ! queue ! vfhipvideofilter invert=true ! vfhipconvertscale ! {caps('I420', 160, 120)} ! fakesink")
+
+
+@pytest.mark.parametrize("iw,ih,ow,oh,fmt", [(1920, 1080, 640, 480, "NV12"), (3840, 2160, 1920, 1080, "NV12"), (1280, 720, 1920, 1080, "I420"), (720, 576, 360, 288, "NV12")])
+def test_pixel_parity_with_cpu_videoconvert_videoscale(tmp_path, iw, ih, ow, oh, fmt):
+    """BASELINE configs[0] and [1] as real pipelines: vfhipconvertscale is byte-identical to videoconvert ! videoscale"""
+    a, b = tmp_path / "cpu.raw", tmp_path / "hip.raw"
+    r = gst_env.launch(f"videotestsrc num-buffers=2 ! {caps(fmt, iw, ih)} ! tee name=t "
+                       f"t. ! queue ! videoconvert ! videoscale ! {caps('BGRA', ow, oh)} ! filesink location={a} "
+                       f"t. ! queue ! vfhipconvertscale ! {caps('BGRA', ow, oh)} ! filesink location={b}", timeout=300)
+    assert r.returncode == 0, r.stderr
+    x, y = np.fromfile(a, np.uint8), np.fromfile(b, np.uint8)
+    assert x.size == y.size == 2 * ow * oh * 4
+    assert np.array_equal(x, y), f"max diff {np.abs(x.astype(int) - y.astype(int)).max()}, {(x != y).sum()} bytes differ"

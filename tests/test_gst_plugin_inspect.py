@@ -1,0 +1,55 @@
+"""The GStreamer plugin (plain C element shells over libvfhip) keeps the reference's element API: same base classes,
+pad templates, property names / nicks / ranges / defaults.  Mirrors the `check_inspect` part of the
+reference's smoke scripts (tests/test-videofilter.sh:69-97, tests/test-convertscale.sh:27-39) with vfhip* names.
+gst-inspect instantiates the elements but creates no renderer, so this runs without a GPU."""
+import re
+
+import pytest
+
+import gst_env
+
+pytestmark = pytest.mark.skipif(not gst_env.available(), reason="GStreamer 1.14 (/opt/conda) or libgstvfhip.so not present")
+
+
+def props(text):
+    body = text.split("Element Properties:")[1]
+    return set(re.findall(r"^  ([a-z][a-z0-9-]*) *:", body, flags=re.M))
+
+
+def squeeze(text):
+    return re.sub(r"\s+", " ", text)
+
+
+def test_plugin_registers_elements():
+    r = gst_env.inspect("vfhip")
+    assert r.returncode == 0, r.stdout + r.stderr
+    for e in ("vfhipconvertscale", "vfhipvideofilter", "vfhipdeinterlace"):
+        assert e in r.stdout
+    # vfhipcompositor needs GstVideoAggregator (gst-plugins-base >= 1.16); this container has 1.14
+
+
+def test_convertscale_api():
+    t = gst_env.inspect("vfhipconvertscale").stdout
+    assert {"method", "add-borders", "border-color", "device-id", "numerics"} <= props(t)
+    assert "GstBaseTransform" in t and "bilinear" in t and "nearest" in t
+    assert t.count("(string)BGRA, (string)RGBA, (string)NV12, (string)I420, (string)UYVY, (string)YUY2") == 2
+    assert "Default: 4278190080" in t                       # border-color 0xFF000000
+
+
+def test_videofilter_api():
+    t = gst_env.inspect("vfhipvideofilter").stdout
+    want = {"brightness", "contrast", "saturation", "hue", "gamma", "sharpness", "sepia", "invert", "noise", "vignette",
+            "chroma-key-enabled", "chroma-key-color", "chroma-key-tolerance", "chroma-key-smoothness", "lut-file"}
+    assert want <= props(t) and len(want) == 15
+    assert "GstVideoFilter" in t
+    assert t.count("(string)BGRA, (string)RGBA, (string)NV12, (string)I420 }") == 2
+    assert "Range: 0.01 - 10 Default: 1 " in squeeze(t)      # gamma
+    assert "Default: 4278255360" in t                       # chroma-key-color 0xFF00FF00
+
+
+def test_deinterlace_api():
+    t = gst_env.inspect("vfhipdeinterlace").stdout
+    assert {"method", "field-layout", "motion-threshold"} <= props(t)
+    for nick in ("bob", "weave", "linear", "greedyh", "auto", "top-field-first", "bottom-field-first"):
+        assert nick in t
+    assert "Range: 0 - 1 Default: 0.1" in squeeze(t)
