@@ -34,7 +34,12 @@ def cpu_baseline(seconds_budget=20.0):
     import numpy as np
     import oracle_lib
     orc = oracle_lib.load()
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's share of the host: 16 cores (os.cpu_count() reports the whole machine)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    cores = orc.lib.gst114_set_threads(min(avail, 16))
     rng = np.random.default_rng(0)
     raw = rng.integers(0, 256, IN_W * IN_H * 3 // 2, dtype=np.uint8)
     orc.convertscale("NV12", IN_W, IN_H, raw, "bt2020", "mpeg2", "bilinear", "BGRA", OUT_W, OUT_H)   # warm-up
@@ -71,20 +76,16 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
+    import bench_dist as bd
     import vfhip                                   # fails loudly when libvfhip.so is missing
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world, rank, local_rank = bd.world()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    bd.init("nccl", torch.device("cuda", local_rank))          # barrier + max-over-ranks only; no data-path collective
 
     F = args.frames
     _, in_size = vfhip.plane_layout("NV12", IN_W, IN_H)
@@ -105,8 +106,7 @@ def main():
                           in_pitch=in_pitch, out_pitch=out_pitch)
 
     def fence():
-        if world > 1:
-            dist.barrier()
+        bd.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -123,13 +123,10 @@ def main():
     fence()
     kernel_ms = ev0.elapsed_time(ev1) / args.steps          # average launch duration (back-to-back launches)
 
-    t = torch.tensor([t_local], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    t_max = float(t.item())
+    t_max = bd.max_over_ranks(t_local, device="cuda")
 
     if rank == 0:
-        fps = world * F * args.steps / t_max
+        fps = bd.whole_job_rate(F, args.steps, world, t_max)
         achieved = ALG_BYTES_PER_FRAME * F / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "frames/sec + achieved HBM GB/s, NV12->BGRA 2160p->1080p",
@@ -148,8 +145,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     cs.close()
-    if world > 1:
-        dist.destroy_process_group()
+    bd.finish()
 
 
 if __name__ == "__main__":

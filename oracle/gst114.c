@@ -22,6 +22,20 @@
 #include "gst114.h"
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* threads used by the OpenMP loops (bench.py cpu_baseline leg) */
+int gst114_set_threads (int n)
+{
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads (n);
+  return omp_get_max_threads ();
+#else
+  (void) n; return 1;
+#endif
+}
 
 static const int COEF[3][5] = {
   { 298, 409, 516, -100, -208 },   /* bt601  */

@@ -9,6 +9,7 @@ enum { GST114_BT601 = 0, GST114_BT709 = 1, GST114_BT2020 = 2 };
 enum { GST114_BGRA = 0, GST114_RGBA = 1 };
 enum { GST114_BILINEAR = 0, GST114_NEAREST = 1 };
 
+int gst114_set_threads (int n);
 void gst114_yuv_to_rgb (int matrix, int Y, int U, int V, int *r, int *g, int *b);
 int gst114_yuv420_to_rgb (const uint8_t *yp, int ys, const uint8_t *up, int us, const uint8_t *vp, int vs,
     int planar, int w, int h, int matrix, int cosited, int out_format, uint8_t *out, int os);
