@@ -52,8 +52,9 @@ template <int HI>
 __device__ __forceinline__ int mad_i32_i16 (uint32_t a, int coef, int acc)
 {
   int d;
-  if (HI) asm ("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(a), "v"(coef), "v"(acc));
-  else    asm ("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(coef), "v"(acc));
+  // coef is wave-uniform (a kernel argument): "s" keeps it in an SGPR (one scalar operand per VOP3 is allowed on gfx9)
+  if (HI) asm ("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(a), "s"(coef), "v"(acc));
+  else    asm ("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(coef), "v"(acc));
   return d;
 }
 __device__ __forceinline__ uint32_t sat_pk_u8_i16 (uint32_t v)
@@ -103,16 +104,17 @@ struct CRow { uint32_t e01, e23, o01, o23; };   // horizontally up-sampled chrom
 
 struct CRaw { uint2 v; uint32_t right, left; };      // raw chroma bytes of one row: 4 samples + right / left neighbour pair
 
+// `plane` is wave-uniform, `off` = row * stride + 8 * cg as a 32-bit byte offset; `roff` / `loff` = byte distance of the
+// right / left neighbour chroma pair, edge-replicated WITHOUT a branch (a divergent branch here forces vmcnt(0) and
+// serialises the software pipeline): the last / first lane of a row re-reads its own outer pair (roff 6, loff 0).
 template <bool COSITED>
-__device__ __forceinline__ CRaw load_craw (const uint8_t *row, int cg, int cgpr)
+__device__ __forceinline__ CRaw load_craw (const uint8_t *plane, uint32_t off, uint32_t roff, uint32_t loff)
 {
   CRaw r;
-  r.v = *reinterpret_cast<const uint2 *> (row + 8 * (size_t) cg);                 // [U0V0U1V1][U2V2U3V3]
-  // neighbour chroma pairs, edge-replicated WITHOUT a branch (a divergent branch here forces vmcnt(0) and
-  // serialises the software pipeline): the last / first lane of a row re-reads its own outer pair
-  r.right = *reinterpret_cast<const uint16_t *> (row + 8 * (size_t) cg + (cg == cgpr - 1 ? 6 : 8));
+  r.v = *reinterpret_cast<const uint2 *> (plane + off);                            // [U0V0U1V1][U2V2U3V3]
+  r.right = *reinterpret_cast<const uint16_t *> (plane + (off + roff));
   r.left = 0;
-  if (!COSITED) r.left = *reinterpret_cast<const uint16_t *> (row + 8 * (size_t) cg - (cg == 0 ? 0 : 2));
+  if (!COSITED) r.left = *reinterpret_cast<const uint16_t *> (plane + (off - loff));
   return r;
 }
 
@@ -159,6 +161,61 @@ __device__ __forceinline__ void orc_pair (uint32_t ys, uint32_t uve, uint32_t uv
   rr = sat_pk_u8_i16 (perm_b32 ((uint32_t) tro, (uint32_t) tre, 0x07060302u));
 }
 
+// per-lane constants of the fast path
+struct HalfCtx {
+  const uint8_t *yp, *uvp;
+  uint8_t *op;
+  uint32_t ys, cs, os, cx, roff, loff;
+  int ch, yend;
+  int c[5];
+  uint32_t wgt[4];
+};
+
+// One output row `y` of one lane (4 output pixels).  In: chroma state (hc = h-filtered chroma row y, mid_up = floor
+// average of rows y-1 and y) and the prefetched raw rows of THIS row.  Out: the state for row y+1 and the prefetch of
+// row y+1 (issued before this row's arithmetic: register double buffer).  Called twice per loop trip with the two
+// register sets swapped, so the rotation costs no moves.
+template <bool COSITED, bool RGBA>
+__device__ __forceinline__ void half_row (const HalfCtx &k, int y, const CRow &hc, const CRow &mid_up, const CRaw &craw, uint2 yt, uint2 yb,
+    CRow &hn, CRow &mid_dn, CRaw &nraw, uint2 &nyt, uint2 &nyb)
+{
+  {
+    const int yn = min (y + 1, k.yend - 1);              // the last row re-reads itself (never out of bounds)
+    nraw = load_craw<COSITED> (k.uvp, __umul24 ((uint32_t) min (yn + 1, k.ch - 1), k.cs) + k.cx, k.roff, k.loff);
+    const uint32_t yo = __umul24 ((uint32_t) (2 * yn), k.ys) + k.cx;
+    nyt = *reinterpret_cast<const uint2 *> (k.yp + yo);
+    nyb = *reinterpret_cast<const uint2 *> (k.yp + (yo + k.ys));
+  }
+  hn = hfilter<COSITED> (craw);
+  mid_dn = { lerp_u8 (hc.e01, hn.e01, 0u), lerp_u8 (hc.e23, hn.e23, 0u), lerp_u8 (hc.o01, hn.o01, 0u), lerp_u8 (hc.o23, hn.o23, 0u) };
+  const uint32_t K1 = 0x01010101u, X = 0x80808080u;
+  const int bias = 128 << 16;
+  // vertical chroma filter (3a+b+2)>>2: source row 2y leans on chroma row y-1, row 2y+1 on chroma row y+1
+  const uint32_t te01 = lerp_u8 (hc.e01, mid_up.e01, K1) ^ X, te23 = lerp_u8 (hc.e23, mid_up.e23, K1) ^ X;
+  const uint32_t to01 = lerp_u8 (hc.o01, mid_up.o01, K1) ^ X, to23 = lerp_u8 (hc.o23, mid_up.o23, K1) ^ X;
+  const uint32_t be01 = lerp_u8 (hc.e01, mid_dn.e01, K1) ^ X, be23 = lerp_u8 (hc.e23, mid_dn.e23, K1) ^ X;
+  const uint32_t bo01 = lerp_u8 (hc.o01, mid_dn.o01, K1) ^ X, bo23 = lerp_u8 (hc.o23, mid_dn.o23, K1) ^ X;
+  const uint32_t yt0 = yt.x ^ X, yt1 = yt.y ^ X, yb0 = yb.x ^ X, yb1 = yb.y ^ X;
+  uint32_t out[4];
+#pragma unroll
+  for (int n = 0; n < 4; n++) {
+    const uint32_t sy = (n & 1) ? 0x03030202u : 0x01010000u;       // luma bytes (2n, 2n+1) of the row's 8
+    const uint32_t su = (n & 1) ? 0x03030202u : 0x01010000u;       // chroma pair n within its dword
+    const uint32_t ytn = n < 2 ? yt0 : yt1, ybn = n < 2 ? yb0 : yb1;
+    const uint32_t ten = n < 2 ? te01 : te23, ton = n < 2 ? to01 : to23, ben = n < 2 ? be01 : be23, bon = n < 2 ? bo01 : bo23;
+    uint32_t bt, gt, rt, bbm, gbm, rbm;
+    orc_pair (perm_b32 (0u, ytn, sy), perm_b32 (0u, ten, su), perm_b32 (0u, ton, su), k.c, bias, bt, gt, rt);
+    orc_pair (perm_b32 (0u, ybn, sy), perm_b32 (0u, ben, su), perm_b32 (0u, bon, su), k.c, bias, bbm, gbm, rbm);
+    // vertical 2-tap, w = 128: s1 + (((s2-s1)*128+128)>>8) == (s1+s2+1)>>1 on the [even, odd] byte pairs
+    const uint32_t vb = avg_rnd_u8 (bt, bbm), vg = avg_rnd_u8 (gt, gbm), vr = avg_rnd_u8 (rt, rbm);
+    // horizontal 2-tap: (e*(256-f) + o*f) >> 8 = (e*(255-f) + o*f + e) >> 8
+    const uint32_t hb = dot4_u8 (vb, k.wgt[n], vb & 0xffu), hg = dot4_u8 (vg, k.wgt[n], vg & 0xffu), hr = dot4_u8 (vr, k.wgt[n], vr & 0xffu);
+    const uint32_t lo = RGBA ? perm_b32 (hg, hr, 0x0c0c0501u) : perm_b32 (hg, hb, 0x0c0c0501u);      // [X>>8, G>>8, -, -]
+    out[n] = perm_b32 (RGBA ? hb : hr, lo, 0x0d050100u);                                               // [X, G, Z, 0xff]
+  }
+  *reinterpret_cast<uint4 *> (k.op + (__umul24 ((uint32_t) y, k.os) + 2u * k.cx)) = make_uint4 (out[0], out[1], out[2], out[3]);
+}
+
 // grid: x = ceil(cgpr * strips / 256), y = frames.  cgpr = out_w / 4 column groups per row.
 template <int ROWS, bool COSITED, bool RGBA>
 __global__ __launch_bounds__ (256, 8) void k_cs_nv12_half (const CsParams p)
@@ -169,68 +226,39 @@ __global__ __launch_bounds__ (256, 8) void k_cs_nv12_half (const CsParams p)
   if (t >= cgpr * strips) return;
   const int strip = t / cgpr, cg = t - strip * cgpr;
   const int y0 = strip * ROWS;
-  const int ch = p.out_h;                       // chroma rows == output rows at 2:1
-  const uint8_t *yp = p.in[0] + (size_t) blockIdx.y * p.in_pitch;
-  const uint8_t *uvp = p.in[1] + (size_t) blockIdx.y * p.in_pitch;
-  uint8_t *op = p.out + (size_t) blockIdx.y * p.out_pitch;
-  const int c[5] = { p.c[0], p.c[1], p.c[2], p.c[3], p.c[4] };
-  const int bias = 128 << 16;
-
+  HalfCtx k;
+  k.yp = p.in[0] + (size_t) blockIdx.y * p.in_pitch;          // wave-uniform plane bases; per-lane parts are 32-bit offsets
+  k.uvp = p.in[1] + (size_t) blockIdx.y * p.in_pitch;         // (global_load with SGPR base + VGPR offset)
+  k.op = p.out + (size_t) blockIdx.y * p.out_pitch;
+  k.ys = (uint32_t) p.is[0]; k.cs = (uint32_t) p.is[1]; k.os = (uint32_t) p.os;
+  k.cx = 8u * (uint32_t) cg;
+  k.roff = cg == cgpr - 1 ? 6u : 8u; k.loff = cg == 0 ? 0u : 2u;
+  k.ch = p.out_h;                                              // chroma rows == output rows at 2:1
+  k.yend = min (y0 + ROWS, p.out_h);
+#pragma unroll
+  for (int i = 0; i < 5; i++) k.c[i] = p.c[i];
   // horizontal tap weights of this lane's 4 output pixels (row independent): bytes [255-f, f, 0, 0]
-  uint32_t wgt[4];
 #pragma unroll
   for (int n = 0; n < 4; n++) {
     const uint32_t tt = (uint32_t) (cg * 4 + n) * p.hinc;
     const uint32_t f = (tt >> 8) & 0xffu;
-    wgt[n] = (255u - f) | (f << 8);
+    k.wgt[n] = (255u - f) | (f << 8);
   }
 
-  const int yend = min (y0 + ROWS, p.out_h);
-  CRow hm = hfilter<COSITED> (load_craw<COSITED> (uvp + (size_t) max (y0 - 1, 0) * p.is[1], cg, cgpr));
-  CRow hc = hfilter<COSITED> (load_craw<COSITED> (uvp + (size_t) y0 * p.is[1], cg, cgpr));
-  // floor-average of chroma rows (j-1, j): the inner half of (3a+b+2)>>2; the (j, j+1) one is reused next row
-  CRow mid_up = { lerp_u8 (hc.e01, hm.e01, 0u), lerp_u8 (hc.e23, hm.e23, 0u), lerp_u8 (hc.o01, hm.o01, 0u), lerp_u8 (hc.o23, hm.o23, 0u) };
-  // software pipeline: the loads of row y+1 are issued before row y is computed (registers as the double buffer)
-  CRaw nraw = load_craw<COSITED> (uvp + (size_t) min (y0 + 1, ch - 1) * p.is[1], cg, cgpr);
-  uint2 nyt = *reinterpret_cast<const uint2 *> (yp + (size_t) (2 * y0) * p.is[0] + 8 * (size_t) cg);
-  uint2 nyb = *reinterpret_cast<const uint2 *> (yp + (size_t) (2 * y0 + 1) * p.is[0] + 8 * (size_t) cg);
-  for (int y = y0; y < yend; y++) {
-    const CRaw craw = nraw;
-    const uint2 yt = nyt, yb = nyb;
-    {
-      const int yn = min (y + 1, yend - 1);              // last iteration re-reads its own rows (never out of bounds)
-      nraw = load_craw<COSITED> (uvp + (size_t) min (yn + 1, ch - 1) * p.is[1], cg, cgpr);
-      nyt = *reinterpret_cast<const uint2 *> (yp + (size_t) (2 * yn) * p.is[0] + 8 * (size_t) cg);
-      nyb = *reinterpret_cast<const uint2 *> (yp + (size_t) (2 * yn + 1) * p.is[0] + 8 * (size_t) cg);
-    }
-    const CRow hn = hfilter<COSITED> (craw);
-    const CRow mid_dn = { lerp_u8 (hc.e01, hn.e01, 0u), lerp_u8 (hc.e23, hn.e23, 0u), lerp_u8 (hc.o01, hn.o01, 0u), lerp_u8 (hc.o23, hn.o23, 0u) };
-    const uint32_t K1 = 0x01010101u, X = 0x80808080u;
-    // vertical chroma filter (3a+b+2)>>2: source row 2y leans on chroma row y-1, row 2y+1 on chroma row y+1
-    const uint32_t te01 = lerp_u8 (hc.e01, mid_up.e01, K1) ^ X, te23 = lerp_u8 (hc.e23, mid_up.e23, K1) ^ X;
-    const uint32_t to01 = lerp_u8 (hc.o01, mid_up.o01, K1) ^ X, to23 = lerp_u8 (hc.o23, mid_up.o23, K1) ^ X;
-    const uint32_t be01 = lerp_u8 (hc.e01, mid_dn.e01, K1) ^ X, be23 = lerp_u8 (hc.e23, mid_dn.e23, K1) ^ X;
-    const uint32_t bo01 = lerp_u8 (hc.o01, mid_dn.o01, K1) ^ X, bo23 = lerp_u8 (hc.o23, mid_dn.o23, K1) ^ X;
-    const uint32_t yt0 = yt.x ^ X, yt1 = yt.y ^ X, yb0 = yb.x ^ X, yb1 = yb.y ^ X;
-    uint32_t out[4];
-#pragma unroll
-    for (int n = 0; n < 4; n++) {
-      const uint32_t sy = (n & 1) ? 0x03030202u : 0x01010000u;       // luma bytes (2n, 2n+1) of the row's 8
-      const uint32_t su = (n & 1) ? 0x03030202u : 0x01010000u;       // chroma pair n within its dword
-      const uint32_t ytn = n < 2 ? yt0 : yt1, ybn = n < 2 ? yb0 : yb1;
-      const uint32_t ten = n < 2 ? te01 : te23, ton = n < 2 ? to01 : to23, ben = n < 2 ? be01 : be23, bon = n < 2 ? bo01 : bo23;
-      uint32_t bt, gt, rt, bbm, gbm, rbm;
-      orc_pair (perm_b32 (0u, ytn, sy), perm_b32 (0u, ten, su), perm_b32 (0u, ton, su), c, bias, bt, gt, rt);
-      orc_pair (perm_b32 (0u, ybn, sy), perm_b32 (0u, ben, su), perm_b32 (0u, bon, su), c, bias, bbm, gbm, rbm);
-      // vertical 2-tap, w = 128: s1 + (((s2-s1)*128+128)>>8) == (s1+s2+1)>>1 on the [even, odd] byte pairs
-      const uint32_t vb = avg_rnd_u8 (bt, bbm), vg = avg_rnd_u8 (gt, gbm), vr = avg_rnd_u8 (rt, rbm);
-      // horizontal 2-tap: (e*(256-f) + o*f) >> 8 = (e*(255-f) + o*f + e) >> 8
-      const uint32_t hb = dot4_u8 (vb, wgt[n], vb & 0xffu), hg = dot4_u8 (vg, wgt[n], vg & 0xffu), hr = dot4_u8 (vr, wgt[n], vr & 0xffu);
-      const uint32_t lo = RGBA ? perm_b32 (hg, hr, 0x0c0c0501u) : perm_b32 (hg, hb, 0x0c0c0501u);      // [X>>8, G>>8, -, -]
-      out[n] = perm_b32 (RGBA ? hb : hr, lo, 0x0d050100u);                                               // [X, G, Z, 0xff]
-    }
-    *reinterpret_cast<uint4 *> (op + (size_t) y * p.os + 16 * (size_t) cg) = make_uint4 (out[0], out[1], out[2], out[3]);
-    hm = hc; hc = hn; mid_up = mid_dn;
+  CRow hcA, midA, hcB, midB;
+  {
+    const CRow hm = hfilter<COSITED> (load_craw<COSITED> (k.uvp, __umul24 ((uint32_t) max (y0 - 1, 0), k.cs) + k.cx, k.roff, k.loff));
+    hcA = hfilter<COSITED> (load_craw<COSITED> (k.uvp, __umul24 ((uint32_t) y0, k.cs) + k.cx, k.roff, k.loff));
+    // floor-average of chroma rows (j-1, j): the inner half of (3a+b+2)>>2; the (j, j+1) one is reused by the next row
+    midA = { lerp_u8 (hcA.e01, hm.e01, 0u), lerp_u8 (hcA.e23, hm.e23, 0u), lerp_u8 (hcA.o01, hm.o01, 0u), lerp_u8 (hcA.o23, hm.o23, 0u) };
+  }
+  CRaw rawA = load_craw<COSITED> (k.uvp, __umul24 ((uint32_t) min (y0 + 1, k.ch - 1), k.cs) + k.cx, k.roff, k.loff), rawB;
+  uint2 ytA = *reinterpret_cast<const uint2 *> (k.yp + (__umul24 ((uint32_t) (2 * y0), k.ys) + k.cx)), ytB;
+  uint2 ybA = *reinterpret_cast<const uint2 *> (k.yp + (__umul24 ((uint32_t) (2 * y0 + 1), k.ys) + k.cx)), ybB;
+  for (int y = y0; y < k.yend; y += 2) {
+    half_row<COSITED, RGBA> (k, y, hcA, midA, rawA, ytA, ybA, hcB, midB, rawB, ytB, ybB);
+    if (y + 1 >= k.yend) break;                                // odd tail (only when out_h is odd)
+    half_row<COSITED, RGBA> (k, y + 1, hcB, midB, rawB, ytB, ybB, hcA, midA, rawA, ytA, ybA);
   }
 }
 
