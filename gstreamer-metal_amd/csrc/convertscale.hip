@@ -7,10 +7,24 @@
 #include "vfhip_internal.h"
 #include "convertscale_kernels.h"
 #include "convertscale_metal_kernels.h"
+#include "convertscale_planar_kernels.h"
 #include <cmath>
 #include <cstdlib>
 
 using namespace vfhip;
+
+// videoconvert's RGB -> YUV 8-bit integer matrices (oracle/gst114.c RGB2YUV, pinned against the real element)
+static const int kRgb2Yuv[3][9] = {
+  {  66, 129,  25,  -38,  -74, 112,  112,  -94, -18 },   // bt601
+  {  47, 157,  16,  -26,  -87, 112,  112, -102, -10 },   // bt709
+  {  58, 149,  13,  -31,  -81, 112,  112, -103,  -9 },   // bt2020
+};
+
+struct PlaneCfg {                 // stage-2 set-up of one output plane (gst-exact, 4:2:0 outputs)
+  int w = 0, h = 0, ow = 0, oh = 0, n = 1, hmode = 0, vscale_on = 0, vfirst = 0;
+  uint32_t hinc = 0;
+  int *d_vtab = nullptr, *d_htab = nullptr;
+};
 
 static const int kOrcCoef[3][5] = {
   { 298, 409, 516, -100, -208 },   // bt601
@@ -30,8 +44,13 @@ struct VfHipConvertScale {
   int *d_vtab = nullptr, *d_htab = nullptr;
   int vfirst = 1, hscale_on = 0;
   uint32_t hinc = 0;
-  enum Kernel { K_NONE, K_HALF, K_GENERIC, K_METAL } kernel = K_NONE;
+  enum Kernel { K_NONE, K_HALF, K_GENERIC, K_METAL, K_STAGED } kernel = K_NONE;
   const char *kernel_name = "none";
+  // K_STAGED: videoconvert at the input size into `mid` (when the format changes), then per-plane videoscale
+  PlaneCfg plane[3];
+  int n_out_planes = 0;
+  bool need_convert = false, need_scale = false;
+  void *mid = nullptr; size_t mid_bytes = 0;
 };
 
 static void free_tables (VfHipConvertScale *h)
@@ -39,6 +58,66 @@ static void free_tables (VfHipConvertScale *h)
   if (h->d_vtab) (void) hipFree (h->d_vtab);
   if (h->d_htab) (void) hipFree (h->d_htab);
   h->d_vtab = h->d_htab = nullptr;
+  for (auto &pc : h->plane) {
+    if (pc.d_vtab) (void) hipFree (pc.d_vtab);
+    if (pc.d_htab) (void) hipFree (pc.d_htab);
+    pc = PlaneCfg ();
+  }
+  if (h->mid) (void) hipFree (h->mid);
+  h->mid = nullptr; h->mid_bytes = 0;
+}
+
+static int upload_ints (const std::vector<int> &v, int **dst)
+{
+  *dst = nullptr;
+  if (v.empty ()) return VFHIP_OK;
+  VFHIP_CHECK_HIP (hipMalloc (dst, v.size () * sizeof (int)));
+  VFHIP_CHECK_HIP (hipMemcpy (*dst, v.data (), v.size () * sizeof (int), hipMemcpyHostToDevice));
+  return VFHIP_OK;
+}
+
+// GstVideoScaler's 2-tap vertical set-up (8-bit weights, centre aligned)
+static void vertical_taps (int in_h, int out_h, std::vector<int> &vt)
+{
+  vt.assign ((size_t) out_h * 4, 0);
+  for (int y = 0; y < out_h; y++) {
+    int i0 = y, i1 = y, w = 0;
+    if (out_h != in_h) {
+      const double p = (y + 0.5) * in_h / out_h - 0.5;
+      const int i = (int) std::floor (p);
+      w = (int) std::floor ((p - i) * 256.0 + 0.5);
+      i0 = i < 0 ? 0 : (i > in_h - 1 ? in_h - 1 : i);
+      i1 = i + 1 < 0 ? 0 : (i + 1 > in_h - 1 ? in_h - 1 : i + 1);
+    }
+    vt[4 * y] = i0; vt[4 * y + 1] = i1; vt[4 * y + 2] = w;
+  }
+}
+
+// stage-2 configuration of one plane (rules: oracle/gst114.c gst114_scale_plane)
+static int setup_plane (PlaneCfg &pc, int w, int h, int ow, int oh, int n)
+{
+  pc = PlaneCfg ();
+  pc.w = w; pc.h = h; pc.ow = ow; pc.oh = oh; pc.n = n;
+  pc.vscale_on = oh != h; pc.vfirst = h > oh + 2;
+  std::vector<int> vt, ht;
+  vertical_taps (h, oh, vt);
+  if (ow == w) pc.hmode = 0;
+  else if (n == 1 && w == 2 * ow && (oh == h || h == 2 * oh)) pc.hmode = 2;
+  else if (n == 1) { pc.hmode = 1; pc.hinc = ow > 1 ? (uint32_t) ((((uint64_t) (w - 1)) << 16) / (uint64_t) (ow - 1)) - 1 : 0; }
+  else {
+    pc.hmode = 3;
+    ht.assign ((size_t) ow * 4, 0);
+    for (int x = 0; x < ow; x++) {
+      const double p = (x + 0.5) * w / ow - 0.5;
+      const int i = (int) std::floor (p);
+      ht[4 * x] = i < 0 ? 0 : (i > w - 1 ? w - 1 : i);
+      ht[4 * x + 1] = i + 1 < 0 ? 0 : (i + 1 > w - 1 ? w - 1 : i + 1);
+      ht[4 * x + 2] = (int) std::floor ((p - i) * 64.0 + 0.5);
+    }
+  }
+  int rc = upload_ints (vt, &pc.d_vtab);
+  if (rc) return rc;
+  return upload_ints (ht, &pc.d_htab);
 }
 
 // GStreamer 1.14 nearest-neighbour source index: floor(((j + .5) / out) * in) in IEEE double, in that order.
@@ -126,6 +205,31 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
   const bool out_rgb = out->format == VFHIP_FORMAT_BGRA || out->format == VFHIP_FORMAT_RGBA;
   // gst-exact covers the cells whose GStreamer arithmetic is pinned; every other cell of
   // the 6x6 matrix runs the reference-shader (metal) arithmetic.
+  const bool in_yuv = in->format == VFHIP_FORMAT_NV12 || in->format == VFHIP_FORMAT_I420;
+  const bool out_420 = out->format == VFHIP_FORMAT_NV12 || out->format == VFHIP_FORMAT_I420;
+  // 4:2:0 outputs: pinned for the 2-tap method, no borders, and (YUV -> YUV) an unchanged matrix (no re-matrixing step)
+  const bool staged = numerics == VFHIP_NUMERICS_GST_EXACT && in_420_or_rgb && out_420 && method == VFHIP_SCALE_BILINEAR &&
+                      !h->add_borders && (!in_yuv || (in->color_matrix == out->color_matrix && in->chroma_site == out->chroma_site));
+  if (staged) {
+    const int iw = in->width, ih = in->height, ow = out->width, oh = out->height;
+    h->need_convert = in->format != out->format;
+    h->need_scale = iw != ow || ih != oh;
+    h->n_out_planes = out->format == VFHIP_FORMAT_NV12 ? 2 : 3;
+    int rc = setup_plane (h->plane[0], iw, ih, ow, oh, 1);
+    if (rc) return rc;
+    if (out->format == VFHIP_FORMAT_NV12) rc = setup_plane (h->plane[1], (iw + 1) / 2, (ih + 1) / 2, (ow + 1) / 2, (oh + 1) / 2, 2);
+    else { rc = setup_plane (h->plane[1], (iw + 1) / 2, (ih + 1) / 2, (ow + 1) / 2, (oh + 1) / 2, 1);
+           if (!rc) rc = setup_plane (h->plane[2], (iw + 1) / 2, (ih + 1) / 2, (ow + 1) / 2, (oh + 1) / 2, 1); }
+    if (rc) return rc;
+    if (h->need_convert && h->need_scale) {        // intermediate frame: output format at the input size
+      const size_t ys = ((size_t) iw + 15) / 16 * 16, cs = ((size_t) 2 * ((iw + 1) / 2) + 15) / 16 * 16;
+      h->mid_bytes = ys * ih + 3 * cs * ((ih + 1) / 2) + 1024;
+      VFHIP_CHECK_HIP (hipMalloc (&h->mid, h->mid_bytes));
+    }
+    h->kernel = VfHipConvertScale::K_STAGED; h->kernel_name = "k_cs_staged_420";
+    h->configured = true;
+    return VFHIP_OK;
+  }
   const bool exact = numerics == VFHIP_NUMERICS_GST_EXACT && in_420_or_rgb && out_rgb;
   if (!exact) {
     h->kernel = VfHipConvertScale::K_METAL; h->kernel_name = "k_cs_metal";
@@ -188,12 +292,82 @@ static int validate_frames (VfHipConvertScale *h, const VfHipFrame *in, const Vf
   return VFHIP_OK;
 }
 
+// gst-exact, 4:2:0 output: stage 1 (format change at the input size) + stage 2 (per-plane scale)
+static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame *out, hipStream_t s)
+{
+  const int iw = h->in.width, ih = h->in.height;
+  const bool out_planar = h->out.format == VFHIP_FORMAT_I420;
+  // where stage 1 writes / stage 2 reads: the output itself (no scaling), the input itself (no conversion), or `mid`
+  VfHipFrame mid {};
+  mid.info = h->out; mid.info.width = iw; mid.info.height = ih;
+  if (h->need_convert && h->need_scale) {
+    const size_t ys = ((size_t) iw + 15) / 16 * 16, cs = ((size_t) 2 * ((iw + 1) / 2) + 15) / 16 * 16;
+    uint8_t *b = (uint8_t *) h->mid;
+    mid.data[0] = b; mid.stride[0] = (int) ys;
+    mid.data[1] = b + ys * ih; mid.stride[1] = (int) cs;
+    mid.data[2] = b + ys * ih + cs * ((ih + 1) / 2); mid.stride[2] = (int) cs;
+  } else if (h->need_convert) mid = *out;
+  else mid = *in;
+  const int cw = (iw + 1) / 2, chh = (ih + 1) / 2;
+  if (h->need_convert) {
+    dim3 grid ((unsigned) ((cw + 63) / 64), (unsigned) ((chh + 3) / 4));
+    if (h->in.format == VFHIP_FORMAT_BGRA || h->in.format == VFHIP_FORMAT_RGBA) {
+      Rgb2YuvParams p {};
+      p.in = (const uint8_t *) in->data[0]; p.is = in->stride[0];
+      p.y = (uint8_t *) mid.data[0]; p.ys = mid.stride[0];
+      p.u = (uint8_t *) mid.data[1]; p.us = mid.stride[1];
+      p.v = (uint8_t *) mid.data[2]; p.vs = mid.stride[2];
+      p.w = iw; p.h = ih; p.in_rgba = h->in.format == VFHIP_FORMAT_RGBA; p.planar = out_planar;
+      p.cosited = h->out.chroma_site == VFHIP_CHROMA_SITE_H_COSITED;
+      for (int k = 0; k < 9; k++) p.c[k] = kRgb2Yuv[h->out.color_matrix][k];
+      hipLaunchKernelGGL (k_rgb_to_yuv420, grid, dim3 (64, 4), 0, s, p);
+    } else {
+      RepackParams p {};
+      p.iy = (const uint8_t *) in->data[0]; p.iys = in->stride[0];
+      p.iu = (const uint8_t *) in->data[1]; p.ius = in->stride[1];
+      p.iv = (const uint8_t *) in->data[2]; p.ivs = in->stride[2];
+      p.oy = (uint8_t *) mid.data[0]; p.oys = mid.stride[0];
+      p.ou = (uint8_t *) mid.data[1]; p.ous = mid.stride[1];
+      p.ov = (uint8_t *) mid.data[2]; p.ovs = mid.stride[2];
+      p.w = iw; p.h = ih; p.in_planar = h->in.format == VFHIP_FORMAT_I420; p.out_planar = out_planar;
+      hipLaunchKernelGGL (k_repack_420, grid, dim3 (64, 4), 0, s, p);
+    }
+    VFHIP_CHECK_HIP (hipGetLastError ());
+  }
+  if (h->need_scale || !h->need_convert) {
+    for (int k = 0; k < h->n_out_planes; k++) {
+      const PlaneCfg &pc = h->plane[k];
+      PlaneScaleParams p {};
+      p.in = (const uint8_t *) mid.data[k]; p.is = mid.stride[k];
+      p.out = (uint8_t *) out->data[k]; p.os = out->stride[k];
+      p.w = pc.w; p.h = pc.h; p.ow = pc.ow; p.oh = pc.oh; p.n = pc.n; p.hmode = pc.hmode;
+      p.vscale_on = pc.vscale_on; p.vfirst = pc.vfirst; p.hinc = pc.hinc; p.vtab = pc.d_vtab; p.htab = pc.d_htab;
+      dim3 grid ((unsigned) ((pc.ow + 63) / 64), (unsigned) ((pc.oh + 3) / 4));
+      hipLaunchKernelGGL (k_scale_plane, grid, dim3 (64, 4), 0, s, p);
+      VFHIP_CHECK_HIP (hipGetLastError ());
+    }
+  }
+  return VFHIP_OK;
+}
+
 // launch on device frames; caller holds the mutex
 static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame *out, size_t in_pitch, size_t out_pitch,
     int n_frames, hipStream_t s)
 {
   if (n_frames <= 0) return VFHIP_OK;
   if (n_frames > 65535) return set_error (VFHIP_ERR_INVALID, "batch of %d frames exceeds 65535", n_frames);
+  if (h->kernel == VfHipConvertScale::K_STAGED) {
+    for (int k = 0; k < n_frames; k++) {
+      VfHipFrame fi = *in, fo = *out;
+      for (int p = 0; p < 3; p++) {
+        if (fi.data[p]) fi.data[p] = (uint8_t *) fi.data[p] + (size_t) k * in_pitch;
+        if (fo.data[p]) fo.data[p] = (uint8_t *) fo.data[p] + (size_t) k * out_pitch;
+      }
+      int rc = staged_launch (h, &fi, &fo, s);
+      if (rc) return rc;
+    }
+    return VFHIP_OK;
+  }
   if (h->kernel == VfHipConvertScale::K_METAL)
     return cs_metal_launch (h->in, h->out, h->method, h->add_borders, h->border_color, in, out, in_pitch, out_pitch, n_frames, s);
   CsParams p {};

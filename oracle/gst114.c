@@ -198,6 +198,128 @@ int gst114_scale_4u8 (const uint8_t *in, int is, int w, int h, uint8_t *out, int
   return 0;
 }
 
+
+/* ---- RGB -> YUV 4:2:0 (videoconvert BGRA/RGBA -> NV12/I420), pinned by probing the real element:
+ *   Y = ((cy . rgb) >> 8) + 16, U = ((cu . rgb) >> 8) + 128, V likewise, arithmetic shifts, 8-bit coefficients;
+ *   4:4:4 -> 4:2:0: vertical (a+b+1)>>1 first (an odd last row pairs with itself), then horizontal:
+ *   not co-sited: (a+b+1)>>1 (an odd last column pairs with itself); h-co-sited (mpeg2): (l + 2c + r + 2)>>2 with the
+ *   left tap of the first sample AND the right tap of the LAST sample replaced by the centre (GStreamer quirk: the last
+ *   sample ignores its right neighbour even when it exists). */
+static const int RGB2YUV[3][9] = {
+  {  66, 129,  25,  -38,  -74, 112,  112,  -94, -18 },   /* bt601  */
+  {  47, 157,  16,  -26,  -87, 112,  112, -102, -10 },   /* bt709  */
+  {  58, 149,  13,  -31,  -81, 112,  112, -103,  -9 },   /* bt2020 */
+};
+
+int gst114_rgb_to_yuv420 (const uint8_t *in, int is, int in_format, int w, int h, int matrix, int cosited,
+    int planar, uint8_t *yp, int ys, uint8_t *up, int us, uint8_t *vp, int vs)
+{
+  if (w <= 0 || h <= 0 || matrix < 0 || matrix > 2) return -1;
+  const int *c = RGB2YUV[matrix];
+  const int ro = in_format == GST114_RGBA ? 0 : 2, bo = 2 - ro;
+  const int cw = (w + 1) / 2, ch = (h + 1) / 2;
+  int *vu = malloc ((size_t) ch * w * sizeof (int)), *vv = malloc ((size_t) ch * w * sizeof (int));
+  if (!vu || !vv) { free (vu); free (vv); return -2; }
+#pragma omp parallel for schedule(static)
+  for (int j = 0; j < ch; j++) {
+    for (int x = 0; x < w; x++) {
+      int su = 1, sv = 1;
+      for (int d = 0; d < 2; d++) {
+        const int y = 2 * j + d < h ? 2 * j + d : h - 1;
+        const uint8_t *px = in + (size_t) y * is + 4 * x;
+        const int r = px[ro], g = px[1], b = px[bo];
+        if (2 * j + d < h) yp[(size_t) y * ys + x] = (uint8_t) (((c[0] * r + c[1] * g + c[2] * b) >> 8) + 16);
+        su += ((c[3] * r + c[4] * g + c[5] * b) >> 8) + 128;
+        sv += ((c[6] * r + c[7] * g + c[8] * b) >> 8) + 128;
+      }
+      vu[(size_t) j * w + x] = su >> 1; vv[(size_t) j * w + x] = sv >> 1;
+    }
+  }
+#pragma omp parallel for schedule(static)
+  for (int j = 0; j < ch; j++) {
+    const int *ru = vu + (size_t) j * w, *rv = vv + (size_t) j * w;
+    for (int k = 0; k < cw; k++) {
+      int U, V;
+      const int x = 2 * k;
+      if (cosited) {
+        const int l = x > 0 ? x - 1 : 0, r = k == cw - 1 ? x : (x + 1 < w ? x + 1 : w - 1);
+        U = (ru[l] + 2 * ru[x] + ru[r] + 2) >> 2; V = (rv[l] + 2 * rv[x] + rv[r] + 2) >> 2;
+      } else {
+        const int r = x + 1 < w ? x + 1 : w - 1;
+        U = (ru[x] + ru[r] + 1) >> 1; V = (rv[x] + rv[r] + 1) >> 1;
+      }
+      if (planar) { up[(size_t) j * us + k] = (uint8_t) U; vp[(size_t) j * vs + k] = (uint8_t) V; }
+      else { up[(size_t) j * us + 2 * k] = (uint8_t) U; up[(size_t) j * us + 2 * k + 1] = (uint8_t) V; }
+    }
+  }
+  free (vu); free (vv);
+  return 0;
+}
+
+/* ---- videoscale on planar 8-bit data (NV12 / I420 -> same format), pinned by probing the real element:
+ *   vertical: the same 8-bit centre-aligned 2-tap as for 4 x u8;
+ *   horizontal, 1 x u8 planes (Y, I420 chroma): the edge-aligned 16.16 path of the 4 x u8 case, EXCEPT when the plane is
+ *   exactly halved horizontally and vertically unchanged or exactly halved: then pairs average, (a+b+1)>>1;
+ *   horizontal, 2 x u8 plane (NV12 chroma): centre-aligned with 6-bit taps: t = round(frac*64), (a(64-t) + b t + 32)>>6;
+ *   pass order per plane: vertical first iff plane_in_h > plane_out_h + 2. */
+static void hscale_plane (const uint8_t *in, int is, int w, int h, int n, uint8_t *out, int os, int ow, int half)
+{
+  if (n == 1 && half) {
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < ow; x++) out[(size_t) y * os + x] = (uint8_t) ((in[(size_t) y * is + 2 * x] + in[(size_t) y * is + 2 * x + 1] + 1) >> 1);
+    return;
+  }
+  if (n == 1) {
+    const uint32_t inc = gst114_hinc (w, ow);
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < ow; x++) {
+        const uint32_t t = (uint32_t) x * inc; const int i = t >> 16, f = (t >> 8) & 0xff, i1 = i + 1 < w ? i + 1 : w - 1;
+        out[(size_t) y * os + x] = (uint8_t) ((in[(size_t) y * is + i] * (256 - f) + in[(size_t) y * is + i1] * f) >> 8);
+      }
+    return;
+  }
+  for (int x = 0; x < ow; x++) {
+    const double p = (x + 0.5) * w / ow - 0.5;
+    const int i = (int) __builtin_floor (p);
+    const int t = (int) __builtin_floor ((p - i) * 64.0 + 0.5);
+    const int i0 = clampi (i, 0, w - 1), i1 = clampi (i + 1, 0, w - 1);
+    for (int y = 0; y < h; y++)
+      for (int c = 0; c < n; c++)
+        out[(size_t) y * os + n * x + c] = (uint8_t) ((in[(size_t) y * is + n * i0 + c] * (64 - t) + in[(size_t) y * is + n * i1 + c] * t + 32) >> 6);
+  }
+}
+
+static void vscale_plane (const uint8_t *in, int is, int wb, int h, uint8_t *out, int os, int oh)
+{
+  for (int y = 0; y < oh; y++) {
+    int i0, i1, wt; gst114_vtaps (h, oh, y, &i0, &i1, &wt);
+    const uint8_t *s1 = in + (size_t) i0 * is, *s2 = in + (size_t) i1 * is;
+    for (int k = 0; k < wb; k++) out[(size_t) y * os + k] = (uint8_t) (s1[k] + ((((int) s2[k] - (int) s1[k]) * wt + 128) >> 8));
+  }
+}
+
+/* one plane of `n` interleaved u8 components, w x h samples -> ow x oh samples */
+int gst114_scale_plane (const uint8_t *in, int is, int w, int h, int n, uint8_t *out, int os, int ow, int oh)
+{
+  if (w <= 0 || h <= 0 || ow <= 0 || oh <= 0 || (n != 1 && n != 2)) return -1;
+  const int half = (w == 2 * ow) && (oh == h || h == 2 * oh);
+  if (ow == w && oh == h) { for (int y = 0; y < h; y++) memcpy (out + (size_t) y * os, in + (size_t) y * is, (size_t) n * w); return 0; }
+  if (ow == w) { vscale_plane (in, is, n * w, h, out, os, oh); return 0; }
+  if (oh == h) { hscale_plane (in, is, w, h, n, out, os, ow, half); return 0; }
+  if (h > oh + 2) {
+    uint8_t *tmp = malloc ((size_t) oh * w * n); if (!tmp) return -2;
+    vscale_plane (in, is, n * w, h, tmp, n * w, oh);
+    hscale_plane (tmp, n * w, w, oh, n, out, os, ow, half);
+    free (tmp);
+  } else {
+    uint8_t *tmp = malloc ((size_t) h * ow * n); if (!tmp) return -2;
+    hscale_plane (in, is, w, h, n, tmp, n * ow, ow, half);
+    vscale_plane (tmp, n * ow, n * ow, h, out, os, oh);
+    free (tmp);
+  }
+  return 0;
+}
+
 int gst114_default_matrix (int height) { return height >= 2160 ? GST114_BT2020 : height > 576 ? GST114_BT709 : GST114_BT601; }
 int gst114_default_cosited (int height) { return height > 576; }
 

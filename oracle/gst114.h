@@ -17,6 +17,9 @@ void gst114_vtaps (int in_h, int out_h, int y, int *i0, int *i1, int *w);
 uint32_t gst114_hinc (int in_w, int out_w);
 int gst114_nearest_index (int in, int out, int j);
 int gst114_scale_4u8 (const uint8_t *in, int is, int w, int h, uint8_t *out, int os, int ow, int oh, int method);
+int gst114_rgb_to_yuv420 (const uint8_t *in, int is, int in_format, int w, int h, int matrix, int cosited,
+    int planar, uint8_t *yp, int ys, uint8_t *up, int us, uint8_t *vp, int vs);
+int gst114_scale_plane (const uint8_t *in, int is, int w, int h, int n, uint8_t *out, int os, int ow, int oh);
 int gst114_default_matrix (int height);
 int gst114_default_cosited (int height);
 int gst114_convertscale_yuv420 (const uint8_t *yp, int ys, const uint8_t *up, int us, const uint8_t *vp, int vs,

@@ -57,26 +57,79 @@ class Oracle:
         return C.c_void_p(a.ctypes.data + off)
 
     def convertscale(self, fmt, w, h, raw, colorimetry, chroma_site, method, out_format, ow, oh):
-        """raw: bytes/array in GstVideoInfo default layout. Returns (oh, ow, 4) uint8."""
+        """GStreamer 1.14 `videoconvert ! videoscale` on one frame in GstVideoInfo default layout, any of
+        {NV12, I420, BGRA, RGBA} -> any of them.  RGB outputs return (oh, ow, 4); YUV outputs the raw output frame."""
         if colorimetry is None:
             colorimetry, chroma_site = default_colorimetry(h)
-        pl = planes(fmt, w, h, np.frombuffer(raw, np.uint8) if isinstance(raw, (bytes, bytearray)) else raw)
-        out = np.zeros((oh, ow, 4), np.uint8)
+        raw = np.ascontiguousarray(np.frombuffer(raw, np.uint8) if isinstance(raw, (bytes, bytearray)) else raw, dtype=np.uint8)
+        pl = planes(fmt, w, h, raw)
         cos = 1 if chroma_site == "mpeg2" else 0
         meth = 1 if method == "nearest" else 0
-        ofmt = 1 if out_format == "RGBA" else 0
-        if fmt == "NV12":
-            (y, ys), (uv, us) = pl
-            rc = self.lib.gst114_convertscale_yuv420(self._p(y), ys, self._p(uv), us, self._p(uv, 1), us, 0, w, h,
-                                                     MATRIX[colorimetry], cos, ofmt, meth, self._p(out), ow * 4, ow, oh)
-        elif fmt == "I420":
-            (y, ys), (u, us), (v, vs) = pl
-            rc = self.lib.gst114_convertscale_yuv420(self._p(y), ys, self._p(u), us, self._p(v), vs, 1, w, h,
-                                                     MATRIX[colorimetry], cos, ofmt, meth, self._p(out), ow * 4, ow, oh)
+        mat = MATRIX[colorimetry]
+        L = self.lib
+        yuv_in, yuv_out = fmt in ("NV12", "I420"), out_format in ("NV12", "I420")
+        if not yuv_out:
+            out = np.zeros((oh, ow, 4), np.uint8)
+            ofmt = 1 if out_format == "RGBA" else 0
+            if fmt == "NV12":
+                (y, ys), (uv, us) = pl
+                rc = L.gst114_convertscale_yuv420(self._p(y), ys, self._p(uv), us, self._p(uv, 1), us, 0, w, h, mat, cos, ofmt, meth,
+                                                  self._p(out), ow * 4, ow, oh)
+            elif fmt == "I420":
+                (y, ys), (u, us), (v, vs) = pl
+                rc = L.gst114_convertscale_yuv420(self._p(y), ys, self._p(u), us, self._p(v), vs, 1, w, h, mat, cos, ofmt, meth,
+                                                  self._p(out), ow * 4, ow, oh)
+            else:
+                src = pl[0][0].reshape(h, w, 4)
+                if fmt != out_format:
+                    src = np.ascontiguousarray(src[..., [2, 1, 0, 3]])
+                rc = L.gst114_scale_4u8(self._p(src), 4 * w, w, h, self._p(out), 4 * ow, ow, oh, meth)
+            if rc != 0:
+                raise RuntimeError(f"oracle rc={rc}")
+            return out
+        assert method == "bilinear", "planar nearest scaling is not restated"
+        # stage 1: videoconvert at the input size -> planes of the output format
+        cw, ch = (w + 1) // 2, (h + 1) // 2
+        Y = np.zeros((h, w), np.uint8)
+        if out_format == "NV12":
+            C = [np.zeros((ch, 2 * cw), np.uint8)]
         else:
-            raise ValueError(fmt)
-        if rc != 0:
-            raise RuntimeError(f"oracle rc={rc}")
+            C = [np.zeros((ch, cw), np.uint8), np.zeros((ch, cw), np.uint8)]
+        if not yuv_in:
+            src = pl[0][0]
+            planar = out_format == "I420"
+            up = C[0]
+            vp = C[1] if planar else C[0]
+            rc = L.gst114_rgb_to_yuv420(self._p(src), 4 * w, 1 if fmt == "RGBA" else 0, w, h, mat, cos, int(planar), self._p(Y), w,
+                                        self._p(up), up.strides[0], self._p(vp), vp.strides[0])
+            assert rc == 0
+        else:
+            Y[:] = pl[0][0].reshape(-1, pl[0][1])[:h, :w]
+            if fmt == "NV12":
+                uv = pl[1][0].reshape(-1, pl[1][1])[:ch, :2 * cw]
+                u, v = uv[:, 0::2], uv[:, 1::2]
+            else:
+                u = pl[1][0].reshape(-1, pl[1][1])[:ch, :cw]
+                v = pl[2][0].reshape(-1, pl[2][1])[:ch, :cw]
+            if out_format == "NV12":
+                C[0][:, 0::2], C[0][:, 1::2] = u, v
+            else:
+                C[0][:], C[1][:] = u, v
+        # stage 2: videoscale, plane by plane
+        ocw, och = (ow + 1) // 2, (oh + 1) // 2
+        lay, size = raw_layout(out_format, ow, oh)
+        out = np.zeros(size, np.uint8)
+
+        def scale(src, sw, sh, n, off, stride, dw, dh):
+            src = np.ascontiguousarray(src)
+            rc = L.gst114_scale_plane(self._p(src), src.strides[0], sw, sh, n, self._p(out, off), stride, dw, dh)
+            assert rc == 0
+        scale(Y, w, h, 1, lay[0][0], lay[0][1], ow, oh)
+        if out_format == "NV12":
+            scale(C[0], cw, ch, 2, lay[1][0], lay[1][1], ocw, och)
+        else:
+            scale(C[0], cw, ch, 1, lay[1][0], lay[1][1], ocw, och)
+            scale(C[1], cw, ch, 1, lay[2][0], lay[2][1], ocw, och)
         return out
 
 

@@ -21,7 +21,7 @@ def run(vfhip, c_in_fmt, w, h, raw, col, site, method, ofmt, ow, oh, numerics="g
     out = cs.process(raw)
     name = cs.kernel_name
     cs.close()
-    return out.reshape(oh, ow, 4), name
+    return (out.reshape(oh, ow, 4) if ofmt in ("BGRA", "RGBA") else out), name
 
 
 @pytest.mark.parametrize("case", MANIFEST, ids=[c["name"] for c in MANIFEST])
@@ -166,3 +166,29 @@ def test_error_behaviour(vfhip):
     cs.cleanup()
     assert vfhip.lib.vfhip_convertscale_process(cs.h, C.byref(fi), C.byref(fo)) == -3
     cs.close()
+
+
+# ---- 4:2:0 outputs (staged gst-exact path: videoconvert at the input size, then per-plane videoscale) ---------------
+from test_oracle_golden import MANIFEST_Y, ZY, meaningful  # noqa: E402
+
+
+@pytest.mark.parametrize("case", MANIFEST_Y, ids=[c["name"] for c in MANIFEST_Y])
+def test_golden_gstreamer_vectors_yuv_outputs(vfhip, case):
+    c = case
+    got, kname = run(vfhip, c["in_format"], c["w"], c["h"], ZY[c["name"] + "_in"], c["colorimetry"], c["chroma_site"],
+                     c["method"], c["out_format"], c["ow"], c["oh"])
+    assert kname == "k_cs_staged_420"
+    want = ZY[c["name"] + "_out"]
+    a, b = meaningful(c["out_format"], c["ow"], c["oh"], got), meaningful(c["out_format"], c["ow"], c["oh"], want)
+    assert np.array_equal(a, b), f"max diff {np.abs(a.astype(int) - b.astype(int)).max()}"
+
+
+@pytest.mark.parametrize("ifmt,ofmt", [("BGRA", "NV12"), ("RGBA", "I420"), ("NV12", "NV12"), ("I420", "NV12"), ("NV12", "I420"), ("I420", "I420")])
+def test_yuv_outputs_1080p_vs_oracle(vfhip, oracle, ifmt, ofmt):
+    """HD sizes against the oracle (1080p -> 720p and the exactly-halved 1080p -> 540p special case)"""
+    rng = np.random.default_rng(17)
+    for (w, h, ow, oh) in [(1920, 1080, 1280, 720), (1920, 1080, 960, 540)]:
+        raw = rng.integers(0, 256, oracle_lib.raw_layout(ifmt, w, h)[1], dtype=np.uint8)
+        got, _ = run(vfhip, ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", ofmt, ow, oh)
+        want = oracle.convertscale(ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", ofmt, ow, oh)
+        assert np.array_equal(meaningful(ofmt, ow, oh, got), meaningful(ofmt, ow, oh, want))

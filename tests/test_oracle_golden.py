@@ -48,3 +48,26 @@ def test_known_answers(oracle):
         assert (r.value, g.value, b.value) == (128, 128, 128)
         oracle.lib.gst114_yuv_to_rgb(m, 16, 128, 128, C.byref(r), C.byref(g), C.byref(b))
         assert r.value == g.value == b.value
+
+
+# ---- cells whose output is NV12 / I420 (golden vectors from the real elements, second fixture file) ----------------
+MANIFEST_Y, ZY = oracle_lib.load_golden("convertscale_gst114_yuvout.npz")
+
+
+def meaningful(fmt, w, h, raw):
+    """the bytes GStreamer defines: rows without their stride padding"""
+    out = []
+    for i, (off, stride) in enumerate(oracle_lib.raw_layout(fmt, w, h)[0]):
+        rows = h if i == 0 else (h + 1) // 2
+        wb = w if i == 0 else (w + 1) // 2 * (2 if fmt == "NV12" else 1)
+        out.append(np.asarray(raw[off: off + rows * stride]).reshape(rows, stride)[:, :wb].reshape(-1))
+    return np.concatenate(out)
+
+
+@pytest.mark.parametrize("case", MANIFEST_Y, ids=[c["name"] for c in MANIFEST_Y])
+def test_oracle_matches_gstreamer_yuv_outputs(oracle, case):
+    c = case
+    got = oracle.convertscale(c["in_format"], c["w"], c["h"], ZY[c["name"] + "_in"], c["colorimetry"], c["chroma_site"],
+                              c["method"], c["out_format"], c["ow"], c["oh"])
+    want = ZY[c["name"] + "_out"]
+    assert np.array_equal(meaningful(c["out_format"], c["ow"], c["oh"], got), meaningful(c["out_format"], c["ow"], c["oh"], want))

@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""tools/bench_elements.py — kernel-only throughput of the other BASELINE configs (device-resident frames, HIP events
+on the launch stream): C3 videofilter BGRA 1080p all 15 properties, C4 compositor 4xBGRA 1080p + NV12 720p -> 2160p,
+C5 greedy-H deinterlace NV12 2160p (+ the convertscale of the chain), plus the generic convertscale kernel on C1.
+Not the headline bench (that is bench.py); one JSON line per config."""
+import json
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gstreamer-metal_amd"))
+import torch  # noqa: E402
+import vfhip  # noqa: E402
+
+PEAK = 8000.0
+
+
+def timed(fn, stream, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    stream.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(iters):
+        fn()
+    e1.record(stream)
+    stream.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def report(name, kernel, ms, frames, bytes_per_frame):
+    gbs = bytes_per_frame * frames / (ms * 1e-3) / 1e9
+    print(json.dumps({"config": name, "kernel": kernel, "ms_per_launch": round(ms, 4), "frames_per_launch": frames,
+                      "frames_per_s": round(frames / ms * 1e3, 1), "algorithmic_bytes_per_frame": bytes_per_frame,
+                      "achieved_GBps": round(gbs, 1), "frac_of_8TBps": round(gbs / PEAK, 4)}), flush=True)
+
+
+def ring(n, size, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return torch.randint(0, 256, (n, (size + 255) // 256 * 256), dtype=torch.uint8, device="cuda", generator=g)
+
+
+def main():
+    s = torch.cuda.Stream()
+    R = 24   # distinct frames per config (>= 400 MB working set with outputs; kernels here are far from the roofline anyway)
+
+    # C3: videofilter BGRA 1080p, all 15 properties (SURVEY.md §8d parameter set)
+    w, h = 1920, 1080
+    fin, fout = ring(R, 4 * w * h, 1), ring(R, 4 * w * h, 2)
+    vf = vfhip.VideoFilter(0)
+    vf.configure("BGRA", w, h)
+    n = 33
+    import numpy as np
+    g = np.linspace(0, 1, n, dtype=np.float32)
+    lut = np.ones((n, n, n, 4), np.float32)
+    lut[..., 0], lut[..., 1], lut[..., 2] = g[None, None, :] ** 1.05, g[None, :, None], g[:, None, None] ** 0.95
+    vf.set_lut(lut)
+    prm = vfhip.filter_params(brightness=0.1, contrast=1.2, saturation=0.8, hue=0.3 * math.pi, gamma=1.5, sharpness=0.5, sepia=0.2,
+                              noise=0.1, vignette=0.3, invert=True, chroma_key=(0.0, 1.0, 0.0), tolerance=0.3, smoothness=0.1)
+
+    def c3():
+        for k in range(R):
+            vf.process_device(fin[k].data_ptr(), fout[k].data_ptr(), prm, stream=s.cuda_stream)
+    report("C3 videofilter BGRA 1080p all-15 + 33^3 LUT", "k_vf_sharp", timed(c3, s, 3), R, 2 * 4 * w * h)
+    prm0 = vfhip.filter_params(brightness=0.1, contrast=1.2, saturation=0.8, gamma=1.5)
+
+    def c3b():
+        for k in range(R):
+            vf.process_device(fin[k].data_ptr(), fout[k].data_ptr(), prm0, stream=s.cuda_stream)
+    vf.clear_lut()
+    report("videofilter BGRA 1080p colour-only (no blur, no LUT)", "k_vf_point", timed(c3b, s, 3), R, 2 * 4 * w * h)
+    vf.close()
+    del fin, fout
+
+    # C5a: greedy-H deinterlace NV12 2160p (cur + prev read, out written)
+    w, h = 3840, 2160
+    size = vfhip.plane_layout("NV12", w, h)[1]
+    din, dout = ring(R, size, 3), ring(R, size, 4)
+    d = vfhip.Deinterlace(0)
+    d.configure("NV12", w, h)
+
+    def c5():
+        for k in range(R):
+            d.process_device(din[k].data_ptr(), dout[k].data_ptr(), method="greedyh", tff=True, threshold=0.1, stream=s.cuda_stream)
+    report("C5a deinterlace greedyh NV12 2160p (+ history copy)", "k_deinterlace", timed(c5, s, 3), R, 3 * size)
+    d.close()
+    del din, dout
+
+    # C4: compositor 4 x BGRA 1080p (alpha .9, over) + NV12 720p centred (alpha .7) -> BGRA 2160p, black background
+    ow, oh = 3840, 2160
+    quads = [ring(4, 4 * 1920 * 1080, 10 + k) for k in range(4)]
+    nv = ring(4, vfhip.plane_layout("NV12", 1280, 720)[1], 20)
+    out = ring(4, 4 * ow * oh, 21)
+    comp = vfhip.Compositor(0)
+    comp.configure("BGRA", ow, oh)
+
+    def c4():
+        for k in range(4):
+            pads = [comp.pad("BGRA", 1920, 1080, quads[q][k].data_ptr(), (q % 2) * 1920, (q // 2) * 1080, 1920, 1080, 0.9, "over") for q in range(4)]
+            pads.append(comp.pad("NV12", 1280, 720, nv[k].data_ptr(), (ow - 1280) // 2, (oh - 720) // 2, 1280, 720, 0.7, "over", "bt709"))
+            comp.composite_device(pads, out[k].data_ptr(), background="black", stream=s.cuda_stream)
+    report("C4 compositor 4xBGRA1080p + NV12 720p -> BGRA 2160p", "k_compositor", timed(c4, s, 3), 4, 4 * 4 * 1920 * 1080 + 1280 * 720 * 3 // 2 + 4 * ow * oh)
+    comp.close()
+    del quads, nv, out
+
+    # C1: generic gst-exact kernel, NV12 1080p -> BGRA 640x480
+    w, h, ow, oh = 1920, 1080, 640, 480
+    size = vfhip.plane_layout("NV12", w, h)[1]
+    pitch = (size + 255) // 256 * 256
+    cin, cout = ring(64, size, 30), ring(64, 4 * ow * oh, 31)
+    cs = vfhip.ConvertScale(0)
+    cs.configure("NV12", w, h, "BGRA", ow, oh, colorimetry="bt709", chroma_site="mpeg2")
+
+    def c1():
+        cs.process_device(cin.data_ptr(), cout.data_ptr(), stream=s.cuda_stream, n_frames=64, in_pitch=pitch, out_pitch=cout.shape[1])
+    report("C1 convertscale NV12 1080p -> BGRA 640x480 (generic gst-exact)", cs.kernel_name, timed(c1, s, 5), 64, w * h * 3 // 2 + 4 * ow * oh)
+    cs.close()
+
+
+if __name__ == "__main__":
+    main()

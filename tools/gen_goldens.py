@@ -114,7 +114,49 @@ def main():
     arrays["manifest"] = np.frombuffer(json.dumps(cases).encode(), np.uint8)
     np.savez_compressed(os.path.join(GOLD, "convertscale_gst114.npz"), **arrays)
     print("wrote", len(cases), "cases")
+    gen_yuv_outputs()
+
+
+def rgb_layout_size(w, h):
+    return 4 * w * h
+
+
+def gen_yuv_outputs():
+    """cells whose OUTPUT is NV12 / I420 (videoconvert's RGB->YUV matrix + chroma averaging, NV12<->I420 re-packing,
+    per-plane videoscale): tests/golden/convertscale_gst114_yuvout.npz"""
+    cases, arrays = [], {}
+    rng = np.random.default_rng(20261005)
+    cols, sites = ["bt601", "bt709", "bt2020"], ["jpeg", "mpeg2"]
+    fixed = [(64, 36, 64, 36), (64, 36, 32, 18), (64, 36, 32, 36), (64, 36, 32, 20), (33, 17, 33, 17), (33, 17, 64, 36), (48, 40, 20, 38),
+             (200, 8, 100, 4), (2, 2, 2, 2), (3, 5, 7, 3), (66, 36, 33, 18), (16, 16, 1, 1)]
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = build_helper(tmp)
+        t = 0
+        for ifmt in ["BGRA", "RGBA", "NV12", "I420"]:
+            for ofmt in ["NV12", "I420"]:
+                for (w, h, ow, oh) in fixed[(t % 3)::3] + [tuple(int(v) for v in rng.integers(2, 90, 4)) for _ in range(5)]:
+                    col, site = cols[t % 3], sites[(t // 3) % 2]
+                    size = rgb_layout_size(w, h) if ifmt in ("BGRA", "RGBA") else (nv12_layout(w, h)[3] if ifmt == "NV12" else i420_layout(w, h)[4])
+                    raw = rng.integers(0, 256, size, dtype=np.uint8).tobytes()
+                    incaps = f"video/x-raw,format={ifmt},width={w},height={h},framerate=1/1"
+                    if ifmt in ("NV12", "I420"):
+                        incaps += f",colorimetry={col},chroma-site={site}"
+                    out = gst_run(exe, tmp, raw, len(raw), incaps, "videoconvert ! videoscale",
+                                  f"video/x-raw,format={ofmt},width={ow},height={oh},colorimetry={col},chroma-site={site}")
+                    name = f"{ifmt.lower()}_to_{ofmt.lower()}_{t:03d}_{w}x{h}_to_{ow}x{oh}"
+                    arrays[name + "_in"] = np.frombuffer(raw, np.uint8)
+                    arrays[name + "_out"] = np.frombuffer(out, np.uint8)
+                    cases.append(dict(name=name, in_format=ifmt, w=w, h=h, colorimetry=col, chroma_site=site, method="bilinear",
+                                      out_format=ofmt, ow=ow, oh=oh, in_sha256=hashlib.sha256(raw).hexdigest(),
+                                      out_sha256=hashlib.sha256(out).hexdigest()))
+                    t += 1
+    arrays["manifest"] = np.frombuffer(json.dumps(cases).encode(), np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "convertscale_gst114_yuvout.npz"), **arrays)
+    print("wrote", len(cases), "yuv-output cases")
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "yuvout":
+        gen_yuv_outputs()
+    else:
+        main()
