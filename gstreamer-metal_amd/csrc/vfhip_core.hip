@@ -173,6 +173,15 @@ int alloc_device_frame (Staging &st, size_t slot, const VfHipVideoInfo *info, Vf
   return VFHIP_OK;
 }
 
+// true when `p` is pinned host memory the HIP runtime knows (hipHostMalloc / hipHostRegister, e.g. a buffer from the
+// plugin's pinned GstAllocator): such planes are DMA'd in place, without the staging memcpy
+static bool is_pinned_host (const void *p)
+{
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes (&a, p) != hipSuccess) { (void) hipGetLastError (); return false; }
+  return a.type == hipMemoryTypeHost;
+}
+
 int upload_frame (Staging &st, size_t slot, const VfHipFrame *host, VfHipFrame *df)
 {
   size_t off[VFHIP_MAX_PLANES], total; int stride[VFHIP_MAX_PLANES];
@@ -188,13 +197,18 @@ int upload_frame (Staging &st, size_t slot, const VfHipFrame *host, VfHipFrame *
     int wb = plane_width_bytes (host->info.format, p, host->info.width);
     int ph = plane_height (host->info.format, p, host->info.height);
     if (host->stride[p] < wb) return set_error (VFHIP_ERR_INVALID, "plane %d stride %d < row bytes %d", p, host->stride[p], wb);
-    uint8_t *dst = (uint8_t *) b.host + off[p];
+    df->data[p] = (uint8_t *) b.devp + off[p]; df->stride[p] = stride[p];
     const uint8_t *src = (const uint8_t *) host->data[p];
+    if (is_pinned_host (src)) {          // zero-copy host side: async 2-D DMA straight from the caller's pinned plane
+      VFHIP_CHECK_HIP (hipMemcpy2DAsync (df->data[p], (size_t) stride[p], src, (size_t) host->stride[p], (size_t) wb, (size_t) ph,
+                                         hipMemcpyHostToDevice, st.s_h2d));
+      continue;
+    }
+    uint8_t *dst = (uint8_t *) b.host + off[p];
     if (host->stride[p] == stride[p]) memcpy (dst, src, (size_t) stride[p] * (ph - 1) + wb);
     else for (int y = 0; y < ph; y++) memcpy (dst + (size_t) y * stride[p], src + (size_t) y * host->stride[p], wb);
-    df->data[p] = (uint8_t *) b.devp + off[p]; df->stride[p] = stride[p];
+    VFHIP_CHECK_HIP (hipMemcpyAsync (df->data[p], dst, (size_t) stride[p] * (ph - 1) + wb, hipMemcpyHostToDevice, st.s_h2d));
   }
-  VFHIP_CHECK_HIP (hipMemcpyAsync (b.devp, b.host, total - 256, hipMemcpyHostToDevice, st.s_h2d));
   VFHIP_CHECK_HIP (hipEventRecord (st.ev_h2d, st.s_h2d));
   return VFHIP_OK;
 }
@@ -206,14 +220,27 @@ int download_frame (Staging &st, size_t slot, const VfHipFrame *df, VfHipFrame *
   if (np < 0) return np;
   Staging::Buf &b = st.slots[slot];
   (void) df;
+  bool staged[VFHIP_MAX_PLANES] = { false, false, false, false };
   VFHIP_CHECK_HIP (hipStreamWaitEvent (st.s_d2h, st.ev_compute, 0));
-  VFHIP_CHECK_HIP (hipMemcpyAsync (b.host, b.devp, total - 256, hipMemcpyDeviceToHost, st.s_d2h));
-  VFHIP_CHECK_HIP (hipStreamSynchronize (st.s_d2h));
   for (int p = 0; p < np; p++) {
     if (!host->data[p]) return set_error (VFHIP_ERR_INVALID, "output plane %d is NULL", p);
     int wb = plane_width_bytes (host->info.format, p, host->info.width);
     int ph = plane_height (host->info.format, p, host->info.height);
     if (host->stride[p] < wb) return set_error (VFHIP_ERR_INVALID, "output plane %d stride %d < row bytes %d", p, host->stride[p], wb);
+    const uint8_t *dsrc = (const uint8_t *) b.devp + off[p];
+    if (is_pinned_host (host->data[p])) {
+      VFHIP_CHECK_HIP (hipMemcpy2DAsync (host->data[p], (size_t) host->stride[p], dsrc, (size_t) stride[p], (size_t) wb, (size_t) ph,
+                                         hipMemcpyDeviceToHost, st.s_d2h));
+    } else {
+      staged[p] = true;
+      VFHIP_CHECK_HIP (hipMemcpyAsync ((uint8_t *) b.host + off[p], dsrc, (size_t) stride[p] * (ph - 1) + wb, hipMemcpyDeviceToHost, st.s_d2h));
+    }
+  }
+  VFHIP_CHECK_HIP (hipStreamSynchronize (st.s_d2h));
+  for (int p = 0; p < np; p++) {
+    if (!staged[p]) continue;
+    int wb = plane_width_bytes (host->info.format, p, host->info.width);
+    int ph = plane_height (host->info.format, p, host->info.height);
     const uint8_t *src = (const uint8_t *) b.host + off[p];
     uint8_t *dst = (uint8_t *) host->data[p];
     for (int y = 0; y < ph; y++) memcpy (dst + (size_t) y * host->stride[p], src + (size_t) y * stride[p], wb);

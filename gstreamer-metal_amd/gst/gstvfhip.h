@@ -21,6 +21,14 @@ gboolean gst_vfhip_videofilter_register (GstPlugin * plugin);
 gboolean gst_vfhip_deinterlace_register (GstPlugin * plugin);
 gboolean gst_vfhip_compositor_register (GstPlugin * plugin);
 
+/* pinned host memory for GstBuffers (gstvfhipallocator.c) */
+GstAllocator *gst_vfhip_pinned_allocator_get (void);
+struct _GstBaseTransform;
+gboolean gst_vfhip_propose_allocation (struct _GstBaseTransform * trans, GstQuery * decide_query, GstQuery * query,
+    gboolean (*parent) (struct _GstBaseTransform *, GstQuery *, GstQuery *));
+gboolean gst_vfhip_decide_allocation (struct _GstBaseTransform * trans, GstQuery * query,
+    gboolean (*parent) (struct _GstBaseTransform *, GstQuery *));
+
 /* new, additive properties every vfhip element has */
 #define GST_VFHIP_DEFAULT_DEVICE_ID (-1)       /* -1: $VFHIP_DEVICE, else GPU 0 */
 

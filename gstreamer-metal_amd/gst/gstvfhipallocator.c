@@ -1,0 +1,144 @@
+/* gst/gstvfhipallocator.c — pinned host memory for GstBuffers.
+ *
+ * The reference copies every plane twice per element per frame on the CPU (upload into a shared texture,
+ * common/vfmetaltextureutil.m:108, and the read-back, common/vfmetalyuvoutput.m:138-176).  On a discrete GPU the
+ * equivalent copies are PCIe DMA; when the GstBuffer memory is pinned (hipHostMalloc), libvfhip DMAs planes straight
+ * from / into it (hipMemcpy2DAsync on the side streams) and the staging memcpy disappears.  The elements offer this
+ * allocator upstream (propose_allocation) and use it for their own output buffers (decide_allocation).
+ * When no HIP device is usable the allocator degrades to plain malloc'd memory (the elements then fail at the first
+ * frame with a proper error, not here). */
+#ifdef HAVE_CONFIG_H
+#include "config.h"
+#endif
+#include <gst/base/gstbasetransform.h>
+#include "gstvfhip.h"
+
+#define GST_CAT_DEFAULT gst_vfhip_debug
+#define VFHIP_PINNED_MEMORY_TYPE "VfHipPinnedMemory"
+
+typedef struct
+{
+  GstMemory mem;
+  gpointer data;
+  gboolean pinned;
+} VfHipPinnedMemory;
+
+typedef struct
+{
+  GstAllocator parent;
+} GstVfHipPinnedAllocator;
+typedef struct
+{
+  GstAllocatorClass parent_class;
+} GstVfHipPinnedAllocatorClass;
+
+G_DEFINE_TYPE (GstVfHipPinnedAllocator, gst_vfhip_pinned_allocator, GST_TYPE_ALLOCATOR);
+
+static GstMemory *
+pinned_alloc (GstAllocator * allocator, gsize size, GstAllocationParams * params)
+{
+  VfHipPinnedMemory *m = g_slice_new0 (VfHipPinnedMemory);
+  const gsize align = params->align | 63;                   /* at least 64-byte aligned rows for the DMA engine */
+  const gsize maxsize = size + params->prefix + params->padding + align;
+  gsize offset;
+  m->data = vfhip_pinned_alloc (-1, maxsize);
+  m->pinned = m->data != NULL;
+  if (!m->data) {
+    GST_INFO ("pinned allocation of %" G_GSIZE_FORMAT " bytes failed (%s): falling back to malloc", maxsize, vfhip_last_error_string ());
+    m->data = g_malloc (maxsize);
+  }
+  offset = params->prefix;
+  if (((guintptr) m->data + offset) & align)
+    offset += (align + 1) - (((guintptr) m->data + offset) & align);
+  gst_memory_init (GST_MEMORY_CAST (m), params->flags, allocator, NULL, maxsize, params->align, offset, size);
+  return GST_MEMORY_CAST (m);
+}
+
+static void
+pinned_free (GstAllocator * allocator, GstMemory * mem)
+{
+  VfHipPinnedMemory *m = (VfHipPinnedMemory *) mem;
+  (void) allocator;
+  if (m->pinned) vfhip_pinned_free (m->data);
+  else g_free (m->data);
+  g_slice_free (VfHipPinnedMemory, m);
+}
+
+static gpointer
+pinned_map (GstMemory * mem, gsize maxsize, GstMapFlags flags)
+{
+  (void) maxsize; (void) flags;
+  return ((VfHipPinnedMemory *) mem)->data;
+}
+
+static void
+pinned_unmap (GstMemory * mem)
+{
+  (void) mem;
+}
+
+static void
+gst_vfhip_pinned_allocator_class_init (GstVfHipPinnedAllocatorClass * klass)
+{
+  GST_ALLOCATOR_CLASS (klass)->alloc = pinned_alloc;
+  GST_ALLOCATOR_CLASS (klass)->free = pinned_free;
+}
+
+static void
+gst_vfhip_pinned_allocator_init (GstVfHipPinnedAllocator * self)
+{
+  GstAllocator *a = GST_ALLOCATOR_CAST (self);
+  a->mem_type = VFHIP_PINNED_MEMORY_TYPE;
+  a->mem_map = pinned_map;
+  a->mem_unmap = pinned_unmap;
+  /* mem_copy / mem_share / mem_is_span: the GstAllocator defaults (copy into system memory, no sub-memories) */
+  GST_OBJECT_FLAG_SET (self, GST_ALLOCATOR_FLAG_CUSTOM_ALLOC);
+}
+
+GstAllocator *
+gst_vfhip_pinned_allocator_get (void)
+{
+  static gsize once = 0;
+  static GstAllocator *alloc = NULL;
+  if (g_once_init_enter (&once)) {
+    alloc = g_object_new (gst_vfhip_pinned_allocator_get_type (), NULL);
+    gst_object_ref_sink (alloc);
+    g_once_init_leave (&once, 1);
+  }
+  return gst_object_ref (alloc);
+}
+
+/* GstBaseTransform::propose_allocation: offer the pinned allocator (and video meta: libvfhip honours strides) upstream */
+gboolean
+gst_vfhip_propose_allocation (GstBaseTransform * trans, GstQuery * decide_query, GstQuery * query,
+    gboolean (*parent) (GstBaseTransform *, GstQuery *, GstQuery *))
+{
+  if (!parent (trans, decide_query, query))
+    return FALSE;
+  if (decide_query != NULL) {                                 /* not in passthrough */
+    GstAllocator *a = gst_vfhip_pinned_allocator_get ();
+    GstAllocationParams params;
+    gst_allocation_params_init (&params);
+    params.align = 63;
+    gst_query_add_allocation_param (query, a, &params);
+    gst_query_add_allocation_meta (query, GST_VIDEO_META_API_TYPE, NULL);
+    gst_object_unref (a);
+  }
+  return TRUE;
+}
+
+/* GstBaseTransform::decide_allocation: our own output buffers come from the pinned allocator */
+gboolean
+gst_vfhip_decide_allocation (GstBaseTransform * trans, GstQuery * query, gboolean (*parent) (GstBaseTransform *, GstQuery *))
+{
+  GstAllocator *a = gst_vfhip_pinned_allocator_get ();
+  GstAllocationParams params;
+  gst_allocation_params_init (&params);
+  params.align = 63;
+  if (gst_query_get_n_allocation_params (query) > 0)
+    gst_query_set_nth_allocation_param (query, 0, a, &params);
+  else
+    gst_query_add_allocation_param (query, a, &params);
+  gst_object_unref (a);
+  return parent (trans, query);
+}

@@ -303,6 +303,19 @@ cs_finalize (GObject * object)
   G_OBJECT_CLASS (gst_vfhip_convertscale_parent_class)->finalize (object);
 }
 
+
+static gboolean
+co_propose_allocation (GstBaseTransform * trans, GstQuery * decide_query, GstQuery * query)
+{
+  return gst_vfhip_propose_allocation (trans, decide_query, query, GST_BASE_TRANSFORM_CLASS (gst_vfhip_convertscale_parent_class)->propose_allocation);
+}
+
+static gboolean
+co_decide_allocation (GstBaseTransform * trans, GstQuery * query)
+{
+  return gst_vfhip_decide_allocation (trans, query, GST_BASE_TRANSFORM_CLASS (gst_vfhip_convertscale_parent_class)->decide_allocation);
+}
+
 static void
 gst_vfhip_convertscale_class_init (GstVfHipConvertScaleClass * klass)
 {
@@ -312,6 +325,8 @@ gst_vfhip_convertscale_class_init (GstVfHipConvertScaleClass * klass)
   oc->set_property = cs_set_property;
   oc->get_property = cs_get_property;
   oc->finalize = cs_finalize;
+  bc->propose_allocation = GST_DEBUG_FUNCPTR (co_propose_allocation);
+  bc->decide_allocation = GST_DEBUG_FUNCPTR (co_decide_allocation);
   ec->change_state = GST_DEBUG_FUNCPTR (cs_change_state);
   bc->transform_caps = GST_DEBUG_FUNCPTR (cs_transform_caps);
   bc->fixate_caps = GST_DEBUG_FUNCPTR (cs_fixate_caps);

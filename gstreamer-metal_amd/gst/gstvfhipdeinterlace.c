@@ -165,6 +165,19 @@ di_finalize (GObject * object)
   G_OBJECT_CLASS (gst_vfhip_deinterlace_parent_class)->finalize (object);
 }
 
+
+static gboolean
+de_propose_allocation (GstBaseTransform * trans, GstQuery * decide_query, GstQuery * query)
+{
+  return gst_vfhip_propose_allocation (trans, decide_query, query, GST_BASE_TRANSFORM_CLASS (gst_vfhip_deinterlace_parent_class)->propose_allocation);
+}
+
+static gboolean
+de_decide_allocation (GstBaseTransform * trans, GstQuery * query)
+{
+  return gst_vfhip_decide_allocation (trans, query, GST_BASE_TRANSFORM_CLASS (gst_vfhip_deinterlace_parent_class)->decide_allocation);
+}
+
 static void
 gst_vfhip_deinterlace_class_init (GstVfHipDeinterlaceClass * klass)
 {
@@ -173,6 +186,8 @@ gst_vfhip_deinterlace_class_init (GstVfHipDeinterlaceClass * klass)
   oc->set_property = di_set_property;
   oc->get_property = di_get_property;
   oc->finalize = di_finalize;
+  GST_BASE_TRANSFORM_CLASS (klass)->propose_allocation = GST_DEBUG_FUNCPTR (de_propose_allocation);
+  GST_BASE_TRANSFORM_CLASS (klass)->decide_allocation = GST_DEBUG_FUNCPTR (de_decide_allocation);
   GST_BASE_TRANSFORM_CLASS (klass)->stop = GST_DEBUG_FUNCPTR (di_stop);
   GST_VIDEO_FILTER_CLASS (klass)->set_info = GST_DEBUG_FUNCPTR (di_set_info);
   GST_VIDEO_FILTER_CLASS (klass)->transform_frame = GST_DEBUG_FUNCPTR (di_transform_frame);

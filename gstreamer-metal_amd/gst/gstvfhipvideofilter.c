@@ -239,6 +239,19 @@ vf_finalize (GObject * object)
   g_object_class_install_property (oc, id, g_param_spec_double (name, nick, blurb, lo, hi, def, \
           G_PARAM_READWRITE | GST_PARAM_CONTROLLABLE | G_PARAM_STATIC_STRINGS))
 
+
+static gboolean
+vi_propose_allocation (GstBaseTransform * trans, GstQuery * decide_query, GstQuery * query)
+{
+  return gst_vfhip_propose_allocation (trans, decide_query, query, GST_BASE_TRANSFORM_CLASS (gst_vfhip_videofilter_parent_class)->propose_allocation);
+}
+
+static gboolean
+vi_decide_allocation (GstBaseTransform * trans, GstQuery * query)
+{
+  return gst_vfhip_decide_allocation (trans, query, GST_BASE_TRANSFORM_CLASS (gst_vfhip_videofilter_parent_class)->decide_allocation);
+}
+
 static void
 gst_vfhip_videofilter_class_init (GstVfHipVideoFilterClass * klass)
 {
@@ -249,6 +262,8 @@ gst_vfhip_videofilter_class_init (GstVfHipVideoFilterClass * klass)
   oc->set_property = vf_set_property;
   oc->get_property = vf_get_property;
   oc->finalize = vf_finalize;
+  bc->propose_allocation = GST_DEBUG_FUNCPTR (vi_propose_allocation);
+  bc->decide_allocation = GST_DEBUG_FUNCPTR (vi_decide_allocation);
   bc->start = GST_DEBUG_FUNCPTR (vf_start);
   bc->stop = GST_DEBUG_FUNCPTR (vf_stop);
   fc->set_info = GST_DEBUG_FUNCPTR (vf_set_info);

@@ -118,5 +118,41 @@ def main():
     cs.close()
 
 
+def e2e():
+    """element-level (PCIe-inclusive) rate of vfhip_convertscale_process on C2: pageable vs pinned host buffers"""
+    import ctypes as C
+    import time
+    import numpy as np
+    w, h, ow, oh = 3840, 2160, 1920, 1080
+    in_size, out_size = vfhip.plane_layout("NV12", w, h)[1], 4 * ow * oh
+    cs = vfhip.ConvertScale(0)
+    cs.configure("NV12", w, h, "BGRA", ow, oh, colorimetry="bt2020", chroma_site="mpeg2")
+    rng = np.random.default_rng(0)
+    for kind in ("pageable", "pinned"):
+        if kind == "pinned":
+            pi, po = vfhip.lib.vfhip_pinned_alloc(0, in_size), vfhip.lib.vfhip_pinned_alloc(0, out_size)
+            src = np.ctypeslib.as_array((C.c_uint8 * in_size).from_address(pi))
+            dst = np.ctypeslib.as_array((C.c_uint8 * out_size).from_address(po))
+        else:
+            src, dst = np.empty(in_size, np.uint8), np.empty(out_size, np.uint8)
+        src[:] = rng.integers(0, 256, in_size, dtype=np.uint8)
+        fi = vfhip.frame_from_base(cs.in_info, "NV12", w, h, src.ctypes.data)
+        fo = vfhip.frame_from_base(cs.out_info, "BGRA", ow, oh, dst.ctypes.data)
+        for _ in range(5):
+            vfhip.check(vfhip.lib.vfhip_convertscale_process(cs.h, C.byref(fi), C.byref(fo)))
+        n, t0 = 100, time.perf_counter()
+        for _ in range(n):
+            vfhip.check(vfhip.lib.vfhip_convertscale_process(cs.h, C.byref(fi), C.byref(fo)))
+        dt = time.perf_counter() - t0
+        print(json.dumps({"config": f"C2 end-to-end vfhip_convertscale_process, {kind} host frames (sync per frame)",
+                          "frames_per_s": round(n / dt, 1), "ms_per_frame": round(dt / n * 1e3, 3),
+                          "pcie_GBps": round((in_size + out_size) * n / dt / 1e9, 2)}), flush=True)
+    cs.close()
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "e2e":
+        e2e()
+    else:
+        main()
+        e2e()
