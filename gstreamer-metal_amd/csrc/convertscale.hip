@@ -44,7 +44,7 @@ struct VfHipConvertScale {
   int *d_vtab = nullptr, *d_htab = nullptr;
   int vfirst = 1, hscale_on = 0;
   uint32_t hinc = 0;
-  enum Kernel { K_NONE, K_HALF, K_GENERIC, K_METAL, K_STAGED } kernel = K_NONE;
+  enum Kernel { K_NONE, K_HALF, K_GENERIC, K_TAPS, K_METAL, K_STAGED } kernel = K_NONE;
   const char *kernel_name = "none";
   // K_STAGED: videoconvert at the input size into `mid` (when the format changes), then per-plane videoscale
   PlaneCfg plane[3];
@@ -268,7 +268,9 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
 
   const bool half = in->format == VFHIP_FORMAT_NV12 && method == VFHIP_SCALE_BILINEAR && !h->add_borders &&
                     in->width == 2 * out->width && in->height == 2 * out->height && (out->width % 4) == 0 && out->height >= 3;
+  const bool taps = in_yuv && method == VFHIP_SCALE_BILINEAR && in->width >= 8;
   if (half) { h->kernel = VfHipConvertScale::K_HALF; h->kernel_name = "k_cs_nv12_half"; }
+  else if (taps) { h->kernel = VfHipConvertScale::K_TAPS; h->kernel_name = "k_cs_taps"; }
   else { h->kernel = VfHipConvertScale::K_GENERIC; h->kernel_name = "k_cs_generic"; }
   h->configured = true;
   return VFHIP_OK;
@@ -402,7 +404,11 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
     else launch_half<4> (p, n_frames, s);
   } else {
     dim3 grid ((unsigned) ((p.out_w + 63) / 64), (unsigned) ((p.out_h + 3) / 4), (unsigned) n_frames);
-    hipLaunchKernelGGL (k_cs_generic, grid, dim3 (64, 4), 0, s, p);
+    // window loads need >= 2 luma columns and >= 4 chroma pairs per row; tiny frames and nearest / RGB inputs use k_cs_generic
+    const bool taps = h->kernel == VfHipConvertScale::K_TAPS && p.in_w >= 8;
+    if (taps && p.in_fmt == VFHIP_FORMAT_I420) hipLaunchKernelGGL (k_cs_taps<true>, grid, dim3 (64, 4), 0, s, p);
+    else if (taps) hipLaunchKernelGGL (k_cs_taps<false>, grid, dim3 (64, 4), 0, s, p);
+    else hipLaunchKernelGGL (k_cs_generic, grid, dim3 (64, 4), 0, s, p);
   }
   VFHIP_CHECK_HIP (hipGetLastError ());
   return VFHIP_OK;

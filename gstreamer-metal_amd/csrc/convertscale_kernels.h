@@ -263,6 +263,103 @@ __global__ __launch_bounds__ (256, 8) void k_cs_nv12_half (const CsParams p)
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_cs_taps<I420>: NV12 / I420 -> BGRA / RGBA, 2-tap bilinear at ANY ratio (BASELINE configs[0], 1080p -> 720p, up-scales ...)
+// ------------------------------------------------------------------------------------------------
+// One output pixel per lane.  Its 2x2 taps are two ADJACENT source columns (xa, xa+1) on two source rows, so per
+// source row everything the pixel needs is one 2-byte luma window and, per chroma row, one 8-byte window of four
+// [U V] pairs (columns k-1 .. k+2): 6 loads per pixel instead of 36 byte gathers.  v_perm_b32 with a per-lane selector
+// pulls the pairs out of the window; from there the arithmetic is the packed-byte ORC pipeline of the fast path
+// (orc_pair on the [xa, xa+1] pair), then the two taps in either pass order with GStreamer's 8-bit weights.
+typedef uint2 __attribute__ ((aligned (2))) uint2_a2;
+typedef uint16_t __attribute__ ((aligned (1))) uint16_a1;
+
+template <bool I420>
+__global__ __launch_bounds__ (256) void k_cs_taps (const CsParams p)
+{
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= p.out_w || y >= p.out_h) return;
+  const uint8_t *yp = p.in[0] + (size_t) blockIdx.z * p.in_pitch;
+  const uint8_t *up = p.in[1] + (size_t) blockIdx.z * p.in_pitch;
+  const uint8_t *vp = I420 ? p.in[2] + (size_t) blockIdx.z * p.in_pitch : nullptr;
+  uint32_t *o = reinterpret_cast<uint32_t *> (p.out + (size_t) blockIdx.z * p.out_pitch + (size_t) y * p.os) + x;
+  const int dx = x - p.rx, dy = y - p.ry;
+  if (dx < 0 || dy < 0 || dx >= p.rw || dy >= p.rh) { *o = p.border; return; }
+  const int i0 = p.vtab[4 * dy], i1 = p.vtab[4 * dy + 1], w = p.vtab[4 * dy + 2];
+  int xa = dx, xb = dx, f = 0;
+  if (p.hscale_on) {
+    const uint32_t t = (uint32_t) dx * p.hinc;
+    xa = (int) (t >> 16); f = (int) ((t >> 8) & 0xff); xb = min (xa + 1, p.in_w - 1);
+  }
+  const int cw = (p.in_w + 1) >> 1, chh = (p.in_h + 1) >> 1;
+  const uint32_t X = 0x80808080u, K1 = 0x01010101u;
+  const int bias = 128 << 16;
+
+  // luma window: 2 bytes at ybase, per-lane selector -> [ya ya yb yb]
+  const int ybase = min (xa, p.in_w - 2);
+  const uint32_t oa = (uint32_t) (xa - ybase), ob = (uint32_t) (xb - ybase);
+  const uint32_t sely = (oa * 0x0101u) | ((ob * 0x0101u) << 16);
+
+  uint32_t sel_c = 0, sel_n = 0;
+  int cbase = 0;
+  const int ka = xa >> 1, kb = xb >> 1;
+  if (!I420) {
+    // chroma window: 8 bytes = pairs cbase .. cbase+3; selectors for [P(k_a) | P(k_b)] and their horizontal neighbours
+    const int kna = (xa & 1) ? min (ka + 1, cw - 1) : (p.cosited ? ka : max (ka - 1, 0));
+    const int knb = (xb & 1) ? min (kb + 1, cw - 1) : (p.cosited ? kb : max (kb - 1, 0));
+    cbase = max (min (ka - 1, cw - 4), 0);
+    const uint32_t fa = (uint32_t) (ka - cbase), fb = (uint32_t) (kb - cbase), ga = (uint32_t) (kna - cbase), gb = (uint32_t) (knb - cbase);
+    sel_c = (fa * 0x0202u + 0x0100u) | ((fb * 0x0202u + 0x0100u) << 16);
+    sel_n = (ga * 0x0202u + 0x0100u) | ((gb * 0x0202u + 0x0100u) << 16);
+  }
+
+  uint32_t bb[2], gg[2], rr[2];
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    const int r = t ? i1 : i0;
+    const int j = r >> 1;
+    uint32_t uv;                                        // [U(xa) V(xa) U(xb) V(xb)], already ^0x80
+    if (I420) {                                         // GStreamer's I420 fast path: nearest-replicated chroma
+      const uint32_t ua = up[(size_t) j * p.is[1] + ka], ub = up[(size_t) j * p.is[1] + kb];
+      const uint32_t va = vp[(size_t) j * p.is[2] + ka], vb = vp[(size_t) j * p.is[2] + kb];
+      uv = (ua | (va << 8) | (ub << 16) | (vb << 24)) ^ X;
+    } else {
+      const int jn = (r & 1) ? min (j + 1, chh - 1) : max (j - 1, 0);
+      const uint2 w0 = *reinterpret_cast<const uint2_a2 *> (up + (size_t) j * p.is[1] + 2 * cbase);
+      const uint2 w1 = *reinterpret_cast<const uint2_a2 *> (up + (size_t) jn * p.is[1] + 2 * cbase);
+      const uint32_t a0 = perm_b32 (w0.y, w0.x, sel_c), n0 = perm_b32 (w0.y, w0.x, sel_n);
+      const uint32_t a1 = perm_b32 (w1.y, w1.x, sel_c), n1 = perm_b32 (w1.y, w1.x, sel_n);
+      // horizontal first: co-sited even columns have n == a, so (a+n+1)>>1 == a; then vertical (3a+b+2)>>2
+      const uint32_t h0 = p.cosited ? lerp_u8 (a0, n0, K1) : filt31_u8 (a0, n0);
+      const uint32_t h1 = p.cosited ? lerp_u8 (a1, n1, K1) : filt31_u8 (a1, n1);
+      uv = filt31_u8 (h0, h1) ^ X;
+    }
+    const uint32_t yw = (uint32_t) *reinterpret_cast<const uint16_a1 *> (yp + (size_t) r * p.is[0] + ybase) ^ 0x8080u;
+    orc_pair (perm_b32 (0u, yw, sely), perm_b32 (0u, uv, 0x01010000u), perm_b32 (0u, uv, 0x03030202u), p.c, bias, bb[t], gg[t], rr[t]);
+  }
+
+  // the two taps.  [a, b] byte pairs -> u16 lanes; vertical: (r0*(256-w) + r1*w + 128)>>8 ; horizontal: (a*(256-f) + b*f)>>8
+  const uint32_t ww = (uint32_t) w | ((uint32_t) w << 16), wm = 0x01000100u - ww;
+  const uint32_t fw = (uint32_t) (256 - f) | ((uint32_t) f << 16);
+  uint32_t ch[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const uint32_t q0 = c == 0 ? bb[0] : (c == 1 ? gg[0] : rr[0]), q1 = c == 0 ? bb[1] : (c == 1 ? gg[1] : rr[1]);
+    const u16x2 e0 = as_u16x2 (perm_b32 (0u, q0, 0x0c010c00u)), e1 = as_u16x2 (perm_b32 (0u, q1, 0x0c010c00u));   // [a | b]
+    if (p.vfirst || !p.hscale_on) {
+      u16x2 t = e0 * as_u16x2 (wm) + as_u16x2 (0x00800080u);
+      t = e1 * as_u16x2 (ww) + t;
+      const uint32_t v = (as_u32 (t) >> 8) & 0x00ff00ffu;                    // [va | vb]
+      ch[c] = p.hscale_on ? (__builtin_amdgcn_udot2 (as_u16x2 (v), as_u16x2 (fw), 0u, false) >> 8) : (v & 0xffu);
+    } else {
+      const int h0 = (int) (__builtin_amdgcn_udot2 (e0, as_u16x2 (fw), 0u, false) >> 8);
+      const int h1 = (int) (__builtin_amdgcn_udot2 (e1, as_u16x2 (fw), 0u, false) >> 8);
+      ch[c] = (uint32_t) (h0 + (((h1 - h0) * w + 128) >> 8));
+    }
+  }
+  *o = p.out_rgba ? (ch[2] | (ch[1] << 8) | (ch[0] << 16) | 0xff000000u) : (ch[0] | (ch[1] << 8) | (ch[2] << 16) | 0xff000000u);
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_cs_generic: one output pixel per thread, 4 converted taps
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int clampi (int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
