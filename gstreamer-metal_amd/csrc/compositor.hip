@@ -53,9 +53,16 @@ __device__ __forceinline__ uint32_t comp_pixel (const CompParams &p, int x, int 
     const CompLayer &L = p.layer[k];
     // a pixel is covered when its centre lies inside the quad [xpos, xpos+width) x [ypos, ypos+height)
     if (x < L.xpos || x >= L.xpos + L.width || y < L.ypos || y >= L.ypos + L.height) continue;
-    const float tu = (((float) x + 0.5f) - (float) L.xpos) / (float) L.width;
-    const float tv = (((float) y + 0.5f) - (float) L.ypos) / (float) L.height;
-    F4 s = metal::sample_rgba (L.img, tu, tv, true);
+    F4 s;
+    if (L.width == L.img.w && L.height == L.img.h) {
+      // unscaled pad: texel centres are sampled, the linear sampler returns the exact texel (SURVEY.md Appendix B
+      // item 2); 4:2:0 chroma still interpolates at its .25/.75 phases.  One dword load instead of 16 byte taps.
+      s = metal::fetch_1to1 (L.img, x - L.xpos, y - L.ypos, true);
+    } else {
+      const float tu = (((float) x + 0.5f) - (float) L.xpos) / (float) L.width;
+      const float tv = (((float) y + 0.5f) - (float) L.ypos) / (float) L.height;
+      s = metal::sample_rgba (L.img, tu, tv, true);
+    }
     s.a *= L.alpha; s.r *= s.a; s.g *= s.a; s.b *= s.a;            // premultiply (compositorFragment, :58-59)
     const F4 d = metal::unpack_rgba8 (q);
     F4 o;

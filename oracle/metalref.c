@@ -486,7 +486,10 @@ int metalref_compositor (const MrPad *pads, int n, int background, const MrImg *
       for (int x = x0; x < x1; x++) {
         const float tu = (((float) x + 0.5f) - (float) pd->xpos) / (float) pd->width;
         const float tv = (((float) y + 0.5f) - (float) pd->ypos) / (float) pd->height;
-        F4 s = sample_rgba (&pd->img, tu, tv, 1);
+        /* an unscaled pad samples texel centres: the linear sampler returns the exact texel (Appendix B item 2),
+         * 4:2:0 chroma still interpolates at its .25/.75 phases */
+        const int unscaled = pd->width == pd->img.w && pd->height == pd->img.h;
+        F4 s = unscaled ? fetch_1to1 (&pd->img, x - pd->xpos, y - pd->ypos, 1) : sample_rgba (&pd->img, tu, tv, 1);
         s.a *= alpha; s.r *= s.a; s.g *= s.a; s.b *= s.a;
         const F4 d = unpack_rgba8 (q[(size_t) y * w + x]);
         F4 o;
