@@ -6,15 +6,20 @@
 //   gst-exact : the integer arithmetic of GStreamer 1.14 videoconvert+videoscale (bit-exact; oracle/gst114.c)
 //   metal     : the float arithmetic of the reference shaders (convertscale_metal_kernels.h)
 //
-// Kernels in this file (all HBM-bound streaming kernels, no MFMA — there is no contraction):
-//   k_cs_nv12_half   : NV12 -> BGRA/RGBA at exactly 2:1 in both axes, bilinear (the BASELINE headline
-//                      2160p -> 1080p).  Each lane owns 4 adjacent output pixels (one 16-byte store per
-//                      row) and slides down a strip of ROWS output rows, keeping the horizontally
-//                      up-sampled chroma rows j-1, j in registers, so every input byte is loaded once.
-//                      Packed-byte ALU: v_lerp_u8 for the (a+b+1)>>1 / (3a+b+2)>>2 chroma filters and the
-//                      w=128 vertical tap, v_mad_i32_i16 with op_sel for the ORC mulhs matrix,
-//                      v_sat_pk_u8_i16 for the clamps, v_pk_mad_u16 for the horizontal taps.
-//   k_cs_generic     : any size / method / {NV12,I420,BGRA,RGBA} -> {BGRA,RGBA}; 4 taps per output pixel.
+// Kernels in this file (streaming per-pixel kernels, no MFMA — there is no contraction; roofline = HBM):
+//   k_cs_nv12_half : NV12 -> BGRA/RGBA at exactly 2:1 in both axes, bilinear (the BASELINE headline 2160p -> 1080p).
+//                    Each lane owns 4 adjacent output pixels (one 16-byte store per row) and slides down a strip of
+//                    ROWS output rows two rows per trip, keeping the horizontally up-sampled chroma row and the
+//                    floor-average with its predecessor in registers, so every input byte is loaded once; the loads
+//                    of the next row are issued before the current row is computed (register double buffer).
+//                    Packed-byte ALU: v_lerp_u8 for (a+b+1)>>1 / (3a+b+2)>>2 and the w=128 vertical tap,
+//                    v_mad_i32_i16 (op_sel) for the ORC mulhs matrix, v_sat_pk_u8_i16 for the clamps on planar
+//                    [even, odd] byte pairs, v_dot4_u32_u8 for the horizontal tap.  DESIGN.md §5.1.
+//   k_cs_taps      : NV12 / I420 -> BGRA/RGBA, bilinear at any ratio: one output pixel per lane, window loads +
+//                    per-lane v_perm selectors, the same packed ORC pipeline.
+//   k_cs_generic   : everything else that is gst-exact with an RGB output (RGB inputs, nearest, tiny frames):
+//                    scalar, one output pixel per lane, 4 converted taps.
+// 4:2:0 outputs: convertscale_planar_kernels.h; `metal` numerics: convertscale_metal_kernels.h.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -64,38 +69,9 @@ __device__ __forceinline__ uint32_t sat_pk_u8_i16 (uint32_t v)
   return d;
 }
 
-// ORC video_orc_convert_AYUV_ARGB on one pixel.  `ys`: two byte-splatted int16 luma samples (already ^0x80),
-// YHI picks the half; `uvs`: [U U V V] (already ^0x80).  Returns the packed BGRA/RGBA pixel, alpha 255.
-template <int YHI, bool RGBA>
-__device__ __forceinline__ uint32_t orc_pixel (uint32_t ys, uint32_t uvs, int c0, int c1, int c2, int c3, int c4, int bias)
-{
-  // wy = mulhs(splat(Y), p1) kept in the high half, with +128 folded in; low half cleared so that later
-  // products floor independently (mulhs(a)+mulhs(b) != mulhs(a+b)).
-  int wy = mad_i32_i16<YHI> (ys, c0, bias) & (int) 0xffff0000;
-  int tr = mad_i32_i16<1> (uvs, c1, wy);                                  // + mulhs(splat(V), p2)
-  int tb = mad_i32_i16<0> (uvs, c2, wy);                                  // + mulhs(splat(U), p3)
-  int tg = mad_i32_i16<1> (uvs, c4, mad_i32_i16<0> (uvs, c3, wy) & (int) 0xffff0000);
-  uint32_t lo, hi;
-  if (RGBA) { lo = perm_b32 ((uint32_t) tg, (uint32_t) tr, 0x07060302u); hi = perm_b32 (0u, (uint32_t) tb, 0x0c0d0302u); }
-  else      { lo = perm_b32 ((uint32_t) tg, (uint32_t) tb, 0x07060302u); hi = perm_b32 (0u, (uint32_t) tr, 0x0c0d0302u); }
-  // lo = [X.hi16 | G.hi16 << 16], hi = [Z.hi16 | 0x00ff << 16]; saturate each int16 to u8 and pack
-  return (sat_pk_u8_i16 (lo) & 0xffffu) | (sat_pk_u8_i16 (hi) << 16);
-}
-
 typedef unsigned short u16x2 __attribute__ ((ext_vector_type (2)));
 __device__ __forceinline__ u16x2 as_u16x2 (uint32_t v) { return __builtin_bit_cast (u16x2, v); }
 __device__ __forceinline__ uint32_t as_u32 (u16x2 v) { return __builtin_bit_cast (uint32_t, v); }
-
-// (a*(256-f) + b*f) >> 8 on the 4 bytes of two packed pixels; f2/wf2 = f and 256-f replicated in both halves
-__device__ __forceinline__ uint32_t hlerp_px (uint32_t a, uint32_t b, uint32_t f2, uint32_t wf2)
-{
-  u16x2 a02 = as_u16x2 (a & 0x00ff00ffu), a13 = as_u16x2 (perm_b32 (0u, a, 0x0c030c01u));
-  u16x2 b02 = as_u16x2 (b & 0x00ff00ffu), b13 = as_u16x2 (perm_b32 (0u, b, 0x0c030c01u));
-  u16x2 f = as_u16x2 (f2), wf = as_u16x2 (wf2);
-  u16x2 t02 = a02 * wf + b02 * f;
-  u16x2 t13 = a13 * wf + b13 * f;
-  return perm_b32 (as_u32 (t13), as_u32 (t02), 0x07030501u);
-}
 
 // ------------------------------------------------------------------------------------------------
 // k_cs_nv12_half

@@ -21,6 +21,7 @@ plugin_init (GstPlugin * plugin)
   ok &= gst_vfhip_videofilter_register (plugin);
   ok &= gst_vfhip_deinterlace_register (plugin);
   ok &= gst_vfhip_compositor_register (plugin);
+  ok &= gst_vfhip_transform_register (plugin);
   return ok;
 }
 

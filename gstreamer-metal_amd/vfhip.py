@@ -51,7 +51,7 @@ def _load():
     lib = C.CDLL(LIB_PATH)
     lib.vfhip_last_error_string.restype = C.c_char_p
     for n in ("vfhip_pinned_alloc", "vfhip_device_malloc", "vfhip_convertscale_new", "vfhip_deinterlace_new",
-              "vfhip_videofilter_new", "vfhip_compositor_new"):
+              "vfhip_videofilter_new", "vfhip_compositor_new", "vfhip_transform_new"):
         getattr(lib, n).restype = C.c_void_p
     lib.vfhip_convertscale_kernel_name.restype = C.c_char_p
     lib.vfhip_pinned_alloc.argtypes = [C.c_int, C.c_size_t]
@@ -79,6 +79,11 @@ def _load():
     lib.vfhip_compositor_configure.argtypes = [C.c_void_p, C.POINTER(VideoInfo)]
     lib.vfhip_compositor_composite.argtypes = [C.c_void_p, C.POINTER(PadInput), C.c_int, C.c_int, C.POINTER(Frame)]
     lib.vfhip_compositor_composite_device.argtypes = [C.c_void_p, C.POINTER(PadInput), C.c_int, C.c_int, C.POINTER(Frame), C.c_void_p]
+    lib.vfhip_transform_configure.argtypes = [C.c_void_p, C.POINTER(VideoInfo), C.POINTER(VideoInfo)]
+    lib.vfhip_transform_process.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(Frame), C.POINTER(TransformParams)]
+    lib.vfhip_transform_process_device.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(Frame), C.POINTER(TransformParams), C.c_void_p]
+    lib.vfhip_transform_cleanup.argtypes = [C.c_void_p]
+    lib.vfhip_transform_free.argtypes = [C.c_void_p]
     for n in ("vfhip_deinterlace_reset", "vfhip_deinterlace_cleanup", "vfhip_deinterlace_free", "vfhip_videofilter_clear_lut",
               "vfhip_videofilter_lut_size", "vfhip_videofilter_cleanup", "vfhip_videofilter_free", "vfhip_compositor_cleanup",
               "vfhip_compositor_free"):
@@ -96,6 +101,11 @@ class VideoFilterParams(C.Structure):
                 ("vignette", C.c_float), ("invert", C.c_int32), ("chroma_key_enabled", C.c_int32),
                 ("chroma_key_r", C.c_float), ("chroma_key_g", C.c_float), ("chroma_key_b", C.c_float),
                 ("chroma_key_tolerance", C.c_float), ("chroma_key_smoothness", C.c_float), ("frame_index", C.c_uint32)]
+
+
+class TransformParams(C.Structure):
+    _fields_ = [("method", C.c_int32), ("crop_top", C.c_int32), ("crop_bottom", C.c_int32), ("crop_left", C.c_int32),
+                ("crop_right", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class PadInput(C.Structure):
@@ -370,3 +380,34 @@ class Compositor(_Element):
         arr = (PadInput * max(len(pad_structs), 1))(*pad_structs)
         fo = frame_from_base(self.info, self.fmt, self.w, self.hh, out_ptr)
         check(lib.vfhip_compositor_composite_device(self.h, arr, len(pad_structs), BACKGROUNDS[background], C.byref(fo), stream))
+
+
+TRANSFORM_METHODS = {"none": 0, "clockwise": 1, "rotate-180": 2, "counterclockwise": 3, "horizontal-flip": 4, "vertical-flip": 5,
+                     "upper-left-diagonal": 6, "upper-right-diagonal": 7}
+
+
+class Transform(_Element):
+    """MetalTransformRenderer equivalent (reference transform/metaltransformrenderer.h)."""
+    _free = "vfhip_transform_free"
+
+    def __init__(self, device=-1):
+        self.h = lib.vfhip_transform_new(device)
+        if not self.h:
+            raise VfHipError(-6, lib.vfhip_last_error_string().decode(errors="replace"))
+
+    def configure(self, in_fmt, w, h, out_fmt=None, colorimetry="bt601"):
+        self.in_fmt, self.out_fmt, self.w, self.hh = in_fmt, out_fmt or in_fmt, w, h
+        self.in_info = make_info(in_fmt, w, h, colorimetry)
+        self.out_info = make_info(self.out_fmt, w, h, colorimetry)
+        check(lib.vfhip_transform_configure(self.h, C.byref(self.in_info), C.byref(self.out_info)))
+        return self
+
+    def process(self, raw_in, method="none", crop=(0, 0, 0, 0)):
+        """crop = (top, bottom, left, right)"""
+        raw_in = np.ascontiguousarray(raw_in, dtype=np.uint8)
+        out = np.zeros(plane_layout(self.out_fmt, self.w, self.hh)[1], np.uint8)
+        fi = frame_from_base(self.in_info, self.in_fmt, self.w, self.hh, raw_in.ctypes.data)
+        fo = frame_from_base(self.out_info, self.out_fmt, self.w, self.hh, out.ctypes.data)
+        prm = TransformParams(TRANSFORM_METHODS[method], *crop)
+        check(lib.vfhip_transform_process(self.h, C.byref(fi), C.byref(fo), C.byref(prm)))
+        return out

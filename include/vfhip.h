@@ -216,6 +216,34 @@ int vfhip_compositor_composite_device (VfHipCompositor *h, const VfHipPadInput *
 void vfhip_compositor_cleanup (VfHipCompositor *h);
 void vfhip_compositor_free (VfHipCompositor *h);
 
+/* ---- transform: flip / rotate / crop (reference: MetalTransformRenderer, transform/metaltransformrenderer.{h,m}) --
+ * SURVEY.md §8f "next" item 2.  Output size == input size (the element is a GstVideoFilter with identical caps). */
+typedef enum {
+  VFHIP_TRANSFORM_IDENTITY = 0,   /* nick "none"                 (transform/gstvfmetaltransform.m:84-91) */
+  VFHIP_TRANSFORM_90R = 1,        /* "clockwise" */
+  VFHIP_TRANSFORM_180 = 2,        /* "rotate-180" */
+  VFHIP_TRANSFORM_90L = 3,        /* "counterclockwise" */
+  VFHIP_TRANSFORM_HORIZ = 4,      /* "horizontal-flip" */
+  VFHIP_TRANSFORM_VERT = 5,       /* "vertical-flip" */
+  VFHIP_TRANSFORM_UL_LR = 6,      /* "upper-left-diagonal" */
+  VFHIP_TRANSFORM_UR_LL = 7       /* "upper-right-diagonal" */
+} VfHipTransformMethod;
+
+typedef struct {                  /* TransformParams */
+  int32_t method;
+  int32_t crop_top, crop_bottom, crop_left, crop_right;
+  int32_t reserved[3];
+} VfHipTransformParams;
+
+typedef struct VfHipTransform VfHipTransform;
+VfHipTransform *vfhip_transform_new (int device);
+int vfhip_transform_configure (VfHipTransform *h, const VfHipVideoInfo *in, const VfHipVideoInfo *out);
+int vfhip_transform_process (VfHipTransform *h, const VfHipFrame *in, VfHipFrame *out, const VfHipTransformParams *params);
+int vfhip_transform_process_device (VfHipTransform *h, const VfHipFrame *in, VfHipFrame *out,
+    const VfHipTransformParams *params, void *stream);
+void vfhip_transform_cleanup (VfHipTransform *h);
+void vfhip_transform_free (VfHipTransform *h);
+
 #ifdef __cplusplus
 }
 #endif

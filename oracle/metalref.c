@@ -503,3 +503,40 @@ int metalref_compositor (const MrPad *pads, int n, int background, const MrImg *
   free (q);
   return 0;
 }
+
+/* ---- transform ---------------------------------------------------------------------------------------- */
+/* UV matrix of the eight methods, column-major [m00 m10 m01 m11] (transform/metaltransformrenderer.m:44-104) */
+static void transform_matrix (int method, float m[4])
+{
+  static const float T[8][4] = {
+    {  1,  0,  0,  1 }, {  0, -1,  1,  0 }, { -1,  0,  0, -1 }, {  0,  1, -1,  0 },
+    { -1,  0,  0,  1 }, {  1,  0,  0, -1 }, {  0,  1,  1,  0 }, {  0, -1, -1,  0 },
+  };
+  for (int k = 0; k < 4; k++) m[k] = T[method & 7][k];
+}
+
+int metalref_transform (const MrImg *in, const MrImg *out, int method, int crop_top, int crop_bottom, int crop_left, int crop_right)
+{
+  const int w = out->w, h = out->h;
+  uint32_t *q = malloc ((size_t) w * h * 4);
+  if (!q) return -2;
+  /* crop folded into the UV transform (metaltransformrenderer.m:265-293) */
+  const float cl = (float) crop_left / (float) in->w, cr = (float) crop_right / (float) in->w;
+  const float ct = (float) crop_top / (float) in->h, cb = (float) crop_bottom / (float) in->h;
+  const float sx = 1.0f - cl - cr, sy = 1.0f - ct - cb, ox = (cl - cr) * 0.5f, oy = (ct - cb) * 0.5f;
+  float t[4]; transform_matrix (method, t);
+  const float m0 = t[0] * sx, m1 = t[1] * sx, m2 = t[2] * sy, m3 = t[3] * sy;
+  const float offx = t[0] * ox + t[2] * oy + 0.0f, offy = t[1] * ox + t[3] * oy + 0.0f;
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      float tx = ((float) x + 0.5f) / (float) w, ty = ((float) y + 0.5f) / (float) h;
+      tx -= 0.5f; ty -= 0.5f;
+      const float ux = m0 * tx + m2 * ty, uy = m1 * tx + m3 * ty;
+      tx = ux + (0.5f + offx); ty = uy + (0.5f + offy);
+      if (tx < 0.0f || tx > 1.0f || ty < 0.0f || ty > 1.0f) q[(size_t) y * w + x] = 0xff000000u;   /* opaque black (:72-74) */
+      else q[(size_t) y * w + x] = quant_rgba8 (sample_rgba (in, tx, ty, 1));
+    }
+  store_image (out, q);
+  free (q);
+  return 0;
+}

@@ -42,6 +42,9 @@ typedef struct {
 } MrPad;
 int metalref_compositor (const MrPad *pads, int n, int background, const MrImg *out);
 
+/* transform (transform/metaltransform_shaders.h:40-120, metaltransformrenderer.m:44-104,265-293) */
+int metalref_transform (const MrImg *in, const MrImg *out, int method, int crop_top, int crop_bottom, int crop_left, int crop_right);
+
 #ifdef __cplusplus
 }
 #endif

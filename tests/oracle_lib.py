@@ -243,10 +243,21 @@ class MetalRef:
         return out
 
 
+def _mr_transform(self, in_fmt, w, h, raw, out_fmt, method, crop=(0, 0, 0, 0), m709=False):
+    raw = np.ascontiguousarray(raw, np.uint8)
+    out = np.zeros(raw_layout(out_fmt, w, h)[1], np.uint8)
+    i, o = mr_img(in_fmt, w, h, raw, m709), mr_img(out_fmt, w, h, out, m709)
+    assert self.lib.metalref_transform(C.byref(i), C.byref(o), method, *crop) == 0
+    return out
+
+
+MetalRef.transform = _mr_transform
+
+
 def load_metalref():
     build()
     lib = C.CDLL(LIB)
-    for n in ("metalref_convertscale", "metalref_deinterlace", "metalref_videofilter", "metalref_compositor"):
+    for n in ("metalref_convertscale", "metalref_deinterlace", "metalref_videofilter", "metalref_compositor", "metalref_transform"):
         getattr(lib, n).restype = C.c_int
     return MetalRef(lib)
 

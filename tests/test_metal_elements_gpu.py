@@ -297,6 +297,37 @@ def test_compositor_c4_config(vfhip, metalref):
     comp.close()
 
 
+@pytest.mark.parametrize("method", ["none", "clockwise", "rotate-180", "counterclockwise", "horizontal-flip", "vertical-flip",
+                                    "upper-left-diagonal", "upper-right-diagonal"])
+@pytest.mark.parametrize("fmt", ["BGRA", "NV12", "I420", "RGBA"])
+def test_transform_methods(vfhip, metalref, method, fmt):
+    """8 methods x 4 formats x crop (reference tests/test-transform.sh shapes), incl. odd sizes"""
+    for (w, h, crop) in [(64, 48, (0, 0, 0, 0)), (61, 35, (3, 5, 7, 2)), (48, 48, (0, 8, 0, 0))]:
+        raw = smooth(fmt, w, h, 50)
+        t = vfhip.Transform(0)
+        t.configure(fmt, w, h, colorimetry="bt709")
+        got = t.process(raw, method=method, crop=crop)
+        want = metalref.transform(fmt, w, h, raw, fmt, vfhip.TRANSFORM_METHODS[method], crop, m709=True)
+        close(got, want, f"transform {method} {fmt} {w}x{h} crop {crop}")
+        t.close()
+
+
+def test_transform_exact_flips(vfhip):
+    """square RGBA frame: the flips / rotations are pure pixel permutations (texel centres map onto texel centres)"""
+    w = h = 32
+    raw = rnd("RGBA", w, h, 51)
+    img = raw.reshape(h, w, 4)
+    t = vfhip.Transform(0)
+    t.configure("RGBA", w, h)
+    exp = {"none": img, "horizontal-flip": img[:, ::-1], "vertical-flip": img[::-1], "rotate-180": img[::-1, ::-1],
+           "upper-left-diagonal": img.transpose(1, 0, 2), "clockwise": img.transpose(1, 0, 2)[:, ::-1],
+           "counterclockwise": img.transpose(1, 0, 2)[::-1]}
+    for m, e in exp.items():
+        got = t.process(raw, method=m).reshape(h, w, 4)
+        assert np.abs(got.astype(int) - e.astype(int)).max() <= 1, m
+    t.close()
+
+
 def test_metal_element_errors(vfhip):
     import ctypes as C
     d = vfhip.Deinterlace(0)

@@ -104,3 +104,17 @@ def test_compositor_properties(metalref):
     assert (part[0, 0] == 255).all() and (part[3, 8] == 255).all() and not (part[4:12, 8:24] == 255).all()
     half = metalref.compositor("RGBA", w, h, [("RGBA", w, h, np.full_like(src, 255), 0, 0, w, h, 0.5, 1)], 1).reshape(-1, 4)
     assert (np.abs(half[:, :3].astype(int) - 128) <= 1).all() and (half[:, 3] == 255).all()     # 0.5*1 + 0*(1-.5); alpha .5 + 1*.5
+
+
+def test_transform_properties(metalref):
+    w = h = 16
+    raw = rnd("RGBA", w, h, 9)
+    img = raw.reshape(h, w, 4).astype(int)
+    ident = metalref.transform("RGBA", w, h, raw, "RGBA", 0).reshape(h, w, 4).astype(int)
+    assert np.abs(ident - img).max() <= 1                                   # texel centres: linear sampler ~ exact texel
+    hf = metalref.transform("RGBA", w, h, raw, "RGBA", 4).reshape(h, w, 4).astype(int)
+    assert np.abs(hf - img[:, ::-1]).max() <= 1
+    r180 = metalref.transform("RGBA", w, h, raw, "RGBA", 2).reshape(h, w, 4).astype(int)
+    assert np.abs(r180 - img[::-1, ::-1]).max() <= 1
+    crop = metalref.transform("RGBA", w, h, np.full_like(raw, 200), "RGBA", 0, (4, 4, 4, 4))
+    assert (crop == 200).all()                                               # cropping a constant frame zooms, never leaves the image
