@@ -83,9 +83,15 @@ def test_deinterlace_field_layout_and_1080p():
     ok(f"{SRC} ! {caps('BGRA', 321, 241)} ! vfhipdeinterlace method=weave ! fakesink")
 
 
+@pytest.mark.parametrize("method", ["clockwise", "rotate-180", "counterclockwise", "horizontal-flip", "vertical-flip", "upper-left-diagonal", "upper-right-diagonal", "none"])
+def test_transform_methods(method):
+    ok(f"{SRC} ! {caps('BGRA', 320, 240)} ! vfhiptransform method={method} ! fakesink")
+    ok(f"{SRC} ! {caps('NV12', 320, 240)} ! vfhiptransform method={method} crop-top=10 crop-left=20 ! fakesink")
+
+
 def test_multi_element_chains():
     """several renderers (each with its own stream trio) in one process (reference tests/test-multi-element.sh:2-4)"""
-    ok(f"{SRC} ! {caps('NV12', 640, 480)} ! vfhipdeinterlace method=greedyh ! vfhipconvertscale ! {caps('BGRA', 320, 240)} ! vfhipvideofilter brightness=0.1 sepia=0.5 ! fakesink")
+    ok(f"{SRC} ! {caps('NV12', 640, 480)} ! vfhipdeinterlace method=greedyh ! vfhipconvertscale ! {caps('BGRA', 320, 240)} ! vfhipvideofilter brightness=0.1 sepia=0.5 ! vfhiptransform method=horizontal-flip ! fakesink")
     ok(f"{SRC} ! {caps('BGRA', 640, 480)} ! tee name=t t. ! queue ! vfhipconvertscale ! {caps('NV12', 320, 240)} ! fakesink "
        f"t. ! queue ! vfhipvideofilter invert=true ! vfhipconvertscale ! {caps('I420', 160, 120)} ! fakesink")
 

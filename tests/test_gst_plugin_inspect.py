@@ -23,7 +23,7 @@ def squeeze(text):
 def test_plugin_registers_elements():
     r = gst_env.inspect("vfhip")
     assert r.returncode == 0, r.stdout + r.stderr
-    for e in ("vfhipconvertscale", "vfhipvideofilter", "vfhipdeinterlace"):
+    for e in ("vfhipconvertscale", "vfhipvideofilter", "vfhipdeinterlace", "vfhiptransform"):
         assert e in r.stdout
     # vfhipcompositor needs GstVideoAggregator (gst-plugins-base >= 1.16); this container has 1.14
 
@@ -53,3 +53,11 @@ def test_deinterlace_api():
     for nick in ("bob", "weave", "linear", "greedyh", "auto", "top-field-first", "bottom-field-first"):
         assert nick in t
     assert "Range: 0 - 1 Default: 0.1" in squeeze(t)
+
+
+def test_transform_api():
+    t = gst_env.inspect("vfhiptransform").stdout
+    assert {"method", "crop-top", "crop-bottom", "crop-left", "crop-right"} <= props(t)
+    for nick in ("none", "clockwise", "rotate-180", "counterclockwise", "horizontal-flip", "vertical-flip", "upper-left-diagonal", "upper-right-diagonal"):
+        assert nick in t
+    assert "GstVideoFilter" in t
