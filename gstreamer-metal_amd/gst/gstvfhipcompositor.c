@@ -8,10 +8,10 @@
  * Inputs keep their own sizes (update_caps does not intersect pad sizes, :394-458); the output size is the bounding
  * box of the positioned pads, BGRA preferred, highest input frame rate (:460-540).
  *
- * GstVideoAggregator moved into gst-plugins-base in 1.16; this container only has 1.14 headers, so this file is
- * compiled to a stub here (the element is not registered) and the real code below is NOT compile-checked in this
- * build environment — DESIGN.md lists it as such.  Not carried over from the reference: navigation-event forwarding
- * and the obscured-pad culling optimisation (output is identical without it). */
+ * Two variants in this file: against GStreamer >= 1.16 the element is a GstVideoAggregator like the reference (that
+ * variant cannot be compile-checked here: this container only has 1.14 headers); against 1.14 it is built directly on
+ * GstAggregator (frame-synchronous; compiled and pipeline-tested on the GPU box).  Not carried over from the reference:
+ * navigation-event forwarding and the obscured-pad culling optimisation (output is identical without it). */
 #ifdef HAVE_CONFIG_H
 #include "config.h"
 #endif
@@ -531,12 +531,562 @@ gst_vfhip_compositor_register (GstPlugin * plugin)
 
 #else /* GStreamer < 1.16: no GstVideoAggregator in gst-plugins-base */
 
+/* A frame-synchronous compositor directly on GstAggregator (which IS in gst-plugins-base 1.14): every aggregate() takes
+ * the next buffer of each sink pad, composites them in zorder and pushes one output frame.  Same element name, pad
+ * template, element / pad properties and caps rules as above; what it lacks against GstVideoAggregator is frame-rate
+ * conversion between inputs of different rates (the reference's smoke tests use equal rates).  This is the variant
+ * that is compiled and exercised by tests/test_gst_plugin_gpu.py in this environment. */
+#include <gst/base/gstaggregator.h>
+#include <stdlib.h>
+
+#define VFHIP_COMP_FORMATS "{ BGRA, RGBA, NV12, I420 }"
+enum { SIZING_NONE = 0, SIZING_KEEP_ASPECT = 1 };
+
+typedef struct
+{
+  GstAggregatorPad parent;
+  GstVideoInfo info;
+  gboolean have_info;
+  gint xpos, ypos, width, height;
+  gdouble alpha;
+  gint op, sizing_policy;
+  guint zorder;
+} GstVfHipCompositorPad;
+typedef struct
+{
+  GstAggregatorPadClass parent_class;
+} GstVfHipCompositorPadClass;
+
+enum { PAD_PROP_0, PAD_PROP_XPOS, PAD_PROP_YPOS, PAD_PROP_WIDTH, PAD_PROP_HEIGHT, PAD_PROP_ALPHA, PAD_PROP_OPERATOR, PAD_PROP_SIZING_POLICY, PAD_PROP_ZORDER };
+
+static GType
+comp_enum (const gchar * name, const GEnumValue * v, gsize * once)
+{
+  if (g_once_init_enter (once))
+    g_once_init_leave (once, g_enum_register_static (name, v));
+  return (GType) *once;
+}
+
+static GType
+comp_operator_type (void)
+{
+  static gsize t = 0;
+  static const GEnumValue v[] = { {VFHIP_BLEND_SOURCE, "Source", "source"}, {VFHIP_BLEND_OVER, "Over", "over"}, {VFHIP_BLEND_ADD, "Add", "add"}, {0, NULL, NULL} };
+  return comp_enum ("GstVfHipCompositorOperator", v, &t);
+}
+
+static GType
+comp_sizing_type (void)
+{
+  static gsize t = 0;
+  static const GEnumValue v[] = {
+    {SIZING_NONE, "None: image is scaled to fill configured destination rectangle without padding or keeping the aspect ratio", "none"},
+    {SIZING_KEEP_ASPECT, "Keep Aspect Ratio: image is scaled to fit destination rectangle with preserved aspect ratio", "keep-aspect-ratio"},
+    {0, NULL, NULL}
+  };
+  return comp_enum ("GstVfHipCompositorSizingPolicy", v, &t);
+}
+
+static GType
+comp_background_type (void)
+{
+  static gsize t = 0;
+  static const GEnumValue v[] = {
+    {VFHIP_BG_CHECKER, "Checker pattern", "checker"}, {VFHIP_BG_BLACK, "Black", "black"}, {VFHIP_BG_WHITE, "White", "white"},
+    {VFHIP_BG_TRANSPARENT, "Transparent Background to enable further compositing", "transparent"}, {0, NULL, NULL}
+  };
+  return comp_enum ("GstVfHipCompositorBackground", v, &t);
+}
+
+G_DEFINE_TYPE (GstVfHipCompositorPad, gst_vfhip_compositor_pad, GST_TYPE_AGGREGATOR_PAD);
+#define CPAD(o) ((GstVfHipCompositorPad *) (o))
+
+static void
+cpad_set_property (GObject * object, guint id, const GValue * value, GParamSpec * pspec)
+{
+  GstVfHipCompositorPad *pad = CPAD (object);
+  GstObject *agg;
+  GST_OBJECT_LOCK (pad);
+  switch (id) {
+    case PAD_PROP_XPOS: pad->xpos = g_value_get_int (value); break;
+    case PAD_PROP_YPOS: pad->ypos = g_value_get_int (value); break;
+    case PAD_PROP_WIDTH: pad->width = g_value_get_int (value); break;
+    case PAD_PROP_HEIGHT: pad->height = g_value_get_int (value); break;
+    case PAD_PROP_ALPHA: pad->alpha = g_value_get_double (value); break;
+    case PAD_PROP_OPERATOR: pad->op = g_value_get_enum (value); break;
+    case PAD_PROP_SIZING_POLICY: pad->sizing_policy = g_value_get_enum (value); break;
+    case PAD_PROP_ZORDER: pad->zorder = g_value_get_uint (value); break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
+  }
+  GST_OBJECT_UNLOCK (pad);
+  if (id != PAD_PROP_ALPHA && id != PAD_PROP_OPERATOR && id != PAD_PROP_ZORDER && (agg = gst_object_get_parent (GST_OBJECT (pad)))) {
+    gst_pad_mark_reconfigure (GST_AGGREGATOR (agg)->srcpad);          /* the output bounding box may have changed */
+    gst_object_unref (agg);
+  }
+}
+
+static void
+cpad_get_property (GObject * object, guint id, GValue * value, GParamSpec * pspec)
+{
+  GstVfHipCompositorPad *pad = CPAD (object);
+  GST_OBJECT_LOCK (pad);
+  switch (id) {
+    case PAD_PROP_XPOS: g_value_set_int (value, pad->xpos); break;
+    case PAD_PROP_YPOS: g_value_set_int (value, pad->ypos); break;
+    case PAD_PROP_WIDTH: g_value_set_int (value, pad->width); break;
+    case PAD_PROP_HEIGHT: g_value_set_int (value, pad->height); break;
+    case PAD_PROP_ALPHA: g_value_set_double (value, pad->alpha); break;
+    case PAD_PROP_OPERATOR: g_value_set_enum (value, pad->op); break;
+    case PAD_PROP_SIZING_POLICY: g_value_set_enum (value, pad->sizing_policy); break;
+    case PAD_PROP_ZORDER: g_value_set_uint (value, pad->zorder); break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
+  }
+  GST_OBJECT_UNLOCK (pad);
+}
+
+static void
+gst_vfhip_compositor_pad_class_init (GstVfHipCompositorPadClass * klass)
+{
+  GObjectClass *oc = G_OBJECT_CLASS (klass);
+  const GParamFlags f = (GParamFlags) (G_PARAM_READWRITE | GST_PARAM_CONTROLLABLE | G_PARAM_STATIC_STRINGS);
+  oc->set_property = cpad_set_property;
+  oc->get_property = cpad_get_property;
+  g_object_class_install_property (oc, PAD_PROP_XPOS, g_param_spec_int ("xpos", "X Position", "X Position of the picture", G_MININT, G_MAXINT, 0, f));
+  g_object_class_install_property (oc, PAD_PROP_YPOS, g_param_spec_int ("ypos", "Y Position", "Y Position of the picture", G_MININT, G_MAXINT, 0, f));
+  g_object_class_install_property (oc, PAD_PROP_WIDTH, g_param_spec_int ("width", "Width", "Width of the picture", G_MININT, G_MAXINT, -1, f));
+  g_object_class_install_property (oc, PAD_PROP_HEIGHT, g_param_spec_int ("height", "Height", "Height of the picture", G_MININT, G_MAXINT, -1, f));
+  g_object_class_install_property (oc, PAD_PROP_ALPHA, g_param_spec_double ("alpha", "Alpha", "Alpha of the picture", 0.0, 1.0, 1.0, f));
+  g_object_class_install_property (oc, PAD_PROP_OPERATOR, g_param_spec_enum ("operator", "Operator",
+          "Blending operator to use for blending this pad over the previous ones", comp_operator_type (), VFHIP_BLEND_OVER, f));
+  g_object_class_install_property (oc, PAD_PROP_SIZING_POLICY, g_param_spec_enum ("sizing-policy", "Sizing policy",
+          "Sizing policy to use for image scaling", comp_sizing_type (), SIZING_NONE, f));
+  g_object_class_install_property (oc, PAD_PROP_ZORDER, g_param_spec_uint ("zorder", "Z-Order", "Z Order of the picture", 0, G_MAXUINT, 0, f));
+}
+
+static void
+gst_vfhip_compositor_pad_init (GstVfHipCompositorPad * pad)
+{
+  pad->width = pad->height = -1;
+  pad->alpha = 1.0;
+  pad->op = VFHIP_BLEND_OVER;
+  pad->sizing_policy = SIZING_NONE;
+  gst_video_info_init (&pad->info);
+}
+
+typedef struct
+{
+  GstAggregator parent;
+  VfHipCompositor *renderer;
+  gint device_id, background;
+  gboolean zero_size_is_unscaled;
+  GstVideoInfo out_info;
+  gboolean have_out_info;
+  guint64 n_frames;
+} GstVfHipCompositor;
+typedef struct
+{
+  GstAggregatorClass parent_class;
+} GstVfHipCompositorClass;
+
+enum { PROP_0, PROP_BACKGROUND, PROP_ZERO_SIZE_IS_UNSCALED, PROP_DEVICE_ID };
+
+static GstStaticPadTemplate comp_src_template = GST_STATIC_PAD_TEMPLATE ("src", GST_PAD_SRC, GST_PAD_ALWAYS,
+    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE (VFHIP_COMP_FORMATS)));
+static GstStaticPadTemplate comp_sink_template = GST_STATIC_PAD_TEMPLATE ("sink_%u", GST_PAD_SINK, GST_PAD_REQUEST,
+    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE (VFHIP_COMP_FORMATS)));
+
+static void comp_child_proxy_init (gpointer g_iface, gpointer iface_data);
+G_DEFINE_TYPE_WITH_CODE (GstVfHipCompositor, gst_vfhip_compositor, GST_TYPE_AGGREGATOR,
+    G_IMPLEMENT_INTERFACE (GST_TYPE_CHILD_PROXY, comp_child_proxy_init));
+#define COMP(o) ((GstVfHipCompositor *) (o))
+
+/* destination rectangle of a pad (same rules as the >= 1.16 variant above / the reference :202-325) */
+static void
+comp_pad_rect (GstVfHipCompositor * self, GstVfHipCompositorPad * cpad, gint out_par_n, gint out_par_d, gint * w, gint * h, gint * xoff, gint * yoff)
+{
+  gint pw, ph;
+  guint dn, dd;
+  *w = *h = *xoff = *yoff = 0;
+  if (!cpad->have_info)
+    return;
+  if (self->zero_size_is_unscaled) {
+    pw = cpad->width <= 0 ? GST_VIDEO_INFO_WIDTH (&cpad->info) : cpad->width;
+    ph = cpad->height <= 0 ? GST_VIDEO_INFO_HEIGHT (&cpad->info) : cpad->height;
+  } else {
+    pw = cpad->width < 0 ? GST_VIDEO_INFO_WIDTH (&cpad->info) : cpad->width;
+    ph = cpad->height < 0 ? GST_VIDEO_INFO_HEIGHT (&cpad->info) : cpad->height;
+  }
+  if (pw == 0 || ph == 0)
+    return;
+  if (!gst_video_calculate_display_ratio (&dn, &dd, pw, ph, GST_VIDEO_INFO_PAR_N (&cpad->info), GST_VIDEO_INFO_PAR_D (&cpad->info), out_par_n, out_par_d))
+    return;
+  if (cpad->sizing_policy == SIZING_NONE) {
+    if (ph % dn == 0) pw = gst_util_uint64_scale_int (ph, dn, dd);
+    else if (pw % dd == 0) ph = gst_util_uint64_scale_int (pw, dd, dn);
+    else pw = gst_util_uint64_scale_int (ph, dn, dd);
+  } else {
+    gint fn, fd, tn, td, num, den;
+    if (!gst_util_fraction_multiply (GST_VIDEO_INFO_WIDTH (&cpad->info), GST_VIDEO_INFO_HEIGHT (&cpad->info),
+            GST_VIDEO_INFO_PAR_N (&cpad->info), GST_VIDEO_INFO_PAR_D (&cpad->info), &fn, &fd)) fn = fd = -1;
+    if (!gst_util_fraction_multiply (pw, ph, out_par_n, out_par_d, &tn, &td)) tn = td = -1;
+    if (fn != tn || fd != td) {
+      GstVideoRectangle src, dst, res;
+      if (fn == -1 || !gst_util_fraction_multiply (fn, fd, out_par_d, out_par_n, &num, &den))
+        return;
+      src.x = src.y = 0; src.w = pw; src.h = gst_util_uint64_scale_int (pw, den, num);
+      if (src.h == 0)
+        return;
+      dst.x = dst.y = 0; dst.w = pw; dst.h = ph;
+      gst_video_sink_center_rect (src, dst, &res, TRUE);
+      *xoff = res.x; *yoff = res.y; pw = res.w; ph = res.h;
+    }
+  }
+  *w = pw; *h = ph;
+}
+
+static gboolean
+comp_sink_event (GstAggregator * agg, GstAggregatorPad * pad, GstEvent * event)
+{
+  if (GST_EVENT_TYPE (event) == GST_EVENT_CAPS) {
+    GstCaps *caps;
+    GstVfHipCompositorPad *cpad = CPAD (pad);
+    gst_event_parse_caps (event, &caps);
+    GST_OBJECT_LOCK (pad);
+    cpad->have_info = gst_video_info_from_caps (&cpad->info, caps);
+    GST_OBJECT_UNLOCK (pad);
+    gst_pad_mark_reconfigure (agg->srcpad);
+  }
+  return GST_AGGREGATOR_CLASS (gst_vfhip_compositor_parent_class)->sink_event (agg, pad, event);
+}
+
+static gboolean
+comp_sink_query (GstAggregator * agg, GstAggregatorPad * pad, GstQuery * query)
+{
+  if (GST_QUERY_TYPE (query) == GST_QUERY_CAPS) {        /* every pad may carry its own size and format */
+    GstCaps *filter, *tmpl = gst_pad_get_pad_template_caps (GST_PAD (pad)), *res;
+    gst_query_parse_caps (query, &filter);
+    res = filter ? gst_caps_intersect_full (filter, tmpl, GST_CAPS_INTERSECT_FIRST) : gst_caps_ref (tmpl);
+    gst_query_set_caps_result (query, res);
+    gst_caps_unref (res); gst_caps_unref (tmpl);
+    return TRUE;
+  }
+  if (GST_QUERY_TYPE (query) == GST_QUERY_ACCEPT_CAPS) {
+    GstCaps *caps, *tmpl = gst_pad_get_pad_template_caps (GST_PAD (pad));
+    gst_query_parse_accept_caps (query, &caps);
+    gst_query_set_accept_caps_result (query, gst_caps_is_subset (caps, tmpl));
+    gst_caps_unref (tmpl);
+    return TRUE;
+  }
+  return GST_AGGREGATOR_CLASS (gst_vfhip_compositor_parent_class)->sink_query (agg, pad, query);
+}
+
+/* output size = bounding box of the positioned pads; BGRA preferred; highest input frame rate (reference :394-540) */
+static GstFlowReturn
+comp_update_src_caps (GstAggregator * agg, GstCaps * caps, GstCaps ** ret)
+{
+  GstVfHipCompositor *self = COMP (agg);
+  gint bw = -1, bh = -1, fn = -1, fd = -1;
+  gdouble best = 0.0;
+  GList *l;
+  GstCaps *tmpl, *size;
+  GST_OBJECT_LOCK (agg);
+  for (l = GST_ELEMENT (agg)->sinkpads; l; l = l->next) {
+    GstVfHipCompositorPad *cpad = CPAD (l->data);
+    gint w, h, xo, yo;
+    gdouble fps = 0.0;
+    comp_pad_rect (self, cpad, 1, 1, &w, &h, &xo, &yo);
+    if (w == 0 || h == 0)
+      continue;
+    bw = MAX (bw, w + MAX (cpad->xpos + 2 * xo, 0));
+    bh = MAX (bh, h + MAX (cpad->ypos + 2 * yo, 0));
+    if (GST_VIDEO_INFO_FPS_D (&cpad->info) != 0)
+      gst_util_fraction_to_double (GST_VIDEO_INFO_FPS_N (&cpad->info), GST_VIDEO_INFO_FPS_D (&cpad->info), &fps);
+    if (fps > best) { best = fps; fn = GST_VIDEO_INFO_FPS_N (&cpad->info); fd = GST_VIDEO_INFO_FPS_D (&cpad->info); }
+  }
+  GST_OBJECT_UNLOCK (agg);
+  if (bw <= 0 || bh <= 0)
+    return GST_AGGREGATOR_FLOW_NEED_DATA;                 /* no pad has caps yet */
+  if (fn <= 0 || fd <= 0) { fn = 25; fd = 1; }
+  size = gst_caps_new_simple ("video/x-raw", "width", G_TYPE_INT, bw, "height", G_TYPE_INT, bh, "framerate", GST_TYPE_FRACTION, fn, fd, NULL);
+  tmpl = gst_static_pad_template_get_caps (&comp_src_template);
+  *ret = gst_caps_intersect (size, tmpl);
+  gst_caps_unref (size); gst_caps_unref (tmpl);
+  if (caps) {
+    GstCaps *tmp = gst_caps_intersect (*ret, caps);
+    gst_caps_unref (*ret);
+    *ret = tmp;
+  }
+  return GST_FLOW_OK;
+}
+
+static GstCaps *
+comp_fixate_src_caps (GstAggregator * agg, GstCaps * caps)
+{
+  GstStructure *s;
+  (void) agg;
+  caps = gst_caps_make_writable (caps);
+  s = gst_caps_get_structure (caps, 0);
+  gst_structure_fixate_field_string (s, "format", "BGRA");
+  if (gst_structure_has_field (s, "pixel-aspect-ratio"))
+    gst_structure_fixate_field_nearest_fraction (s, "pixel-aspect-ratio", 1, 1);
+  return gst_caps_fixate (caps);
+}
+
+static gboolean
+comp_negotiated_src_caps (GstAggregator * agg, GstCaps * caps)
+{
+  GstVfHipCompositor *self = COMP (agg);
+  VfHipVideoInfo out;
+  if (!gst_video_info_from_caps (&self->out_info, caps))
+    return FALSE;
+  self->have_out_info = TRUE;
+  if (!self->renderer && !(self->renderer = vfhip_compositor_new (self->device_id))) {
+    GST_ERROR_OBJECT (self, "no HIP renderer: %s", vfhip_last_error_string ());
+    return FALSE;
+  }
+  gst_vfhip_info (&self->out_info, &out);
+  if (vfhip_compositor_configure (self->renderer, &out) != VFHIP_OK) {
+    GST_ERROR_OBJECT (self, "configure failed: %s", vfhip_last_error_string ());
+    return FALSE;
+  }
+  return GST_AGGREGATOR_CLASS (gst_vfhip_compositor_parent_class)->negotiated_src_caps (agg, caps);
+}
+
+typedef struct { GstVfHipCompositorPad *pad; guint order; } PadRef;
+static int
+padref_cmp (const void *a, const void *b)
+{
+  const PadRef *x = a, *y = b;
+  if (x->pad->zorder != y->pad->zorder) return x->pad->zorder < y->pad->zorder ? -1 : 1;
+  return x->order < y->order ? -1 : (x->order > y->order);
+}
+
+static GstFlowReturn
+comp_aggregate (GstAggregator * agg, gboolean timeout)
+{
+  GstVfHipCompositor *self = COMP (agg);
+  GList *l;
+  guint n = 0, i, used = 0, n_eos = 0;
+  PadRef *refs;
+  GstBuffer **bufs, *outbuf;
+  GstVideoFrame *frames, out;
+  VfHipPadInput *pads;
+  VfHipFrame vout;
+  GstAllocator *alloc;
+  gboolean covered = FALSE;
+  gint rc;
+  (void) timeout;
+  if (!self->renderer || !self->have_out_info)
+    return GST_FLOW_NOT_NEGOTIATED;
+  GST_OBJECT_LOCK (agg);
+  n = GST_ELEMENT (agg)->numsinkpads;
+  refs = g_new0 (PadRef, MAX (n, 1));
+  for (l = GST_ELEMENT (agg)->sinkpads, i = 0; l && i < n; l = l->next, i++) {
+    refs[i].pad = gst_object_ref (l->data);
+    refs[i].order = i;
+  }
+  GST_OBJECT_UNLOCK (agg);
+  qsort (refs, n, sizeof (PadRef), padref_cmp);            /* draw order = zorder, ties in pad creation order */
+  bufs = g_new0 (GstBuffer *, MAX (n, 1));
+  frames = g_new0 (GstVideoFrame, MAX (n, 1));
+  pads = g_new0 (VfHipPadInput, MAX (n, 1));
+  for (i = 0; i < n; i++) {
+    GstVfHipCompositorPad *cpad = refs[i].pad;
+    gint w, h, xo, yo;
+    if (gst_aggregator_pad_is_eos (GST_AGGREGATOR_PAD (cpad))) { n_eos++; continue; }
+    bufs[i] = gst_aggregator_pad_pop_buffer (GST_AGGREGATOR_PAD (cpad));
+    if (!bufs[i] || !cpad->have_info || cpad->alpha == 0.0)
+      continue;
+    if (!gst_video_frame_map (&frames[i], &cpad->info, bufs[i], GST_MAP_READ))
+      continue;
+    comp_pad_rect (self, cpad, GST_VIDEO_INFO_PAR_N (&self->out_info), GST_VIDEO_INFO_PAR_D (&self->out_info), &w, &h, &xo, &yo);
+    gst_vfhip_frame (&frames[i], &pads[used].frame);
+    pads[used].xpos = cpad->xpos + xo; pads[used].ypos = cpad->ypos + yo; pads[used].width = w; pads[used].height = h;
+    pads[used].alpha = cpad->alpha; pads[used].blend_mode = cpad->op;
+    if (cpad->alpha == 1.0 && !GST_VIDEO_INFO_HAS_ALPHA (&cpad->info) && pads[used].xpos <= 0 && pads[used].ypos <= 0 &&
+        pads[used].xpos + w >= GST_VIDEO_INFO_WIDTH (&self->out_info) && pads[used].ypos + h >= GST_VIDEO_INFO_HEIGHT (&self->out_info))
+      covered = TRUE;                                      /* background invisible: TRANSPARENT like the reference (:649-651) */
+    used++;
+  }
+  if (n > 0 && n_eos == n) {
+    rc = GST_FLOW_EOS;
+    goto done;
+  }
+  alloc = gst_vfhip_pinned_allocator_get ();
+  outbuf = gst_buffer_new_allocate (alloc, GST_VIDEO_INFO_SIZE (&self->out_info), NULL);
+  gst_object_unref (alloc);
+  if (!outbuf || !gst_video_frame_map (&out, &self->out_info, outbuf, GST_MAP_WRITE)) {
+    if (outbuf) gst_buffer_unref (outbuf);
+    rc = GST_FLOW_ERROR;
+    goto done;
+  }
+  gst_vfhip_frame (&out, &vout);
+  rc = vfhip_compositor_composite (self->renderer, pads, (int) used, (covered && used > 0) ? VFHIP_BG_TRANSPARENT : self->background, &vout);
+  gst_video_frame_unmap (&out);
+  if (rc != VFHIP_OK) {
+    GST_ERROR_OBJECT (self, "HIP compositing failed: %s", vfhip_last_error_string ());
+    gst_buffer_unref (outbuf);
+    rc = GST_FLOW_ERROR;
+    goto done;
+  }
+  if (GST_VIDEO_INFO_FPS_N (&self->out_info) > 0) {
+    GST_BUFFER_PTS (outbuf) = gst_util_uint64_scale (self->n_frames, GST_SECOND * GST_VIDEO_INFO_FPS_D (&self->out_info), GST_VIDEO_INFO_FPS_N (&self->out_info));
+    GST_BUFFER_DURATION (outbuf) = gst_util_uint64_scale (1, GST_SECOND * GST_VIDEO_INFO_FPS_D (&self->out_info), GST_VIDEO_INFO_FPS_N (&self->out_info));
+  }
+  self->n_frames++;
+  rc = gst_aggregator_finish_buffer (agg, outbuf);
+done:
+  for (i = 0; i < n; i++) {
+    if (frames[i].buffer) gst_video_frame_unmap (&frames[i]);
+    if (bufs[i]) gst_buffer_unref (bufs[i]);
+    gst_object_unref (refs[i].pad);
+  }
+  g_free (pads); g_free (frames); g_free (bufs); g_free (refs);
+  return (GstFlowReturn) rc;
+}
+
+static gboolean
+comp_stop (GstAggregator * agg)
+{
+  GstVfHipCompositor *self = COMP (agg);
+  if (self->renderer)
+    vfhip_compositor_cleanup (self->renderer);
+  self->n_frames = 0;
+  self->have_out_info = FALSE;
+  return TRUE;
+}
+
+static void
+comp_set_property (GObject * object, guint id, const GValue * value, GParamSpec * pspec)
+{
+  GstVfHipCompositor *self = COMP (object);
+  switch (id) {
+    case PROP_BACKGROUND: self->background = g_value_get_enum (value); break;
+    case PROP_ZERO_SIZE_IS_UNSCALED: self->zero_size_is_unscaled = g_value_get_boolean (value); break;
+    case PROP_DEVICE_ID: self->device_id = g_value_get_int (value); break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
+  }
+}
+
+static void
+comp_get_property (GObject * object, guint id, GValue * value, GParamSpec * pspec)
+{
+  GstVfHipCompositor *self = COMP (object);
+  switch (id) {
+    case PROP_BACKGROUND: g_value_set_enum (value, self->background); break;
+    case PROP_ZERO_SIZE_IS_UNSCALED: g_value_set_boolean (value, self->zero_size_is_unscaled); break;
+    case PROP_DEVICE_ID: g_value_set_int (value, self->device_id); break;
+    default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
+  }
+}
+
+static void
+comp_finalize (GObject * object)
+{
+  GstVfHipCompositor *self = COMP (object);
+  if (self->renderer)
+    vfhip_compositor_free (self->renderer);
+  self->renderer = NULL;
+  G_OBJECT_CLASS (gst_vfhip_compositor_parent_class)->finalize (object);
+}
+
+static GObject *
+comp_child_by_index (GstChildProxy * proxy, guint index)
+{
+  GObject *obj;
+  GST_OBJECT_LOCK (proxy);
+  obj = g_list_nth_data (GST_ELEMENT_CAST (proxy)->sinkpads, index);
+  if (obj)
+    gst_object_ref (obj);
+  GST_OBJECT_UNLOCK (proxy);
+  return obj;
+}
+
+static guint
+comp_children_count (GstChildProxy * proxy)
+{
+  guint n;
+  GST_OBJECT_LOCK (proxy);
+  n = GST_ELEMENT_CAST (proxy)->numsinkpads;
+  GST_OBJECT_UNLOCK (proxy);
+  return n;
+}
+
+static void
+comp_child_proxy_init (gpointer g_iface, gpointer iface_data)
+{
+  GstChildProxyInterface *iface = g_iface;
+  (void) iface_data;
+  iface->get_child_by_index = comp_child_by_index;
+  iface->get_children_count = comp_children_count;
+}
+
+static GstPad *
+comp_request_new_pad (GstElement * element, GstPadTemplate * templ, const gchar * name, const GstCaps * caps)
+{
+  GstPad *pad = GST_ELEMENT_CLASS (gst_vfhip_compositor_parent_class)->request_new_pad (element, templ, name, caps);
+  if (pad)
+    gst_child_proxy_child_added (GST_CHILD_PROXY (element), G_OBJECT (pad), GST_OBJECT_NAME (pad));
+  return pad;
+}
+
+static void
+comp_release_pad (GstElement * element, GstPad * pad)
+{
+  gst_child_proxy_child_removed (GST_CHILD_PROXY (element), G_OBJECT (pad), GST_OBJECT_NAME (pad));
+  GST_ELEMENT_CLASS (gst_vfhip_compositor_parent_class)->release_pad (element, pad);
+}
+
+static void
+gst_vfhip_compositor_class_init (GstVfHipCompositorClass * klass)
+{
+  GObjectClass *oc = G_OBJECT_CLASS (klass);
+  GstElementClass *ec = GST_ELEMENT_CLASS (klass);
+  GstAggregatorClass *ac = GST_AGGREGATOR_CLASS (klass);
+  oc->set_property = comp_set_property;
+  oc->get_property = comp_get_property;
+  oc->finalize = comp_finalize;
+  ec->request_new_pad = GST_DEBUG_FUNCPTR (comp_request_new_pad);
+  ec->release_pad = GST_DEBUG_FUNCPTR (comp_release_pad);
+  ac->sink_event = GST_DEBUG_FUNCPTR (comp_sink_event);
+  ac->sink_query = GST_DEBUG_FUNCPTR (comp_sink_query);
+  ac->update_src_caps = GST_DEBUG_FUNCPTR (comp_update_src_caps);
+  ac->fixate_src_caps = GST_DEBUG_FUNCPTR (comp_fixate_src_caps);
+  ac->negotiated_src_caps = GST_DEBUG_FUNCPTR (comp_negotiated_src_caps);
+  ac->aggregate = GST_DEBUG_FUNCPTR (comp_aggregate);
+  ac->stop = GST_DEBUG_FUNCPTR (comp_stop);
+
+  g_object_class_install_property (oc, PROP_BACKGROUND, g_param_spec_enum ("background", "Background", "Background type",
+          comp_background_type (), VFHIP_BG_CHECKER, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_ZERO_SIZE_IS_UNSCALED, g_param_spec_boolean ("zero-size-is-unscaled", "Zero size is unscaled",
+          "If TRUE, then input video is unscaled in that dimension if width or height is 0 (for backwards compatibility)", TRUE,
+          G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_DEVICE_ID, g_param_spec_int ("device-id", "Device ID",
+          "GPU ordinal to run on (-1: $VFHIP_DEVICE, else 0)", -1, 63, GST_VFHIP_DEFAULT_DEVICE_ID, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+
+  gst_element_class_add_static_pad_template_with_gtype (ec, &comp_src_template, GST_TYPE_AGGREGATOR_PAD);
+  gst_element_class_add_static_pad_template_with_gtype (ec, &comp_sink_template, gst_vfhip_compositor_pad_get_type ());
+  gst_element_class_set_static_metadata (ec, "HIP Compositor", "Filter/Editor/Video/Compositor",
+      "MI355X-accelerated compositing of multiple video streams", "vfhip");
+}
+
+static void
+gst_vfhip_compositor_init (GstVfHipCompositor * self)
+{
+  self->background = VFHIP_BG_CHECKER;
+  self->zero_size_is_unscaled = TRUE;
+  self->device_id = GST_VFHIP_DEFAULT_DEVICE_ID;
+  gst_video_info_init (&self->out_info);
+}
+
 gboolean
 gst_vfhip_compositor_register (GstPlugin * plugin)
 {
-  (void) plugin;
-  GST_INFO ("vfhipcompositor needs GStreamer >= 1.16 (GstVideoAggregator); not registered in this build");
-  return TRUE;
+  gboolean ok = gst_element_register (plugin, "vfhipcompositor", GST_RANK_PRIMARY + 2, gst_vfhip_compositor_get_type ());
+#ifdef VFHIP_REGISTER_VFMETAL_NAMES
+  ok &= gst_element_register (plugin, "vfmetalcompositor", GST_RANK_PRIMARY + 2, gst_vfhip_compositor_get_type ());
+#endif
+  return ok;
 }
 
 #endif

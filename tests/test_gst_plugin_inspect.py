@@ -23,9 +23,8 @@ def squeeze(text):
 def test_plugin_registers_elements():
     r = gst_env.inspect("vfhip")
     assert r.returncode == 0, r.stdout + r.stderr
-    for e in ("vfhipconvertscale", "vfhipvideofilter", "vfhipdeinterlace", "vfhiptransform"):
+    for e in ("vfhipconvertscale", "vfhipvideofilter", "vfhipdeinterlace", "vfhiptransform", "vfhipcompositor"):
         assert e in r.stdout
-    # vfhipcompositor needs GstVideoAggregator (gst-plugins-base >= 1.16); this container has 1.14
 
 
 def test_convertscale_api():
@@ -61,3 +60,17 @@ def test_transform_api():
     for nick in ("none", "clockwise", "rotate-180", "counterclockwise", "horizontal-flip", "vertical-flip", "upper-left-diagonal", "upper-right-diagonal"):
         assert nick in t
     assert "GstVideoFilter" in t
+
+
+def test_compositor_api():
+    """reference tests/test-compositor.sh:60-88: element + pad property surface (pad properties show on a requested pad)"""
+    t = gst_env.inspect("vfhipcompositor").stdout
+    assert {"background", "zero-size-is-unscaled", "device-id"} <= props(t)
+    for nick in ("checker", "black", "white", "transparent"):
+        assert nick in t
+    assert "GstAggregator" in t and "GstChildProxy" in t and "sink_%u" in t and "On request" in t
+    assert "primary + 2" in t
+    assert t.count("(string)BGRA, (string)RGBA, (string)NV12, (string)I420 }") == 2
+    src = open(gst_env.PLUGIN_DIR + "/gstvfhipcompositor.c").read()
+    for prop in ("xpos", "ypos", "width", "height", "alpha", "operator", "sizing-policy", "zorder"):
+        assert f'("{prop}"' in src
