@@ -69,8 +69,8 @@ def load_traffic(frames):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=500)   # ~0.3 s: long enough to sit at the sustained clock
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--frames", type=int, default=128, help="frames per launch (= ring size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

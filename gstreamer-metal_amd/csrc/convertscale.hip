@@ -153,17 +153,29 @@ static uint32_t border_in_output_order (uint32_t argb, int out_format)
   return b | (g << 8) | (r << 16) | (a << 24);
 }
 
-template <int ROWS>
-static void launch_half (const CsParams &p, int n_frames, hipStream_t s)
+static int env_int (const char *name, int dflt)
 {
-  const int cgpr = p.out_w / 4, strips = (p.out_h + ROWS - 1) / ROWS;
-  dim3 grid ((unsigned) (((size_t) cgpr * strips + 255) / 256), (unsigned) n_frames);
+  const char *e = getenv (name);
+  return e && *e ? atoi (e) : dflt;
+}
+
+static void launch_half (CsParams &p, int n_frames, int n_cu, hipStream_t s)
+{
+  const int cgpr = p.out_w / 4;
+  auto bpf = [&] (int rows) { return (cgpr * ((p.out_h + rows - 1) / rows) + 255) / 256; };
+  // rows per lane: long strips amortise the 2-row chroma prologue; short ones keep a small batch wide enough
+  const size_t want = (size_t) n_cu * 4;                       // blocks for >= 16 waves per CU
+  int rows = (size_t) bpf (16) * n_frames >= want ? 16 : ((size_t) bpf (8) * n_frames >= want ? 8 : 4);
+  const int r = env_int ("VFHIP_HALF_ROWS", 0);                // tuning knobs (tools/gpu_ab.sh)
+  if (r == 4 || r == 8 || r == 16) rows = r;
+  p.half_rows = rows;
+  dim3 grid ((unsigned) (bpf (rows) * n_frames));
   if (p.cosited) {
-    if (p.out_rgba) hipLaunchKernelGGL ((k_cs_nv12_half<ROWS, true, true>), grid, dim3 (256), 0, s, p);
-    else hipLaunchKernelGGL ((k_cs_nv12_half<ROWS, true, false>), grid, dim3 (256), 0, s, p);
+    if (p.out_rgba) hipLaunchKernelGGL ((k_cs_nv12_half<true, true>), grid, dim3 (256), 0, s, p);
+    else hipLaunchKernelGGL ((k_cs_nv12_half<true, false>), grid, dim3 (256), 0, s, p);
   } else {
-    if (p.out_rgba) hipLaunchKernelGGL ((k_cs_nv12_half<ROWS, false, true>), grid, dim3 (256), 0, s, p);
-    else hipLaunchKernelGGL ((k_cs_nv12_half<ROWS, false, false>), grid, dim3 (256), 0, s, p);
+    if (p.out_rgba) hipLaunchKernelGGL ((k_cs_nv12_half<false, true>), grid, dim3 (256), 0, s, p);
+    else hipLaunchKernelGGL ((k_cs_nv12_half<false, false>), grid, dim3 (256), 0, s, p);
   }
 }
 
@@ -393,15 +405,7 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
     if ((a & 7) || (b & 15)) half = false;
   }
   if (half) {
-    // rows per lane: long strips amortise the 2-row chroma prologue; short ones keep a single frame wide enough
-    const size_t waves16 = (size_t) (p.out_w / 4) * ((p.out_h + 15) / 16) * n_frames / 64;
-    const size_t waves8 = (size_t) (p.out_w / 4) * ((p.out_h + 7) / 8) * n_frames / 64;
-    const size_t want = (size_t) h->dev->n_cu * 16;
-    int rows = waves16 >= want ? 16 : (waves8 >= want ? 8 : 4);
-    if (const char *e = getenv ("VFHIP_HALF_ROWS")) { const int r = atoi (e); if (r == 4 || r == 8 || r == 16) rows = r; }   // tuning knob
-    if (rows == 16) launch_half<16> (p, n_frames, s);
-    else if (rows == 8) launch_half<8> (p, n_frames, s);
-    else launch_half<4> (p, n_frames, s);
+    launch_half (p, n_frames, h->dev->n_cu, s);
   } else {
     dim3 grid ((unsigned) ((p.out_w + 63) / 64), (unsigned) ((p.out_h + 3) / 4), (unsigned) n_frames);
     // window loads need >= 2 luma columns and >= 4 chroma pairs per row; tiny frames and nearest / RGB inputs use k_cs_generic

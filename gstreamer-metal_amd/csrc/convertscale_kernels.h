@@ -9,7 +9,7 @@
 // Kernels in this file (streaming per-pixel kernels, no MFMA — there is no contraction; roofline = HBM):
 //   k_cs_nv12_half : NV12 -> BGRA/RGBA at exactly 2:1 in both axes, bilinear (the BASELINE headline 2160p -> 1080p).
 //                    Each lane owns 4 adjacent output pixels (one 16-byte store per row) and slides down a strip of
-//                    ROWS output rows two rows per trip, keeping the horizontally up-sampled chroma row and the
+//                    `rows` output rows two rows per trip, keeping the horizontally up-sampled chroma row and the
 //                    floor-average with its predecessor in registers, so every input byte is loaded once; the loads
 //                    of the next row are issued before the current row is computed (register double buffer).
 //                    Packed-byte ALU: v_lerp_u8 for (a+b+1)>>1 / (3a+b+2)>>2 and the w=128 vertical tap,
@@ -41,6 +41,7 @@ struct CsParams {
   const int *vtab;                  // bilinear: rh * {i0, i1, w, pad}; nearest: rh * {i, 0, 0, 0}
   const int *htab;                  // nearest: rw source columns
   uint32_t border;                  // border colour in output byte order
+  int half_rows;                    // k_cs_nv12_half: output rows per lane (strip height)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -192,25 +193,30 @@ __device__ __forceinline__ void half_row (const HalfCtx &k, int y, const CRow &h
   *reinterpret_cast<uint4 *> (k.op + (__umul24 ((uint32_t) y, k.os) + 2u * k.cx)) = make_uint4 (out[0], out[1], out[2], out[3]);
 }
 
-// grid: x = ceil(cgpr * strips / 256), y = frames.  cgpr = out_w / 4 column groups per row.
-template <int ROWS, bool COSITED, bool RGBA>
+// grid: 1-D, ceil(cgpr * strips / 256) blocks of 256 lanes per frame, frames back to back (cgpr = out_w / 4 column
+// groups per row, strips of p.half_rows output rows).  (A "guided" variant that finished each batch with short strips
+// to shorten the drain phase between back-to-back launches measured no gain — profiles/r01q_tail_ab.txt — and was dropped.)
+template <bool COSITED, bool RGBA>
 __global__ __launch_bounds__ (256, 8) void k_cs_nv12_half (const CsParams p)
 {
   const int cgpr = p.out_w >> 2;
-  const int strips = (p.out_h + ROWS - 1) / ROWS;
-  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.x, rows = p.half_rows;
+  const int strips = (p.out_h + rows - 1) / rows;
+  const int bpf = (cgpr * strips + 255) >> 8;                  // blocks per frame (wave-uniform scalar arithmetic)
+  const int frame = b / bpf;
+  const int t = (b % bpf) * 256 + threadIdx.x;
   if (t >= cgpr * strips) return;
   const int strip = t / cgpr, cg = t - strip * cgpr;
-  const int y0 = strip * ROWS;
+  const int y0 = strip * rows;
   HalfCtx k;
-  k.yp = p.in[0] + (size_t) blockIdx.y * p.in_pitch;          // wave-uniform plane bases; per-lane parts are 32-bit offsets
-  k.uvp = p.in[1] + (size_t) blockIdx.y * p.in_pitch;         // (global_load with SGPR base + VGPR offset)
-  k.op = p.out + (size_t) blockIdx.y * p.out_pitch;
+  k.yp = p.in[0] + (size_t) frame * p.in_pitch;               // wave-uniform plane bases; per-lane parts are 32-bit offsets
+  k.uvp = p.in[1] + (size_t) frame * p.in_pitch;         // (global_load with SGPR base + VGPR offset)
+  k.op = p.out + (size_t) frame * p.out_pitch;
   k.ys = (uint32_t) p.is[0]; k.cs = (uint32_t) p.is[1]; k.os = (uint32_t) p.os;
   k.cx = 8u * (uint32_t) cg;
   k.roff = cg == cgpr - 1 ? 6u : 8u; k.loff = cg == 0 ? 0u : 2u;
   k.ch = p.out_h;                                              // chroma rows == output rows at 2:1
-  k.yend = min (y0 + ROWS, p.out_h);
+  k.yend = min (y0 + rows, p.out_h);
 #pragma unroll
   for (int i = 0; i < 5; i++) k.c[i] = p.c[i];
   // horizontal tap weights of this lane's 4 output pixels (row independent): bytes [255-f, f, 0, 0]

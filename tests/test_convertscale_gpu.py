@@ -153,6 +153,31 @@ def test_full_size_batch_properties(vfhip, oracle):
     cs.close()
 
 
+@pytest.mark.parametrize("rows", [16, 8, 4])
+def test_batch_grid_decomposition(vfhip, oracle, rows, monkeypatch):
+    """the batched launch is one 1-D grid over (frame, strip, column group): every frame of a 16-frame batch equals
+    the oracle for each strip height"""
+    import torch
+    w, h, ow, oh, n = 512, 136, 256, 68, 16
+    monkeypatch.setenv("VFHIP_HALF_ROWS", str(rows))
+    _, size = vfhip.plane_layout("NV12", w, h)
+    pitch = (size + 255) // 256 * 256
+    g = torch.Generator(device="cpu").manual_seed(11)
+    host = torch.randint(0, 256, (n, pitch), dtype=torch.uint8, generator=g)
+    dev_in, dev_out = host.cuda(), torch.zeros((n, ow * oh * 4), dtype=torch.uint8, device="cuda")
+    cs = vfhip.ConvertScale(0)
+    cs.configure("NV12", w, h, "RGBA", ow, oh, colorimetry="bt601", chroma_site="jpeg")
+    assert cs.kernel_name == "k_cs_nv12_half"
+    s = torch.cuda.Stream()
+    cs.process_device(dev_in.data_ptr(), dev_out.data_ptr(), stream=s.cuda_stream, n_frames=n, in_pitch=pitch, out_pitch=ow * oh * 4)
+    s.synchronize()
+    out = dev_out.cpu().numpy().reshape(n, oh, ow, 4)
+    for k in range(n):
+        want = oracle.convertscale("NV12", w, h, host[k, :size].numpy(), "bt601", "jpeg", "bilinear", "RGBA", ow, oh)
+        assert np.array_equal(out[k], want), f"frame {k}"
+    cs.close()
+
+
 def test_error_behaviour(vfhip):
     import ctypes as C
     cs = vfhip.ConvertScale(0)

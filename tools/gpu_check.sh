@@ -11,7 +11,7 @@ tail -2 $OUT/smoke.log
 timeout -k 10 600 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; rc=$?
 tail -15 $OUT/pytest_gpu.log
 [ $rc -eq 0 ] || exit $rc
-timeout -k 10 300 python bench.py --steps 40 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err || { tail -20 $OUT/bench.err; exit 1; }
+timeout -k 10 300 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -20 $OUT/bench.err; exit 1; }
 cat $OUT/bench.json
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err || { tail -20 $OUT/prof.err; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py --steps 100 --warmup 20 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err || { tail -20 $OUT/prof.err; exit 1; }
 find $OUT/prof -name '*kernel_stats.csv' | head -1 | xargs -r head -8
