@@ -13,5 +13,5 @@ tail -15 $OUT/pytest_gpu.log
 [ $rc -eq 0 ] || exit $rc
 timeout -k 10 300 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -20 $OUT/bench.err; exit 1; }
 cat $OUT/bench.json
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py --steps 100 --warmup 20 --no-cpu-baseline > $OUT/prof_bench.json 2> $OUT/prof.err || { tail -20 $OUT/prof.err; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python bench.py > $OUT/prof_bench.json 2> $OUT/prof.err || { tail -20 $OUT/prof.err; exit 1; }
 find $OUT/prof -name '*kernel_stats.csv' | head -1 | xargs -r head -8
