@@ -23,6 +23,7 @@ struct CompLayer {
   int xpos, ypos, width, height;
   float alpha;
   int blend;
+  size_t pitch;                         // batch: this pad's frame z at base + z * pitch
 };
 struct CompParams {
   CompLayer layer[COMP_MAX_LAYERS];
@@ -31,11 +32,12 @@ struct CompParams {
   const uint32_t *prev; int prev_stride;
   metal::OutImg out;
   uint32_t *scratch; int scratch_stride;   // != nullptr: write logical RGBA8 here instead of `out`
+  size_t out_pitch;                     // batch: output frame z at base + z * out_pitch (single-pass launches only)
 };
 
 using metal::F4;
 
-__device__ __forceinline__ uint32_t comp_pixel (const CompParams &p, int x, int y)
+__device__ __forceinline__ uint32_t comp_pixel (const CompParams &p, int x, int y, unsigned z)
 {
   uint32_t q;
   if (p.background < 0) q = p.prev[(size_t) y * p.prev_stride + x];
@@ -57,11 +59,11 @@ __device__ __forceinline__ uint32_t comp_pixel (const CompParams &p, int x, int 
     if (L.width == L.img.w && L.height == L.img.h) {
       // unscaled pad: texel centres are sampled, the linear sampler returns the exact texel (SURVEY.md Appendix B
       // item 2); 4:2:0 chroma still interpolates at its .25/.75 phases.  One dword load instead of 16 byte taps.
-      s = metal::fetch_1to1 (L.img, x - L.xpos, y - L.ypos, true);
+      s = metal::fetch_1to1 (metal::img_at (L.img, z * L.pitch), x - L.xpos, y - L.ypos, true);
     } else {
       const float tu = (((float) x + 0.5f) - (float) L.xpos) / (float) L.width;
       const float tv = (((float) y + 0.5f) - (float) L.ypos) / (float) L.height;
-      s = metal::sample_rgba (L.img, tu, tv, true);
+      s = metal::sample_rgba (metal::img_at (L.img, z * L.pitch), tu, tv, true);
     }
     s.a *= L.alpha; s.r *= s.a; s.g *= s.a; s.b *= s.a;            // premultiply (compositorFragment, :58-59)
     const F4 d = metal::unpack_rgba8 (q);
@@ -83,7 +85,7 @@ __global__ __launch_bounds__ (256) void k_compositor (const CompParams p)
   for (int dy = 0; dy < 2; dy++)
 #pragma unroll
     for (int dx = 0; dx < 2; dx++)
-      q[dy][dx] = comp_pixel (p, min (2 * bx + dx, p.out.w - 1), min (2 * by + dy, p.out.h - 1));
+      q[dy][dx] = comp_pixel (p, min (2 * bx + dx, p.out.w - 1), min (2 * by + dy, p.out.h - 1), blockIdx.z);
   if (p.scratch) {
 #pragma unroll
     for (int dy = 0; dy < 2; dy++)
@@ -92,7 +94,7 @@ __global__ __launch_bounds__ (256) void k_compositor (const CompParams p)
         if (2 * bx + dx < p.out.w && 2 * by + dy < p.out.h) p.scratch[(size_t) (2 * by + dy) * p.scratch_stride + 2 * bx + dx] = q[dy][dx];
     return;
   }
-  metal::store_block (p.out, bx, by, q);
+  metal::store_block (metal::out_at (p.out, blockIdx.z * p.out_pitch), bx, by, q);
 }
 
 }  // namespace vfhip
@@ -106,11 +108,12 @@ struct VfHipCompositor {
   uint32_t *scratch[2] = { nullptr, nullptr };   // only for > COMP_MAX_LAYERS pads
 };
 
-static int comp_launch (VfHipCompositor *h, const VfHipPadInput *pads, int count, int background, VfHipFrame *out, hipStream_t s)
+static int comp_launch (VfHipCompositor *h, const VfHipPadInput *pads, int count, int background, VfHipFrame *out, hipStream_t s,
+    int n_frames = 1, const size_t *pad_pitch = nullptr, size_t out_pitch = 0)
 {
   const int w = h->out.width, hh = h->out.height;
   const int bw = (w + 1) / 2, bh = (hh + 1) / 2;
-  dim3 grid ((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4));
+  dim3 grid ((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4), (unsigned) n_frames);
   const int passes = count <= COMP_MAX_LAYERS ? 1 : (count + COMP_MAX_LAYERS - 1) / COMP_MAX_LAYERS;
   if (passes > 1)
     for (int k = 0; k < 2; k++)
@@ -126,10 +129,11 @@ static int comp_launch (VfHipCompositor *h, const VfHipPadInput *pads, int count
       L.img = metal::make_img (&in.frame);
       L.xpos = in.xpos; L.ypos = in.ypos; L.width = in.width; L.height = in.height;
       L.alpha = (float) in.alpha; L.blend = in.blend_mode;
+      L.pitch = pad_pitch ? pad_pitch[first + k] : 0;
     }
     p.background = pass == 0 ? background : -1;
     p.prev = pass == 0 ? nullptr : h->scratch[(pass - 1) & 1]; p.prev_stride = w;
-    p.out = metal::make_out (out);
+    p.out = metal::make_out (out); p.out_pitch = out_pitch;
     p.scratch = pass == passes - 1 ? nullptr : h->scratch[pass & 1]; p.scratch_stride = w;
     hipLaunchKernelGGL (k_compositor, grid, dim3 (64, 4), 0, s, p);
     VFHIP_CHECK_HIP (hipGetLastError ());
@@ -187,6 +191,19 @@ int vfhip_compositor_composite_device (VfHipCompositor *h, const VfHipPadInput *
   std::lock_guard<std::mutex> lk (h->mu);
   VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
   return comp_launch (h, pads, count, background, out, stream ? (hipStream_t) stream : h->st.s_compute);
+}
+
+int vfhip_compositor_composite_device_batch (VfHipCompositor *h, const VfHipPadInput *pads, const size_t *pad_frame_pitch, int count,
+    int background, VfHipFrame *out0, size_t out_frame_pitch, int n_frames, void *stream)
+{
+  int rc = comp_check (h, pads, count, background, out0);
+  if (rc) return rc;
+  if (n_frames < 1 || n_frames > 65535) return set_error (VFHIP_ERR_INVALID, "n_frames %d outside 1..65535", n_frames);
+  if (n_frames > 1 && (count > COMP_MAX_LAYERS || !pad_frame_pitch))
+    return set_error (VFHIP_ERR_UNSUPPORTED, "batched compositing takes at most %d pads and needs the per-pad frame pitches", COMP_MAX_LAYERS);
+  std::lock_guard<std::mutex> lk (h->mu);
+  VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
+  return comp_launch (h, pads, count, background, out0, stream ? (hipStream_t) stream : h->st.s_compute, n_frames, pad_frame_pitch, out_frame_pitch);
 }
 
 int vfhip_compositor_composite (VfHipCompositor *h, const VfHipPadInput *pads, int count, int background, VfHipFrame *out)

@@ -18,7 +18,19 @@ struct DeintParams {
   metal::OutImg out;
   int method, tff;
   float threshold;
+  // batch of consecutive frames of ONE stream: frame z at base + z * pitch; its history is frame z-1 of the batch
+  // (frame 0: `prev`, the handle's stored history)
+  size_t in_pitch, out_pitch;
 };
+
+__device__ __forceinline__ DeintParams deint_frame (const DeintParams &p, unsigned z)
+{
+  DeintParams q = p;
+  q.cur = metal::img_at (p.cur, z * p.in_pitch);
+  q.out = metal::out_at (p.out, z * p.out_pitch);
+  if (z > 0) q.prev = metal::img_at (p.cur, (z - 1) * p.in_pitch);
+  return q;
+}
 
 // the reference's _inputRGBA texel: YUV -> RGB with NEAREST chroma, quantised to 8 bits; RGBA bytes pass through
 __device__ __forceinline__ uint32_t deint_input_rgba8 (const metal::Img &im, int x, int y)
@@ -53,8 +65,9 @@ __device__ __forceinline__ uint32_t deint_pixel (const DeintParams &p, int x, in
   return metal::quant_rgba8 (o);
 }
 
-__global__ __launch_bounds__ (256) void k_deinterlace (const DeintParams p)
+__global__ __launch_bounds__ (256) void k_deinterlace (const DeintParams pp)
 {
+  const DeintParams p = deint_frame (pp, blockIdx.z);
   const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
   if (2 * bx >= p.out.w || 2 * by >= p.out.h) return;
   uint32_t q[2][2];
@@ -115,8 +128,9 @@ __device__ __forceinline__ uint32_t deint_other8 (int method, float thr, uint32_
 constexpr int DEINT_ROWS = 8;
 
 template <bool PLANAR>
-__global__ __launch_bounds__ (256) void k_deinterlace_420 (const DeintParams p)
+__global__ __launch_bounds__ (256) void k_deinterlace_420 (const DeintParams pp)
 {
+  const DeintParams p = deint_frame (pp, blockIdx.y);
   const int cw = (p.out.w + 1) >> 1, h = p.out.h;
   const int strips = (h + DEINT_ROWS - 1) / DEINT_ROWS;
   const int t = blockIdx.x * 256 + threadIdx.x;
@@ -171,9 +185,10 @@ struct VfHipDeinterlace {
 };
 
 static int deint_launch (VfHipDeinterlace *h, const VfHipFrame *cur, const VfHipFrame *prev, VfHipFrame *out,
-    const VfHipDeinterlaceParams *prm, hipStream_t s)
+    const VfHipDeinterlaceParams *prm, hipStream_t s, int n_frames = 1, size_t in_pitch = 0, size_t out_pitch = 0)
 {
   DeintParams p {};
+  p.in_pitch = in_pitch; p.out_pitch = out_pitch;
   p.cur = metal::make_img (cur);
   if (prev) p.prev = metal::make_img (prev);
   p.out = metal::make_out (out);
@@ -181,11 +196,11 @@ static int deint_launch (VfHipDeinterlace *h, const VfHipFrame *cur, const VfHip
   const int bw = (h->info.width + 1) / 2, bh = (h->info.height + 1) / 2;
   if (h->info.format == VFHIP_FORMAT_NV12 || h->info.format == VFHIP_FORMAT_I420) {
     const int strips = (h->info.height + DEINT_ROWS - 1) / DEINT_ROWS;
-    dim3 grid ((unsigned) (((size_t) bw * strips + 255) / 256));
+    dim3 grid ((unsigned) (((size_t) bw * strips + 255) / 256), (unsigned) n_frames);
     if (h->info.format == VFHIP_FORMAT_I420) hipLaunchKernelGGL (k_deinterlace_420<true>, grid, dim3 (256), 0, s, p);
     else hipLaunchKernelGGL (k_deinterlace_420<false>, grid, dim3 (256), 0, s, p);
   } else {
-    dim3 grid ((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4));
+    dim3 grid ((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4), (unsigned) n_frames);
     hipLaunchKernelGGL (k_deinterlace, grid, dim3 (64, 4), 0, s, p);
   }
   VFHIP_CHECK_HIP (hipGetLastError ());
@@ -256,35 +271,50 @@ int vfhip_deinterlace_process (VfHipDeinterlace *h, const VfHipFrame *in, VfHipF
   return rc;
 }
 
-int vfhip_deinterlace_process_device (VfHipDeinterlace *h, const VfHipFrame *in, VfHipFrame *out,
+// history = the previous input frame, kept in one of two internal device images and filled by a stream-ordered
+// device-to-device copy (the reference blits _inputRGBA -> _prevFrameRGBA, :394-405).  Writing the history from
+// inside the kernel was measured 3x SLOWER (2-byte stores per lane: 9.2 k vs 27.3 k frames/s on NV12 2160p).
+// In a batch the history of frame k is frame k-1 of the batch itself; only the LAST frame is copied.
+static int deint_device (VfHipDeinterlace *h, const VfHipFrame *in0, VfHipFrame *out0, size_t in_pitch, size_t out_pitch, int n_frames,
     const VfHipDeinterlaceParams *prm, void *stream)
 {
-  int rc = deint_check (h, in, out, prm);
+  int rc = deint_check (h, in0, out0, prm);
   if (rc) return rc;
+  if (n_frames < 1 || n_frames > 65535) return set_error (VFHIP_ERR_INVALID, "n_frames %d outside 1..65535", n_frames);
   std::lock_guard<std::mutex> lk (h->mu);
   VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
   hipStream_t s = stream ? (hipStream_t) stream : h->st.s_compute;
-  // history = the previous input frame, kept in one of two internal device images and filled by a stream-ordered
-  // device-to-device copy (the reference blits _inputRGBA -> _prevFrameRGBA, :394-405).  Writing the history from
-  // inside the kernel was measured 3x SLOWER (2-byte stores per lane: 9.2 k vs 27.3 k frames/s on NV12 2160p).
   size_t total = 0, off[VFHIP_MAX_PLANES] = { 0 };
-  const int np = format_n_planes (in->info.format);
-  for (int p = 0; p < np; p++) { off[p] = total; total += (frame_plane_bytes (in, p) + 255) / 256 * 256; }
+  const int np = format_n_planes (in0->info.format);
+  for (int p = 0; p < np; p++) { off[p] = total; total += (frame_plane_bytes (in0, p) + 255) / 256 * 256; }
   if (h->hist_bytes < total) {
     for (int k = 0; k < 2; k++) { if (h->hist[k]) (void) hipFree (h->hist[k]); h->hist[k] = nullptr; }
     h->hist_bytes = 0; h->has_prev = false;
     for (int k = 0; k < 2; k++) VFHIP_CHECK_HIP (hipMalloc (&h->hist[k], total));
     h->hist_bytes = total;
   }
-  VfHipFrame next = *in;
+  VfHipFrame next = *in0;
   const int nxt = 1 - h->hist_cur;
   for (int p = 0; p < np; p++) next.data[p] = (uint8_t *) h->hist[nxt] + off[p];
-  if ((rc = deint_launch (h, in, h->has_prev ? &h->prev_dev : nullptr, out, prm, s))) return rc;
+  if ((rc = deint_launch (h, in0, h->has_prev ? &h->prev_dev : nullptr, out0, prm, s, n_frames, in_pitch, out_pitch))) return rc;
+  const size_t last = (size_t) (n_frames - 1) * in_pitch;
   for (int p = 0; p < np; p++)
-    VFHIP_CHECK_HIP (hipMemcpyAsync (next.data[p], in->data[p], frame_plane_bytes (in, p), hipMemcpyDeviceToDevice, s));
+    VFHIP_CHECK_HIP (hipMemcpyAsync (next.data[p], (const uint8_t *) in0->data[p] + last, frame_plane_bytes (in0, p), hipMemcpyDeviceToDevice, s));
   h->prev_dev = next; h->hist_cur = nxt;
   h->has_prev = true;
   return VFHIP_OK;
+}
+
+int vfhip_deinterlace_process_device (VfHipDeinterlace *h, const VfHipFrame *in, VfHipFrame *out,
+    const VfHipDeinterlaceParams *prm, void *stream)
+{
+  return deint_device (h, in, out, 0, 0, 1, prm, stream);
+}
+
+int vfhip_deinterlace_process_device_batch (VfHipDeinterlace *h, const VfHipFrame *in0, VfHipFrame *out0,
+    size_t in_frame_pitch, size_t out_frame_pitch, int n_frames, const VfHipDeinterlaceParams *prm, void *stream)
+{
+  return deint_device (h, in0, out0, in_frame_pitch, out_frame_pitch, n_frames, prm, stream);
 }
 
 void vfhip_deinterlace_cleanup (VfHipDeinterlace *h)

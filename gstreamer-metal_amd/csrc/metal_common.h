@@ -268,6 +268,10 @@ __device__ __forceinline__ void store_block (const OutImg &o, int bx, int by, co
 }
 
 // host helpers: VfHipFrame -> device image descriptors
+// frame k of a batch: every plane pointer advanced by k * frame pitch (wave-uniform, scalar arithmetic)
+__device__ __forceinline__ Img img_at (const Img &im, size_t off) { Img r = im; r.p[0] += off; r.p[1] += off; r.p[2] += off; return r; }
+__device__ __forceinline__ OutImg out_at (const OutImg &im, size_t off) { OutImg r = im; r.p[0] += off; r.p[1] += off; r.p[2] += off; return r; }
+
 static inline Img make_img (const VfHipFrame *f)
 {
   Img im {};

@@ -14,10 +14,13 @@ struct TransformKParams {
   metal::Img in;
   metal::OutImg out;
   float m0, m1, m2, m3, offx, offy;
+  size_t in_pitch, out_pitch;      // batch: frame blockIdx.z at base + z * pitch
 };
 
-__global__ __launch_bounds__ (256) void k_transform (const TransformKParams p)
+__global__ __launch_bounds__ (256) void k_transform (const TransformKParams pp)
 {
+  TransformKParams p = pp;
+  p.in = metal::img_at (pp.in, blockIdx.z * pp.in_pitch); p.out = metal::out_at (pp.out, blockIdx.z * pp.out_pitch);
   const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
   if (2 * bx >= p.out.w || 2 * by >= p.out.h) return;
   uint32_t q[2][2];
@@ -52,9 +55,11 @@ static const float kTransformMat[8][4] = {
   { -1,  0,  0,  1 }, {  1,  0,  0, -1 }, {  0,  1,  1,  0 }, {  0, -1, -1,  0 },
 };
 
-static int tr_launch (VfHipTransform *h, const VfHipFrame *in, VfHipFrame *out, const VfHipTransformParams *prm, hipStream_t s)
+static int tr_launch (VfHipTransform *h, const VfHipFrame *in, VfHipFrame *out, const VfHipTransformParams *prm, hipStream_t s,
+    int n_frames = 1, size_t in_pitch = 0, size_t out_pitch = 0)
 {
   TransformKParams p {};
+  p.in_pitch = in_pitch; p.out_pitch = out_pitch;
   p.in = metal::make_img (in); p.out = metal::make_out (out);
   const float cl = (float) prm->crop_left / (float) h->in.width, cr = (float) prm->crop_right / (float) h->in.width;
   const float ct = (float) prm->crop_top / (float) h->in.height, cb = (float) prm->crop_bottom / (float) h->in.height;
@@ -63,7 +68,7 @@ static int tr_launch (VfHipTransform *h, const VfHipFrame *in, VfHipFrame *out, 
   p.m0 = t[0] * sx; p.m1 = t[1] * sx; p.m2 = t[2] * sy; p.m3 = t[3] * sy;
   p.offx = t[0] * ox + t[2] * oy + 0.0f; p.offy = t[1] * ox + t[3] * oy + 0.0f;
   const int bw = (h->out.width + 1) / 2, bh = (h->out.height + 1) / 2;
-  dim3 grid ((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4));
+  dim3 grid ((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4), (unsigned) n_frames);
   hipLaunchKernelGGL (k_transform, grid, dim3 (64, 4), 0, s, p);
   VFHIP_CHECK_HIP (hipGetLastError ());
   return VFHIP_OK;
@@ -129,6 +134,17 @@ int vfhip_transform_process_device (VfHipTransform *h, const VfHipFrame *in, VfH
   std::lock_guard<std::mutex> lk (h->mu);
   VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
   return tr_launch (h, in, out, prm, stream ? (hipStream_t) stream : h->st.s_compute);
+}
+
+int vfhip_transform_process_device_batch (VfHipTransform *h, const VfHipFrame *in0, VfHipFrame *out0,
+    size_t in_frame_pitch, size_t out_frame_pitch, int n_frames, const VfHipTransformParams *prm, void *stream)
+{
+  int rc = tr_check (h, in0, out0, prm);
+  if (rc) return rc;
+  if (n_frames < 1 || n_frames > 65535) return set_error (VFHIP_ERR_INVALID, "n_frames %d outside 1..65535", n_frames);
+  std::lock_guard<std::mutex> lk (h->mu);
+  VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
+  return tr_launch (h, in0, out0, prm, stream ? (hipStream_t) stream : h->st.s_compute, n_frames, in_frame_pitch, out_frame_pitch);
 }
 
 void vfhip_transform_cleanup (VfHipTransform *h)

@@ -27,7 +27,18 @@ struct VfParams {
   VfHipVideoFilterParams u;
   const float4 *lut;
   int lut_size;
+  size_t in_pitch, out_pitch;      // batch: frame blockIdx.z at base + z * pitch, frame_index + z
 };
+
+// this launch's frame of the batch
+__device__ __forceinline__ VfParams vf_frame (const VfParams &p)
+{
+  VfParams q = p;
+  q.in = metal::img_at (p.in, blockIdx.z * p.in_pitch);
+  q.out = metal::out_at (p.out, blockIdx.z * p.out_pitch);
+  q.u.frame_index += blockIdx.z;
+  return q;
+}
 
 using metal::F4;
 using metal::clamp01;
@@ -165,8 +176,9 @@ __device__ __forceinline__ uint32_t vf_pass1 (const VfParams &p, int x, int y)
   return metal::quant_rgba8 (c);
 }
 
-__global__ __launch_bounds__ (256) void k_vf_point (const VfParams p)
+__global__ __launch_bounds__ (256) void k_vf_point (const VfParams pp)
 {
+  const VfParams p = vf_frame (pp);
   const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
   if (2 * bx >= p.out.w || 2 * by >= p.out.h) return;
   uint32_t q[2][2];
@@ -181,8 +193,9 @@ constexpr int VF_TW = 64, VF_TH = 16, VF_HALO = 4;
 constexpr int VF_RW = VF_TW + 2 * VF_HALO, VF_RH = VF_TH + 2 * VF_HALO;
 __constant__ float kBlurW[9] = { 0.028532f, 0.067234f, 0.124009f, 0.179044f, 0.20236f, 0.179044f, 0.124009f, 0.067234f, 0.028532f };
 
-__global__ __launch_bounds__ (256) void k_vf_sharp (const VfParams p)
+__global__ __launch_bounds__ (256) void k_vf_sharp (const VfParams pp)
 {
+  const VfParams p = vf_frame (pp);
   __shared__ uint32_t rt[VF_RH][VF_RW];       // pass-1 render target, tile + halo (clamped to the image like the blur's reads)
   __shared__ uint32_t hb[VF_RH][VF_TW];       // horizontal blur (8-bit, like _blurTemp)
   __shared__ uint32_t fin[VF_TH][VF_TW];      // unsharp result (8-bit)
@@ -259,18 +272,20 @@ struct VfHipVideoFilter {
   int lut_size = 0;
 };
 
-static int vf_launch (VfHipVideoFilter *h, const VfHipFrame *in, VfHipFrame *out, const VfHipVideoFilterParams *prm, hipStream_t s)
+static int vf_launch (VfHipVideoFilter *h, const VfHipFrame *in, VfHipFrame *out, const VfHipVideoFilterParams *prm, hipStream_t s,
+    int n_frames = 1, size_t in_pitch = 0, size_t out_pitch = 0)
 {
   VfParams p {};
+  p.in_pitch = in_pitch; p.out_pitch = out_pitch;
   p.in = metal::make_img (in); p.out = metal::make_out (out);
   p.u = *prm; p.lut = h->d_lut; p.lut_size = h->lut_size;
   const int w = h->out.width, hh = h->out.height;
   if (prm->sharpness < -0.001f || prm->sharpness > 0.001f) {
-    dim3 grid ((unsigned) ((w + VF_TW - 1) / VF_TW), (unsigned) ((hh + VF_TH - 1) / VF_TH));
+    dim3 grid ((unsigned) ((w + VF_TW - 1) / VF_TW), (unsigned) ((hh + VF_TH - 1) / VF_TH), (unsigned) n_frames);
     hipLaunchKernelGGL (k_vf_sharp, grid, dim3 (256), 0, s, p);
   } else {
     const int bw = (w + 1) / 2, bh = (hh + 1) / 2;
-    dim3 grid ((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4));
+    dim3 grid ((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4), (unsigned) n_frames);
     hipLaunchKernelGGL (k_vf_point, grid, dim3 (64, 4), 0, s, p);
   }
   VFHIP_CHECK_HIP (hipGetLastError ());
@@ -354,6 +369,17 @@ int vfhip_videofilter_process_device (VfHipVideoFilter *h, const VfHipFrame *in,
   std::lock_guard<std::mutex> lk (h->mu);
   VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
   return vf_launch (h, in, out, prm, stream ? (hipStream_t) stream : h->st.s_compute);
+}
+
+int vfhip_videofilter_process_device_batch (VfHipVideoFilter *h, const VfHipFrame *in0, VfHipFrame *out0,
+    size_t in_frame_pitch, size_t out_frame_pitch, int n_frames, const VfHipVideoFilterParams *prm, void *stream)
+{
+  int rc = vf_check (h, in0, out0, prm);
+  if (rc) return rc;
+  if (n_frames < 1 || n_frames > 65535) return set_error (VFHIP_ERR_INVALID, "n_frames %d outside 1..65535", n_frames);
+  std::lock_guard<std::mutex> lk (h->mu);
+  VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
+  return vf_launch (h, in0, out0, prm, stream ? (hipStream_t) stream : h->st.s_compute, n_frames, in_frame_pitch, out_frame_pitch);
 }
 
 int vfhip_videofilter_set_lut (VfHipVideoFilter *h, const float *rgba, int size)

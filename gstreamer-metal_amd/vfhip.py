@@ -82,6 +82,12 @@ def _load():
     lib.vfhip_transform_configure.argtypes = [C.c_void_p, C.POINTER(VideoInfo), C.POINTER(VideoInfo)]
     lib.vfhip_transform_process.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(Frame), C.POINTER(TransformParams)]
     lib.vfhip_transform_process_device.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(Frame), C.POINTER(TransformParams), C.c_void_p]
+    batch = [C.c_void_p, C.POINTER(Frame), C.POINTER(Frame), C.c_size_t, C.c_size_t, C.c_int]
+    lib.vfhip_deinterlace_process_device_batch.argtypes = batch + [C.POINTER(DeinterlaceParams), C.c_void_p]
+    lib.vfhip_videofilter_process_device_batch.argtypes = batch + [C.POINTER(VideoFilterParams), C.c_void_p]
+    lib.vfhip_transform_process_device_batch.argtypes = batch + [C.POINTER(TransformParams), C.c_void_p]
+    lib.vfhip_compositor_composite_device_batch.argtypes = [C.c_void_p, C.POINTER(PadInput), C.POINTER(C.c_size_t), C.c_int, C.c_int,
+                                                            C.POINTER(Frame), C.c_size_t, C.c_int, C.c_void_p]
     lib.vfhip_transform_cleanup.argtypes = [C.c_void_p]
     lib.vfhip_transform_free.argtypes = [C.c_void_p]
     for n in ("vfhip_deinterlace_reset", "vfhip_deinterlace_cleanup", "vfhip_deinterlace_free", "vfhip_videofilter_clear_lut",
@@ -285,11 +291,12 @@ class Deinterlace(_Element):
         check(lib.vfhip_deinterlace_process(self.h, C.byref(fi), C.byref(fo), C.byref(prm)))
         return out
 
-    def process_device(self, in_ptr, out_ptr, method="bob", tff=True, threshold=0.1, stream=None):
+    def process_device(self, in_ptr, out_ptr, method="bob", tff=True, threshold=0.1, stream=None, n_frames=1, in_pitch=0, out_pitch=0):
+        """n_frames > 1: consecutive frames of one stream, frame k at ptr + k * pitch (history of k = frame k-1)"""
         fi = frame_from_base(self.info, self.fmt, self.w, self.hh, in_ptr)
         fo = frame_from_base(self.info, self.fmt, self.w, self.hh, out_ptr)
         prm = DeinterlaceParams(DEINTERLACE_METHODS[method], int(tff), threshold, 0)
-        check(lib.vfhip_deinterlace_process_device(self.h, C.byref(fi), C.byref(fo), C.byref(prm), stream))
+        check(lib.vfhip_deinterlace_process_device_batch(self.h, C.byref(fi), C.byref(fo), in_pitch, out_pitch, n_frames, C.byref(prm), stream))
 
     def reset(self):
         check(lib.vfhip_deinterlace_reset(self.h))
@@ -320,10 +327,11 @@ class VideoFilter(_Element):
         check(lib.vfhip_videofilter_process(self.h, C.byref(fi), C.byref(fo), C.byref(params)))
         return out
 
-    def process_device(self, in_ptr, out_ptr, params, stream=None):
+    def process_device(self, in_ptr, out_ptr, params, stream=None, n_frames=1, in_pitch=0, out_pitch=0):
+        """n_frames > 1: frame k at ptr + k * pitch, filtered with frame_index + k"""
         fi = frame_from_base(self.in_info, self.in_fmt, self.w, self.hh, in_ptr)
         fo = frame_from_base(self.out_info, self.out_fmt, self.w, self.hh, out_ptr)
-        check(lib.vfhip_videofilter_process_device(self.h, C.byref(fi), C.byref(fo), C.byref(params), stream))
+        check(lib.vfhip_videofilter_process_device_batch(self.h, C.byref(fi), C.byref(fo), in_pitch, out_pitch, n_frames, C.byref(params), stream))
 
     def load_lut(self, path):
         check(lib.vfhip_videofilter_load_lut(self.h, path.encode()))
@@ -376,10 +384,16 @@ class Compositor(_Element):
         check(lib.vfhip_compositor_composite(self.h, arr, len(pads), BACKGROUNDS[background], C.byref(fo)))
         return out
 
-    def composite_device(self, pad_structs, out_ptr, background="checker", stream=None):
+    def composite_device(self, pad_structs, out_ptr, background="checker", stream=None, n_frames=1, pad_pitches=None, out_pitch=0):
+        """n_frames > 1: pad i's frame k at its base + k * pad_pitches[i], output frame k at out_ptr + k * out_pitch"""
         arr = (PadInput * max(len(pad_structs), 1))(*pad_structs)
         fo = frame_from_base(self.info, self.fmt, self.w, self.hh, out_ptr)
-        check(lib.vfhip_compositor_composite_device(self.h, arr, len(pad_structs), BACKGROUNDS[background], C.byref(fo), stream))
+        if n_frames == 1 and pad_pitches is None:
+            check(lib.vfhip_compositor_composite_device(self.h, arr, len(pad_structs), BACKGROUNDS[background], C.byref(fo), stream))
+            return
+        pit = (C.c_size_t * max(len(pad_structs), 1))(*(pad_pitches or [0] * len(pad_structs)))
+        check(lib.vfhip_compositor_composite_device_batch(self.h, arr, pit, len(pad_structs), BACKGROUNDS[background], C.byref(fo), out_pitch,
+                                                          n_frames, stream))
 
 
 TRANSFORM_METHODS = {"none": 0, "clockwise": 1, "rotate-180": 2, "counterclockwise": 3, "horizontal-flip": 4, "vertical-flip": 5,
@@ -411,3 +425,9 @@ class Transform(_Element):
         prm = TransformParams(TRANSFORM_METHODS[method], *crop)
         check(lib.vfhip_transform_process(self.h, C.byref(fi), C.byref(fo), C.byref(prm)))
         return out
+
+    def process_device(self, in_ptr, out_ptr, method="none", crop=(0, 0, 0, 0), stream=None, n_frames=1, in_pitch=0, out_pitch=0):
+        fi = frame_from_base(self.in_info, self.in_fmt, self.w, self.hh, in_ptr)
+        fo = frame_from_base(self.out_info, self.out_fmt, self.w, self.hh, out_ptr)
+        prm = TransformParams(TRANSFORM_METHODS[method], *crop)
+        check(lib.vfhip_transform_process_device_batch(self.h, C.byref(fi), C.byref(fo), in_pitch, out_pitch, n_frames, C.byref(prm), stream))

@@ -166,6 +166,10 @@ int vfhip_deinterlace_process (VfHipDeinterlace *h, const VfHipFrame *in, VfHipF
 /* device frames, asynchronous; the previous input frame is kept in an internal device buffer (stream-ordered copy) */
 int vfhip_deinterlace_process_device (VfHipDeinterlace *h, const VfHipFrame *in, VfHipFrame *out,
     const VfHipDeinterlaceParams *params, void *stream);
+/* batch of n consecutive frames of ONE stream (frame k at data[p] + k * pitch): the history of frame k is frame k-1 of the
+ * batch, of frame 0 the handle's stored history; afterwards the history is the last frame of the batch */
+int vfhip_deinterlace_process_device_batch (VfHipDeinterlace *h, const VfHipFrame *in0, VfHipFrame *out0,
+    size_t in_frame_pitch, size_t out_frame_pitch, int n_frames, const VfHipDeinterlaceParams *params, void *stream);
 int vfhip_deinterlace_reset (VfHipDeinterlace *h);                                            /* drop the 1-frame history */
 void vfhip_deinterlace_cleanup (VfHipDeinterlace *h);
 void vfhip_deinterlace_free (VfHipDeinterlace *h);
@@ -188,6 +192,9 @@ int vfhip_videofilter_configure (VfHipVideoFilter *h, const VfHipVideoInfo *in, 
 int vfhip_videofilter_process (VfHipVideoFilter *h, const VfHipFrame *in, VfHipFrame *out, const VfHipVideoFilterParams *params);
 int vfhip_videofilter_process_device (VfHipVideoFilter *h, const VfHipFrame *in, VfHipFrame *out,
     const VfHipVideoFilterParams *params, void *stream);
+/* batch: frame k at data[p] + k * pitch, filtered with params->frame_index + k */
+int vfhip_videofilter_process_device_batch (VfHipVideoFilter *h, const VfHipFrame *in0, VfHipFrame *out0,
+    size_t in_frame_pitch, size_t out_frame_pitch, int n_frames, const VfHipVideoFilterParams *params, void *stream);
 int vfhip_videofilter_load_lut (VfHipVideoFilter *h, const char *path);                       /* -loadLUTFromFile: (.cube only) */
 int vfhip_videofilter_set_lut (VfHipVideoFilter *h, const float *rgba, int size);             /* size^3 RGBA32F, R fastest */
 void vfhip_videofilter_clear_lut (VfHipVideoFilter *h);
@@ -213,6 +220,10 @@ int vfhip_compositor_configure (VfHipCompositor *h, const VfHipVideoInfo *out); 
 int vfhip_compositor_composite (VfHipCompositor *h, const VfHipPadInput *inputs, int count, int background, VfHipFrame *out);
 int vfhip_compositor_composite_device (VfHipCompositor *h, const VfHipPadInput *inputs, int count, int background,
     VfHipFrame *out, void *stream);
+/* batch: pad i's frame k at inputs[i].frame.data[p] + k * pad_frame_pitch[i] (0 = the same frame every time), output frame k
+ * at out0->data[p] + k * out_frame_pitch; at most 16 pads */
+int vfhip_compositor_composite_device_batch (VfHipCompositor *h, const VfHipPadInput *inputs, const size_t *pad_frame_pitch, int count,
+    int background, VfHipFrame *out0, size_t out_frame_pitch, int n_frames, void *stream);
 void vfhip_compositor_cleanup (VfHipCompositor *h);
 void vfhip_compositor_free (VfHipCompositor *h);
 
@@ -241,6 +252,8 @@ int vfhip_transform_configure (VfHipTransform *h, const VfHipVideoInfo *in, cons
 int vfhip_transform_process (VfHipTransform *h, const VfHipFrame *in, VfHipFrame *out, const VfHipTransformParams *params);
 int vfhip_transform_process_device (VfHipTransform *h, const VfHipFrame *in, VfHipFrame *out,
     const VfHipTransformParams *params, void *stream);
+int vfhip_transform_process_device_batch (VfHipTransform *h, const VfHipFrame *in0, VfHipFrame *out0,
+    size_t in_frame_pitch, size_t out_frame_pitch, int n_frames, const VfHipTransformParams *params, void *stream);
 void vfhip_transform_cleanup (VfHipTransform *h);
 void vfhip_transform_free (VfHipTransform *h);
 

@@ -351,3 +351,108 @@ def test_zz_report_exactness():
     """not a check: prints how close to bit-exact the float kernels are against the oracle (pytest -s / -rP shows it)"""
     worst = sorted(STATS, key=lambda t: -t[2])[:8]
     print("comparisons:", len(STATS), "bit-exact:", sum(1 for t in STATS if t[1] == 0), "worst off-by-one fractions:", worst)
+
+
+# ---- batched device entry points (frame k at base + k * pitch): every frame of a batch == the oracle on that frame ------
+def _ring(frames, pitch):
+    import torch
+    buf = np.zeros((len(frames), pitch), np.uint8)
+    for k, f in enumerate(frames):
+        buf[k, :f.size] = f
+    return torch.from_numpy(buf).cuda()
+
+
+@pytest.mark.parametrize("fmt", ["BGRA", "NV12", "I420"])
+def test_deinterlace_batch_is_a_stream(vfhip, metalref, fmt):
+    """a batch is n consecutive frames of one stream: history of frame k = frame k-1, and the handle's history carries
+    across batches (two batches of 3 == six sequential frames)"""
+    import torch
+    w, h, n = 130, 74, 6
+    size = ol.raw_layout(fmt, w, h)[1]
+    pitch = (size + 255) // 256 * 256
+    frames = [smooth(fmt, w, h, 40 + k) for k in range(n)]
+    d = vfhip.Deinterlace(0)
+    d.configure(fmt, w, h)
+    s = torch.cuda.Stream()
+    din, dout = _ring(frames, pitch), torch.zeros((n, pitch), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for b in range(2):
+        d.process_device(din[3 * b].data_ptr(), dout[3 * b].data_ptr(), method="greedyh", tff=False, threshold=0.05, stream=s.cuda_stream,
+                         n_frames=3, in_pitch=pitch, out_pitch=pitch)
+    s.synchronize()
+    out = dout.cpu().numpy()
+    for k in range(n):
+        want = metalref.deinterlace(fmt, w, h, frames[k], frames[k - 1] if k else None, 3, tff=False, threshold=0.05)
+        close(out[k, :size], want, f"batch deinterlace {fmt} frame {k}")
+    d.close()
+
+
+@pytest.mark.parametrize("sharp", [0.0, 0.6])
+def test_videofilter_batch(vfhip, metalref, sharp):
+    import torch
+    w, h, n = 100, 44, 4
+    size = 4 * w * h
+    pitch = (size + 255) // 256 * 256
+    frames = [smooth("RGBA", w, h, 60 + k) for k in range(n)]
+    vf = vfhip.VideoFilter(0)
+    vf.configure("RGBA", w, h, "NV12")
+    osize = ol.raw_layout("NV12", w, h)[1]
+    opitch = (osize + 255) // 256 * 256
+    kw = dict(brightness=0.05, contrast=1.1, gamma=1.3, noise=0.2, vignette=0.4, sharpness=sharp, frame_index=7)
+    prm = vfhip.filter_params(**kw)
+    s = torch.cuda.Stream()
+    din, dout = _ring(frames, pitch), torch.zeros((n, opitch), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    vf.process_device(din.data_ptr(), dout.data_ptr(), prm, stream=s.cuda_stream, n_frames=n, in_pitch=pitch, out_pitch=opitch)
+    s.synchronize()
+    out = dout.cpu().numpy()
+    for k in range(n):
+        pk = ol.mr_filter_params(vfhip.filter_params(**dict(kw, frame_index=7 + k)))      # frame_index advances per frame
+        want = metalref.videofilter("RGBA", w, h, frames[k], "NV12", pk)
+        close(out[k, :osize], want, f"batch videofilter frame {k}", max_off_by_one=0.05)
+    vf.close()
+
+
+def test_compositor_batch(vfhip, metalref):
+    import torch
+    ow, oh, n = 96, 64, 3
+    a = [smooth("BGRA", 64, 48, 70 + k) for k in range(n)]
+    b = [smooth("NV12", 40, 30, 80 + k) for k in range(n)]
+    logo = smooth("RGBA", 16, 16, 90)                          # pitch 0: the same frame in every output
+    pa, pb = (a[0].size + 255) // 256 * 256, (b[0].size + 255) // 256 * 256
+    da, db, dl = _ring(a, pa), _ring(b, pb), torch.from_numpy(logo).cuda()
+    dout = torch.zeros((n, ow * oh * 4), dtype=torch.uint8, device="cuda")
+    comp = vfhip.Compositor(0)
+    comp.configure("BGRA", ow, oh)
+    pads = [comp.pad("BGRA", 64, 48, da.data_ptr(), 0, 0, 64, 48, 0.9, "over"),
+            comp.pad("NV12", 40, 30, db.data_ptr(), 30, 20, 60, 40, 0.7, "add"),
+            comp.pad("RGBA", 16, 16, dl.data_ptr(), 70, 4, 16, 16, 1.0, "over")]
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    comp.composite_device(pads, dout.data_ptr(), background="checker", stream=s.cuda_stream, n_frames=n, pad_pitches=[pa, pb, 0], out_pitch=ow * oh * 4)
+    s.synchronize()
+    out = dout.cpu().numpy()
+    for k in range(n):
+        want = metalref.compositor("BGRA", ow, oh, [("BGRA", 64, 48, a[k], 0, 0, 64, 48, 0.9, 1), ("NV12", 40, 30, b[k], 30, 20, 60, 40, 0.7, 2),
+                                                    ("RGBA", 16, 16, logo, 70, 4, 16, 16, 1.0, 1)], 0)
+        close(out[k], want, f"batch compositor frame {k}")
+    comp.close()
+
+
+def test_transform_batch(vfhip, metalref):
+    import torch
+    w, h, n = 66, 38, 3
+    size = ol.raw_layout("I420", w, h)[1]
+    pitch = (size + 255) // 256 * 256
+    frames = [smooth("I420", w, h, 95 + k) for k in range(n)]
+    t = vfhip.Transform(0)
+    t.configure("I420", w, h)
+    din, dout = _ring(frames, pitch), torch.zeros((n, pitch), dtype=torch.uint8, device="cuda")
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    t.process_device(din.data_ptr(), dout.data_ptr(), method="rotate-180", crop=(2, 4, 6, 0), stream=s.cuda_stream, n_frames=n, in_pitch=pitch, out_pitch=pitch)
+    s.synchronize()
+    out = dout.cpu().numpy()
+    for k in range(n):
+        close(out[k, :size], metalref.transform("I420", w, h, frames[k], "I420", 2, crop=(2, 4, 6, 0)), f"batch transform frame {k}")
+    t.close()

@@ -59,17 +59,17 @@ def main():
     prm = vfhip.filter_params(brightness=0.1, contrast=1.2, saturation=0.8, hue=0.3 * math.pi, gamma=1.5, sharpness=0.5, sepia=0.2,
                               noise=0.1, vignette=0.3, invert=True, chroma_key=(0.0, 1.0, 0.0), tolerance=0.3, smoothness=0.1)
 
+    vp = fin.shape[1]
+
     def c3():
-        for k in range(R):
-            vf.process_device(fin[k].data_ptr(), fout[k].data_ptr(), prm, stream=s.cuda_stream)
-    report("C3 videofilter BGRA 1080p all-15 + 33^3 LUT", "k_vf_sharp", timed(c3, s, 3), R, 2 * 4 * w * h)
+        vf.process_device(fin.data_ptr(), fout.data_ptr(), prm, stream=s.cuda_stream, n_frames=R, in_pitch=vp, out_pitch=vp)
+    report("C3 videofilter BGRA 1080p all-15 + 33^3 LUT", "k_vf_sharp", timed(c3, s, 5), R, 2 * 4 * w * h)
     prm0 = vfhip.filter_params(brightness=0.1, contrast=1.2, saturation=0.8, gamma=1.5)
 
     def c3b():
-        for k in range(R):
-            vf.process_device(fin[k].data_ptr(), fout[k].data_ptr(), prm0, stream=s.cuda_stream)
+        vf.process_device(fin.data_ptr(), fout.data_ptr(), prm0, stream=s.cuda_stream, n_frames=R, in_pitch=vp, out_pitch=vp)
     vf.clear_lut()
-    report("videofilter BGRA 1080p colour-only (no blur, no LUT)", "k_vf_point", timed(c3b, s, 3), R, 2 * 4 * w * h)
+    report("videofilter BGRA 1080p colour-only (no blur, no LUT)", "k_vf_point", timed(c3b, s, 5), R, 2 * 4 * w * h)
     vf.close()
     del fin, fout
 
@@ -80,27 +80,31 @@ def main():
     d = vfhip.Deinterlace(0)
     d.configure("NV12", w, h)
 
+    dp = din.shape[1]
+
     def c5():
-        for k in range(R):
-            d.process_device(din[k].data_ptr(), dout[k].data_ptr(), method="greedyh", tff=True, threshold=0.1, stream=s.cuda_stream)
-    report("C5a deinterlace greedyh NV12 2160p (+ history copy)", "k_deinterlace", timed(c5, s, 3), R, 3 * size)
+        d.process_device(din.data_ptr(), dout.data_ptr(), method="greedyh", tff=True, threshold=0.1, stream=s.cuda_stream,
+                         n_frames=R, in_pitch=dp, out_pitch=dp)
+    report("C5a deinterlace greedyh NV12 2160p (batch = one stream's consecutive frames)", "k_deinterlace_420", timed(c5, s, 5), R, 3 * size)
     d.close()
     del din, dout
 
     # C4: compositor 4 x BGRA 1080p (alpha .9, over) + NV12 720p centred (alpha .7) -> BGRA 2160p, black background
     ow, oh = 3840, 2160
-    quads = [ring(4, 4 * 1920 * 1080, 10 + k) for k in range(4)]
-    nv = ring(4, vfhip.plane_layout("NV12", 1280, 720)[1], 20)
-    out = ring(4, 4 * ow * oh, 21)
+    NC = 8
+    quads = [ring(NC, 4 * 1920 * 1080, 10 + k) for k in range(4)]
+    nv = ring(NC, vfhip.plane_layout("NV12", 1280, 720)[1], 20)
+    out = ring(NC, 4 * ow * oh, 21)
     comp = vfhip.Compositor(0)
     comp.configure("BGRA", ow, oh)
 
+    pads = [comp.pad("BGRA", 1920, 1080, quads[q].data_ptr(), (q % 2) * 1920, (q // 2) * 1080, 1920, 1080, 0.9, "over") for q in range(4)]
+    pads.append(comp.pad("NV12", 1280, 720, nv.data_ptr(), (ow - 1280) // 2, (oh - 720) // 2, 1280, 720, 0.7, "over", "bt709"))
+    pitches = [quads[q].shape[1] for q in range(4)] + [nv.shape[1]]
+
     def c4():
-        for k in range(4):
-            pads = [comp.pad("BGRA", 1920, 1080, quads[q][k].data_ptr(), (q % 2) * 1920, (q // 2) * 1080, 1920, 1080, 0.9, "over") for q in range(4)]
-            pads.append(comp.pad("NV12", 1280, 720, nv[k].data_ptr(), (ow - 1280) // 2, (oh - 720) // 2, 1280, 720, 0.7, "over", "bt709"))
-            comp.composite_device(pads, out[k].data_ptr(), background="black", stream=s.cuda_stream)
-    report("C4 compositor 4xBGRA1080p + NV12 720p -> BGRA 2160p", "k_compositor", timed(c4, s, 3), 4, 4 * 4 * 1920 * 1080 + 1280 * 720 * 3 // 2 + 4 * ow * oh)
+        comp.composite_device(pads, out.data_ptr(), background="black", stream=s.cuda_stream, n_frames=NC, pad_pitches=pitches, out_pitch=out.shape[1])
+    report("C4 compositor 4xBGRA1080p + NV12 720p -> BGRA 2160p", "k_compositor", timed(c4, s, 5), NC, 4 * 4 * 1920 * 1080 + 1280 * 720 * 3 // 2 + 4 * ow * oh)
     comp.close()
     del quads, nv, out
 
@@ -151,7 +155,9 @@ def e2e():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "e2e":
+    if len(sys.argv) > 1 and sys.argv[1] == "main":
+        main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "e2e":
         e2e()
     else:
         main()
