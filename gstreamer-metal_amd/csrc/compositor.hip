@@ -216,7 +216,7 @@ int vfhip_compositor_composite (VfHipCompositor *h, const VfHipPadInput *pads, i
   for (int k = 0; k < count; k++)                     // slot k + 1 per pad (slot-indexed like the reference's texture cache)
     if ((rc = upload_frame (h->st, (size_t) k + 1, &pads[k].frame, &dpads[k].frame))) return rc;
   VfHipFrame dout;
-  if ((rc = alloc_device_frame (h->st, 0, &h->out, &dout))) return rc;
+  if ((rc = output_frame (h->st, 0, &h->out, out, &dout))) return rc;
   if (count > 0) VFHIP_CHECK_HIP (hipStreamWaitEvent (h->st.s_compute, h->st.ev_h2d, 0));
   if ((rc = comp_launch (h, dpads.data (), count, background, &dout, h->st.s_compute))) return rc;
   VFHIP_CHECK_HIP (hipEventRecord (h->st.ev_compute, h->st.s_compute));

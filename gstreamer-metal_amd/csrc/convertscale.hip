@@ -441,7 +441,7 @@ int vfhip_convertscale_process (VfHipConvertScale *h, const VfHipFrame *in, VfHi
   VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
   VfHipFrame din, dout;
   if ((rc = upload_frame (h->st, 0, in, &din))) return rc;                 // pinned staging + async H2D on the h2d stream
-  if ((rc = alloc_device_frame (h->st, 1, &h->out, &dout))) return rc;
+  if ((rc = output_frame (h->st, 1, &h->out, out, &dout))) return rc;
   VFHIP_CHECK_HIP (hipStreamWaitEvent (h->st.s_compute, h->st.ev_h2d, 0));
   if ((rc = launch_device (h, &din, &dout, 0, 0, 1, h->st.s_compute))) return rc;
   VFHIP_CHECK_HIP (hipEventRecord (h->st.ev_compute, h->st.s_compute));

@@ -217,6 +217,9 @@ static int deint_check (VfHipDeinterlace *h, const VfHipFrame *in, const VfHipFr
   return check_frame (out, &h->info, "output");
 }
 
+static int deint_device_locked (VfHipDeinterlace *h, const VfHipFrame *in0, VfHipFrame *out0, size_t in_pitch, size_t out_pitch, int n_frames,
+    const VfHipDeinterlaceParams *prm, hipStream_t s);
+
 extern "C" {
 
 VfHipDeinterlace *vfhip_deinterlace_new (int device)
@@ -260,9 +263,18 @@ int vfhip_deinterlace_process (VfHipDeinterlace *h, const VfHipFrame *in, VfHipF
   std::lock_guard<std::mutex> lk (h->mu);
   VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
   VfHipFrame din, dout;
+  if (in->flags & VFHIP_FRAME_FLAG_DEVICE) {
+    // device-resident input (memory:HIPMemory buffer): it belongs to the caller and may be recycled after this call,
+    // so the history is copied device-to-device like in the process_device path
+    if ((rc = upload_frame (h->st, 0, in, &din))) return rc;              // validates; no copy
+    if ((rc = output_frame (h->st, 2, &h->info, out, &dout))) return rc;
+    if ((rc = deint_device_locked (h, &din, &dout, 0, 0, 1, prm, h->st.s_compute))) return rc;
+    VFHIP_CHECK_HIP (hipEventRecord (h->st.ev_compute, h->st.s_compute));
+    return download_frame (h->st, 2, &dout, out);
+  }
   const int slot = h->cur_slot;                         // slots 0/1 alternate: no device copy for the history
   if ((rc = upload_frame (h->st, slot, in, &din))) return rc;
-  if ((rc = alloc_device_frame (h->st, 2, &h->info, &dout))) return rc;
+  if ((rc = output_frame (h->st, 2, &h->info, out, &dout))) return rc;
   VFHIP_CHECK_HIP (hipStreamWaitEvent (h->st.s_compute, h->st.ev_h2d, 0));
   if ((rc = deint_launch (h, &din, h->has_prev ? &h->prev_dev : nullptr, &dout, prm, h->st.s_compute))) return rc;
   VFHIP_CHECK_HIP (hipEventRecord (h->st.ev_compute, h->st.s_compute));
@@ -275,15 +287,10 @@ int vfhip_deinterlace_process (VfHipDeinterlace *h, const VfHipFrame *in, VfHipF
 // device-to-device copy (the reference blits _inputRGBA -> _prevFrameRGBA, :394-405).  Writing the history from
 // inside the kernel was measured 3x SLOWER (2-byte stores per lane: 9.2 k vs 27.3 k frames/s on NV12 2160p).
 // In a batch the history of frame k is frame k-1 of the batch itself; only the LAST frame is copied.
-static int deint_device (VfHipDeinterlace *h, const VfHipFrame *in0, VfHipFrame *out0, size_t in_pitch, size_t out_pitch, int n_frames,
-    const VfHipDeinterlaceParams *prm, void *stream)
+static int deint_device_locked (VfHipDeinterlace *h, const VfHipFrame *in0, VfHipFrame *out0, size_t in_pitch, size_t out_pitch, int n_frames,
+    const VfHipDeinterlaceParams *prm, hipStream_t s)
 {
-  int rc = deint_check (h, in0, out0, prm);
-  if (rc) return rc;
-  if (n_frames < 1 || n_frames > 65535) return set_error (VFHIP_ERR_INVALID, "n_frames %d outside 1..65535", n_frames);
-  std::lock_guard<std::mutex> lk (h->mu);
-  VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
-  hipStream_t s = stream ? (hipStream_t) stream : h->st.s_compute;
+  int rc;
   size_t total = 0, off[VFHIP_MAX_PLANES] = { 0 };
   const int np = format_n_planes (in0->info.format);
   for (int p = 0; p < np; p++) { off[p] = total; total += (frame_plane_bytes (in0, p) + 255) / 256 * 256; }
@@ -303,6 +310,17 @@ static int deint_device (VfHipDeinterlace *h, const VfHipFrame *in0, VfHipFrame 
   h->prev_dev = next; h->hist_cur = nxt;
   h->has_prev = true;
   return VFHIP_OK;
+}
+
+static int deint_device (VfHipDeinterlace *h, const VfHipFrame *in0, VfHipFrame *out0, size_t in_pitch, size_t out_pitch, int n_frames,
+    const VfHipDeinterlaceParams *prm, void *stream)
+{
+  int rc = deint_check (h, in0, out0, prm);
+  if (rc) return rc;
+  if (n_frames < 1 || n_frames > 65535) return set_error (VFHIP_ERR_INVALID, "n_frames %d outside 1..65535", n_frames);
+  std::lock_guard<std::mutex> lk (h->mu);
+  VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
+  return deint_device_locked (h, in0, out0, in_pitch, out_pitch, n_frames, prm, stream ? (hipStream_t) stream : h->st.s_compute);
 }
 
 int vfhip_deinterlace_process_device (VfHipDeinterlace *h, const VfHipFrame *in, VfHipFrame *out,

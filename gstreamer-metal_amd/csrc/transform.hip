@@ -120,7 +120,7 @@ int vfhip_transform_process (VfHipTransform *h, const VfHipFrame *in, VfHipFrame
   VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
   VfHipFrame din, dout;
   if ((rc = upload_frame (h->st, 0, in, &din))) return rc;
-  if ((rc = alloc_device_frame (h->st, 1, &h->out, &dout))) return rc;
+  if ((rc = output_frame (h->st, 1, &h->out, out, &dout))) return rc;
   VFHIP_CHECK_HIP (hipStreamWaitEvent (h->st.s_compute, h->st.ev_h2d, 0));
   if ((rc = tr_launch (h, &din, &dout, prm, h->st.s_compute))) return rc;
   VFHIP_CHECK_HIP (hipEventRecord (h->st.ev_compute, h->st.s_compute));

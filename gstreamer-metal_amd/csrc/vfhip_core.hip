@@ -182,8 +182,42 @@ static bool is_pinned_host (const void *p)
   return a.type == hipMemoryTypeHost;
 }
 
+// device-resident frames (VFHIP_FRAME_FLAG_DEVICE) are used in place; alignment is what the kernels' 2- and 4-byte
+// accesses need
+static int check_device_frame (const VfHipFrame *f, const char *what)
+{
+  const int np = format_n_planes (f->info.format);
+  if (np < 0) return np;
+  const uintptr_t need = (f->info.format == VFHIP_FORMAT_BGRA || f->info.format == VFHIP_FORMAT_RGBA) ? 3u : 1u;
+  for (int p = 0; p < np; p++) {
+    if (!f->data[p]) return set_error (VFHIP_ERR_INVALID, "%s plane %d is NULL", what, p);
+    if (f->stride[p] < plane_width_bytes (f->info.format, p, f->info.width)) return set_error (VFHIP_ERR_INVALID, "%s plane %d: short stride", what, p);
+    if (((uintptr_t) f->data[p] | (uintptr_t) f->stride[p]) & need)
+      return set_error (VFHIP_ERR_INVALID, "%s device plane %d is not %d-byte aligned", what, p, (int) need + 1);
+  }
+  return VFHIP_OK;
+}
+
+int output_frame (Staging &st, size_t slot, const VfHipVideoInfo *info, const VfHipFrame *out, VfHipFrame *df)
+{
+  if (out && (out->flags & VFHIP_FRAME_FLAG_DEVICE)) {
+    int rc = check_device_frame (out, "output");
+    if (rc) return rc;
+    *df = *out;
+    return VFHIP_OK;
+  }
+  return alloc_device_frame (st, slot, info, df);
+}
+
 int upload_frame (Staging &st, size_t slot, const VfHipFrame *host, VfHipFrame *df)
 {
+  if (host->flags & VFHIP_FRAME_FLAG_DEVICE) {            // already on the GPU: nothing to copy
+    int rc = check_device_frame (host, "input");
+    if (rc) return rc;
+    *df = *host;
+    VFHIP_CHECK_HIP (hipEventRecord (st.ev_h2d, st.s_h2d));
+    return VFHIP_OK;
+  }
   size_t off[VFHIP_MAX_PLANES], total; int stride[VFHIP_MAX_PLANES];
   int np = device_layout (&host->info, off, stride, &total);
   if (np < 0) return np;
@@ -215,6 +249,10 @@ int upload_frame (Staging &st, size_t slot, const VfHipFrame *host, VfHipFrame *
 
 int download_frame (Staging &st, size_t slot, const VfHipFrame *df, VfHipFrame *host)
 {
+  if (host->flags & VFHIP_FRAME_FLAG_DEVICE) {            // the kernel wrote the caller's device frame in place (output_frame)
+    VFHIP_CHECK_HIP (hipStreamSynchronize (st.s_compute));
+    return VFHIP_OK;
+  }
   size_t off[VFHIP_MAX_PLANES], total; int stride[VFHIP_MAX_PLANES];
   int np = device_layout (&host->info, off, stride, &total);
   if (np < 0) return np;

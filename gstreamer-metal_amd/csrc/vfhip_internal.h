@@ -56,6 +56,9 @@ bool format_is_yuv (int format);
 int upload_frame (Staging &st, size_t slot, const VfHipFrame *host, VfHipFrame *dev_frame);
 // allocate a device image for an output frame of the given info (aligned strides)
 int alloc_device_frame (Staging &st, size_t slot, const VfHipVideoInfo *info, VfHipFrame *dev_frame);
+// the device image a kernel should write: the caller's own frame when it is device-resident (VFHIP_FRAME_FLAG_DEVICE),
+// else a staging image like alloc_device_frame
+int output_frame (Staging &st, size_t slot, const VfHipVideoInfo *info, const VfHipFrame *out, VfHipFrame *dev_frame);
 // download a device image into host frame planes (honours the host strides); synchronises
 int download_frame (Staging &st, size_t slot, const VfHipFrame *dev_frame, VfHipFrame *host);
 

@@ -354,7 +354,7 @@ int vfhip_videofilter_process (VfHipVideoFilter *h, const VfHipFrame *in, VfHipF
   VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
   VfHipFrame din, dout;
   if ((rc = upload_frame (h->st, 0, in, &din))) return rc;
-  if ((rc = alloc_device_frame (h->st, 1, &h->out, &dout))) return rc;
+  if ((rc = output_frame (h->st, 1, &h->out, out, &dout))) return rc;
   VFHIP_CHECK_HIP (hipStreamWaitEvent (h->st.s_compute, h->st.ev_h2d, 0));
   if ((rc = vf_launch (h, &din, &dout, prm, h->st.s_compute))) return rc;
   VFHIP_CHECK_HIP (hipEventRecord (h->st.ev_compute, h->st.s_compute));

@@ -88,6 +88,11 @@ typedef struct {
 } VfHipVideoInfo;
 
 #define VFHIP_FRAME_FLAG_TFF 0x1u   /* GST_VIDEO_BUFFER_FLAG_TFF (deinterlace/gstvfmetaldeinterlace.m:176-184) */
+/* data[] are DEVICE pointers on the handle's GPU (a `memory:HIPMemory` GstBuffer of an upstream / downstream vfhip
+ * element): the synchronous *_process / _composite entry points then skip the PCIe copy on that
+ * side — no upload for such an input, the kernel writes such an output in place — and still return only when the
+ * output is complete.  RGBA / BGRA planes must be 4-byte aligned, 4:2:0 and packed-YUV planes 2-byte aligned. */
+#define VFHIP_FRAME_FLAG_DEVICE 0x2u
 
 typedef struct {
   VfHipVideoInfo info;

@@ -1,0 +1,133 @@
+"""VFHIP_FRAME_FLAG_DEVICE: the synchronous entry points accept device-resident frames on either side (what the
+plugin's `memory:HIPMemory` buffers carry) and produce the same bytes as with host frames."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+DEVICE = 2
+
+
+def smooth(fmt, w, h, seed):
+    from test_metal_elements_gpu import smooth as s
+    return s(fmt, w, h, seed)
+
+
+def dev_frame(vfhip, info, fmt, w, h, tensor):
+    f = vfhip.frame_from_base(info, fmt, w, h, tensor.data_ptr())
+    f.flags |= DEVICE
+    return f
+
+
+@pytest.mark.parametrize("din,dout", [(True, True), (True, False), (False, True)])
+def test_convertscale_device_frames(vfhip, din, dout):
+    import torch
+    w, h, ow, oh = 256, 128, 128, 64
+    raw = smooth("NV12", w, h, 1)
+    cs = vfhip.ConvertScale(0)
+    cs.configure("NV12", w, h, "BGRA", ow, oh, colorimetry="bt601", chroma_site="jpeg")
+    want = cs.process(raw)
+    tin = torch.from_numpy(raw).cuda()
+    tout = torch.zeros(ow * oh * 4, dtype=torch.uint8, device="cuda")
+    hout = np.zeros(ow * oh * 4, np.uint8)
+    torch.cuda.synchronize()
+    fi = dev_frame(vfhip, cs.in_info, "NV12", w, h, tin) if din else vfhip.frame_from_base(cs.in_info, "NV12", w, h, raw.ctypes.data)
+    fo = dev_frame(vfhip, cs.out_info, "BGRA", ow, oh, tout) if dout else vfhip.frame_from_base(cs.out_info, "BGRA", ow, oh, hout.ctypes.data)
+    vfhip.check(vfhip.lib.vfhip_convertscale_process(cs.h, C.byref(fi), C.byref(fo)))
+    got = tout.cpu().numpy() if dout else hout            # complete on return: no extra synchronisation here
+    assert np.array_equal(got.reshape(want.shape), want)
+    cs.close()
+
+
+def test_chain_stays_on_device(vfhip, metalref):
+    """deinterlace -> convertscale -> videofilter -> transform with device frames in between == the same chain through
+    host frames (what a gst-launch pipeline of vfhip elements negotiating memory:HIPMemory does)"""
+    import torch
+    w, h = 128, 72
+    frames = [smooth("NV12", w, h, 10 + k) for k in range(3)]
+    d, d2 = vfhip.Deinterlace(0), vfhip.Deinterlace(0)
+    cs, vf, tr = vfhip.ConvertScale(0), vfhip.VideoFilter(0), vfhip.Transform(0)
+    for x in (d, d2):
+        x.configure("NV12", w, h)
+    cs.configure("NV12", w, h, "RGBA", 64, 36, numerics="metal")
+    vf.configure("RGBA", 64, 36)
+    tr.configure("RGBA", 64, 36)
+    prm = vfhip.filter_params(brightness=0.1, sharpness=0.4, gamma=1.3)
+    dprm = vfhip.DeinterlaceParams(vfhip.DEINTERLACE_METHODS["greedyh"], 1, 0.05, 0)
+    tprm = vfhip.TransformParams(vfhip.TRANSFORM_METHODS["horizontal-flip"], 0, 0, 0, 0)
+    size = ol.raw_layout("NV12", w, h)[1]
+    for raw in frames:
+        # host chain
+        a = d.process(raw, method="greedyh", tff=True, threshold=0.05)
+        b = cs.process(a)
+        c = vf.process(b, prm)
+        want = tr.process(c, method="horizontal-flip")
+        # device chain: one upload, one download
+        t0 = torch.zeros(size, dtype=torch.uint8, device="cuda")
+        t1 = torch.zeros(64 * 36 * 4, dtype=torch.uint8, device="cuda")
+        t2 = torch.zeros(64 * 36 * 4, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        hin = vfhip.frame_from_base(d2.info, "NV12", w, h, raw.ctypes.data)
+        f0 = dev_frame(vfhip, d2.info, "NV12", w, h, t0)
+        vfhip.check(vfhip.lib.vfhip_deinterlace_process(d2.h, C.byref(hin), C.byref(f0), C.byref(dprm)))
+        f1 = dev_frame(vfhip, cs.out_info, "RGBA", 64, 36, t1)
+        vfhip.check(vfhip.lib.vfhip_convertscale_process(cs.h, C.byref(f0), C.byref(f1)))
+        f2 = dev_frame(vfhip, vf.out_info, "RGBA", 64, 36, t2)
+        vfhip.check(vfhip.lib.vfhip_videofilter_process(vf.h, C.byref(f1), C.byref(f2), C.byref(prm)))
+        got = np.zeros(64 * 36 * 4, np.uint8)
+        hout = vfhip.frame_from_base(tr.out_info, "RGBA", 64, 36, got.ctypes.data)
+        vfhip.check(vfhip.lib.vfhip_transform_process(tr.h, C.byref(f2), C.byref(hout), C.byref(tprm)))
+        assert np.array_equal(got, want)
+    for x in (d, d2, cs, vf, tr):
+        x.close()
+
+
+def test_deinterlace_device_input_keeps_history(vfhip, metalref):
+    import torch
+    fmt, w, h = "I420", 64, 40
+    size = ol.raw_layout(fmt, w, h)[1]
+    frames = [smooth(fmt, w, h, 30 + k) for k in range(3)]
+    d = vfhip.Deinterlace(0)
+    d.configure(fmt, w, h)
+    prm = vfhip.DeinterlaceParams(vfhip.DEINTERLACE_METHODS["weave"], 1, 0.1, 0)
+    t = torch.zeros(size, dtype=torch.uint8, device="cuda")          # ONE input buffer, overwritten per frame (recycled pool buffer)
+    prev = None
+    for raw in frames:
+        t.copy_(torch.from_numpy(raw))
+        torch.cuda.synchronize()
+        fi = dev_frame(vfhip, d.info, fmt, w, h, t)
+        got = np.zeros(size, np.uint8)
+        fo = vfhip.frame_from_base(d.info, fmt, w, h, got.ctypes.data)
+        vfhip.check(vfhip.lib.vfhip_deinterlace_process(d.h, C.byref(fi), C.byref(fo), C.byref(prm)))
+        want = metalref.deinterlace(fmt, w, h, raw, prev, 1, tff=True)
+        assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+        prev = raw
+    d.close()
+
+
+def test_compositor_device_pads_and_misaligned_device_frame(vfhip, metalref):
+    import torch
+    a, b = smooth("BGRA", 64, 48, 1), smooth("NV12", 32, 24, 2)
+    comp = vfhip.Compositor(0)
+    comp.configure("BGRA", 64, 48)
+    want = comp.composite([("BGRA", 64, 48, a, 0, 0, 64, 48, 1.0, "over"), ("NV12", 32, 24, b, 10, 10, 32, 24, 0.5, "over")], background="black")
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    tout = torch.zeros(64 * 48 * 4 + 4, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    pa = comp.pad("BGRA", 64, 48, ta.data_ptr(), 0, 0, 64, 48, 1.0, "over")
+    pb = comp.pad("NV12", 32, 24, tb.data_ptr(), 10, 10, 32, 24, 0.5, "over")
+    pa.frame.flags |= DEVICE
+    pb.frame.flags |= DEVICE
+    arr = (vfhip.PadInput * 2)(pa, pb)
+    fo = vfhip.frame_from_base(comp.info, "BGRA", 64, 48, tout.data_ptr())
+    fo.flags |= DEVICE
+    vfhip.check(vfhip.lib.vfhip_compositor_composite(comp.h, arr, 2, vfhip.BACKGROUNDS["black"], C.byref(fo)))
+    assert np.array_equal(tout[:64 * 48 * 4].cpu().numpy(), want)
+    bad = vfhip.frame_from_base(comp.info, "BGRA", 64, 48, tout.data_ptr() + 1)           # BGRA needs 4-byte alignment
+    bad.flags |= DEVICE
+    rc = vfhip.lib.vfhip_compositor_composite(comp.h, arr, 2, vfhip.BACKGROUNDS["black"], C.byref(bad))
+    assert rc == -1 and b"aligned" in vfhip.lib.vfhip_last_error_string()
+    comp.close()
