@@ -30,6 +30,18 @@ gboolean gst_vfhip_propose_allocation (struct _GstBaseTransform * trans, GstQuer
 gboolean gst_vfhip_decide_allocation (struct _GstBaseTransform * trans, GstQuery * query,
     gboolean (*parent) (struct _GstBaseTransform *, GstQuery *));
 
+/* device-resident buffers: caps feature memory:HIPMemory (gstvfhipmemory.c) */
+#define GST_CAPS_FEATURE_MEMORY_HIP "memory:HIPMemory"
+#define GST_MAP_VFHIP ((GstMapFlags) (GST_MAP_FLAG_LAST << 3))     /* map a device GstMemory to its DEVICE pointer */
+/* template caps: both memories, device memory first */
+#define GST_VFHIP_CAPS(formats) GST_VIDEO_CAPS_MAKE_WITH_FEATURES (GST_CAPS_FEATURE_MEMORY_HIP, formats) "; " GST_VIDEO_CAPS_MAKE (formats)
+GstAllocator *gst_vfhip_device_allocator_get (gint device);
+gboolean gst_vfhip_is_device_memory (GstMemory * mem);
+gboolean gst_vfhip_caps_has_hip_feature (GstCaps * caps);
+GstCaps *gst_vfhip_caps_both_memories (GstCaps * caps);
+GstCaps *gst_vfhip_filter_transform_caps (struct _GstBaseTransform * trans, GstPadDirection direction, GstCaps * caps, GstCaps * filter);
+GstFlowReturn gst_vfhip_filter_transform (struct _GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf);
+
 /* new, additive properties every vfhip element has */
 #define GST_VFHIP_DEFAULT_DEVICE_ID (-1)       /* -1: $VFHIP_DEVICE, else GPU 0 */
 
@@ -78,6 +90,9 @@ gst_vfhip_frame (GstVideoFrame * gf, VfHipFrame * vf)
   }
   if (gf->buffer && GST_BUFFER_FLAG_IS_SET (gf->buffer, GST_VIDEO_BUFFER_FLAG_TFF))
     vf->flags |= VFHIP_FRAME_FLAG_TFF;
+  /* mapped with GST_MAP_VFHIP from a memory:HIPMemory buffer: the plane pointers are device pointers */
+  if (gf->buffer && (gf->map[0].flags & GST_MAP_VFHIP) && gst_vfhip_is_device_memory (gst_buffer_peek_memory (gf->buffer, 0)))
+    vf->flags |= VFHIP_FRAME_FLAG_DEVICE;
 }
 
 G_END_DECLS

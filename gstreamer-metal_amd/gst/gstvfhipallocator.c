@@ -116,8 +116,12 @@ gst_vfhip_propose_allocation (GstBaseTransform * trans, GstQuery * decide_query,
   if (!parent (trans, decide_query, query))
     return FALSE;
   if (decide_query != NULL) {                                 /* not in passthrough */
-    GstAllocator *a = gst_vfhip_pinned_allocator_get ();
+    GstCaps *caps = NULL;
+    GstAllocator *a;
     GstAllocationParams params;
+    gst_query_parse_allocation (query, &caps, NULL);
+    /* memory:HIPMemory negotiated on our sink pad: upstream should hand us device buffers */
+    a = gst_vfhip_caps_has_hip_feature (caps) ? gst_vfhip_device_allocator_get (-1) : gst_vfhip_pinned_allocator_get ();
     gst_allocation_params_init (&params);
     params.align = 63;
     gst_query_add_allocation_param (query, a, &params);
@@ -127,12 +131,21 @@ gst_vfhip_propose_allocation (GstBaseTransform * trans, GstQuery * decide_query,
   return TRUE;
 }
 
-/* GstBaseTransform::decide_allocation: our own output buffers come from the pinned allocator */
+/* GstBaseTransform::decide_allocation: our own output buffers come from the pinned allocator, or — when the src caps
+ * carry memory:HIPMemory — from the device allocator (any pool downstream proposed for system memory is dropped then) */
 gboolean
 gst_vfhip_decide_allocation (GstBaseTransform * trans, GstQuery * query, gboolean (*parent) (GstBaseTransform *, GstQuery *))
 {
-  GstAllocator *a = gst_vfhip_pinned_allocator_get ();
+  GstCaps *caps = NULL;
+  GstAllocator *a;
   GstAllocationParams params;
+  gst_query_parse_allocation (query, &caps, NULL);
+  if (gst_vfhip_caps_has_hip_feature (caps)) {
+    a = gst_vfhip_device_allocator_get (-1);
+    while (gst_query_get_n_allocation_pools (query) > 0)
+      gst_query_remove_nth_allocation_pool (query, 0);
+  } else
+    a = gst_vfhip_pinned_allocator_get ();
   gst_allocation_params_init (&params);
   params.align = 63;
   if (gst_query_get_n_allocation_params (query) > 0)

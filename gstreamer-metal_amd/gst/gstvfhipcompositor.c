@@ -692,8 +692,9 @@ enum { PROP_0, PROP_BACKGROUND, PROP_ZERO_SIZE_IS_UNSCALED, PROP_DEVICE_ID };
 
 static GstStaticPadTemplate comp_src_template = GST_STATIC_PAD_TEMPLATE ("src", GST_PAD_SRC, GST_PAD_ALWAYS,
     GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE (VFHIP_COMP_FORMATS)));
+/* sink pads also take memory:HIPMemory buffers from upstream vfhip elements (gstvfhipmemory.c) */
 static GstStaticPadTemplate comp_sink_template = GST_STATIC_PAD_TEMPLATE ("sink_%u", GST_PAD_SINK, GST_PAD_REQUEST,
-    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE (VFHIP_COMP_FORMATS)));
+    GST_STATIC_CAPS (GST_VFHIP_CAPS (VFHIP_COMP_FORMATS)));
 
 static void comp_child_proxy_init (gpointer g_iface, gpointer iface_data);
 G_DEFINE_TYPE_WITH_CODE (GstVfHipCompositor, gst_vfhip_compositor, GST_TYPE_AGGREGATOR,
@@ -897,7 +898,7 @@ comp_aggregate (GstAggregator * agg, gboolean timeout)
     bufs[i] = gst_aggregator_pad_pop_buffer (GST_AGGREGATOR_PAD (cpad));
     if (!bufs[i] || !cpad->have_info || cpad->alpha == 0.0)
       continue;
-    if (!gst_video_frame_map (&frames[i], &cpad->info, bufs[i], GST_MAP_READ))
+    if (!gst_video_frame_map (&frames[i], &cpad->info, bufs[i], (GstMapFlags) (GST_MAP_READ | GST_MAP_VFHIP)))
       continue;
     comp_pad_rect (self, cpad, GST_VIDEO_INFO_PAR_N (&self->out_info), GST_VIDEO_INFO_PAR_D (&self->out_info), &w, &h, &xo, &yo);
     gst_vfhip_frame (&frames[i], &pads[used].frame);

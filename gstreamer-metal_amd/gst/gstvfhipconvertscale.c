@@ -38,9 +38,9 @@ typedef struct
 enum { PROP_0, PROP_METHOD, PROP_ADD_BORDERS, PROP_BORDER_COLOR, PROP_DEVICE_ID, PROP_NUMERICS };
 
 static GstStaticPadTemplate cs_sink_template = GST_STATIC_PAD_TEMPLATE ("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
-    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE (VFHIP_CS_FORMATS)));
+    GST_STATIC_CAPS (GST_VFHIP_CAPS (VFHIP_CS_FORMATS)));
 static GstStaticPadTemplate cs_src_template = GST_STATIC_PAD_TEMPLATE ("src", GST_PAD_SRC, GST_PAD_ALWAYS,
-    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE (VFHIP_CS_FORMATS)));
+    GST_STATIC_CAPS (GST_VFHIP_CAPS (VFHIP_CS_FORMATS)));
 
 static GType
 scale_method_type (void)
@@ -73,12 +73,13 @@ gst_vfhip_numerics_get_type (void)
 G_DEFINE_TYPE (GstVfHipConvertScale, gst_vfhip_convertscale, GST_TYPE_BASE_TRANSFORM);
 #define CS(obj) ((GstVfHipConvertScale *) (obj))
 
-/* any of the six formats at any size converts to any other: drop what we can change, keep the rest (framerate ...) */
+/* any of the six formats at any size, in either memory, converts to any other: drop what we can change, keep the rest
+ * (framerate ...) */
 static GstCaps *
 cs_transform_caps (GstBaseTransform * trans, GstPadDirection direction, GstCaps * caps, GstCaps * filter)
 {
   static const gchar *formats[] = { "BGRA", "RGBA", "NV12", "I420", "UYVY", "YUY2" };
-  GstCaps *res = gst_caps_new_empty ();
+  GstCaps *res = gst_caps_new_empty (), *both;
   guint i, k, n = gst_caps_get_size (caps);
   (void) trans; (void) direction;
   for (i = 0; i < n; i++) {
@@ -97,6 +98,9 @@ cs_transform_caps (GstBaseTransform * trans, GstPadDirection direction, GstCaps 
     gst_structure_set (st, "width", GST_TYPE_INT_RANGE, 1, G_MAXINT, "height", GST_TYPE_INT_RANGE, 1, G_MAXINT, NULL);
     gst_caps_append_structure (res, st);
   }
+  both = gst_vfhip_caps_both_memories (res);
+  gst_caps_unref (res);
+  res = both;
   if (filter) {
     GstCaps *tmp = gst_caps_intersect_full (res, filter, GST_CAPS_INTERSECT_FIRST);
     gst_caps_unref (res);
@@ -225,9 +229,9 @@ cs_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
     GST_WARNING_OBJECT (self, "no HIP renderer");
     return GST_FLOW_ERROR;
   }
-  if (!gst_video_frame_map (&in, &self->in_info, inbuf, GST_MAP_READ))
+  if (!gst_video_frame_map (&in, &self->in_info, inbuf, (GstMapFlags) (GST_MAP_READ | GST_MAP_VFHIP)))
     return GST_FLOW_ERROR;
-  if (!gst_video_frame_map (&out, &self->out_info, outbuf, GST_MAP_WRITE)) {
+  if (!gst_video_frame_map (&out, &self->out_info, outbuf, (GstMapFlags) (GST_MAP_WRITE | GST_MAP_VFHIP))) {
     gst_video_frame_unmap (&in);
     return GST_FLOW_ERROR;
   }

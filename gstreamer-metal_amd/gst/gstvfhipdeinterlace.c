@@ -31,9 +31,9 @@ enum { PROP_0, PROP_METHOD, PROP_FIELD_LAYOUT, PROP_MOTION_THRESHOLD, PROP_DEVIC
 enum { FIELDS_AUTO = 0, FIELDS_TFF = 1, FIELDS_BFF = 2 };
 
 static GstStaticPadTemplate di_sink_template = GST_STATIC_PAD_TEMPLATE ("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
-    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE (VFHIP_DI_FORMATS)));
+    GST_STATIC_CAPS (GST_VFHIP_CAPS (VFHIP_DI_FORMATS)));
 static GstStaticPadTemplate di_src_template = GST_STATIC_PAD_TEMPLATE ("src", GST_PAD_SRC, GST_PAD_ALWAYS,
-    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE (VFHIP_DI_FORMATS)));
+    GST_STATIC_CAPS (GST_VFHIP_CAPS (VFHIP_DI_FORMATS)));
 
 static GType
 di_method_type (void)
@@ -191,6 +191,9 @@ gst_vfhip_deinterlace_class_init (GstVfHipDeinterlaceClass * klass)
   GST_BASE_TRANSFORM_CLASS (klass)->stop = GST_DEBUG_FUNCPTR (di_stop);
   GST_VIDEO_FILTER_CLASS (klass)->set_info = GST_DEBUG_FUNCPTR (di_set_info);
   GST_VIDEO_FILTER_CLASS (klass)->transform_frame = GST_DEBUG_FUNCPTR (di_transform_frame);
+  /* memory:HIPMemory on either pad (gstvfhipmemory.c): same video caps in both memories, device buffers mapped in place */
+  GST_BASE_TRANSFORM_CLASS (klass)->transform_caps = GST_DEBUG_FUNCPTR (gst_vfhip_filter_transform_caps);
+  GST_BASE_TRANSFORM_CLASS (klass)->transform = GST_DEBUG_FUNCPTR (gst_vfhip_filter_transform);
 
   g_object_class_install_property (oc, PROP_METHOD, g_param_spec_enum ("method", "Method", "Deinterlacing algorithm",
           di_method_type (), VFHIP_DEINTERLACE_BOB, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));

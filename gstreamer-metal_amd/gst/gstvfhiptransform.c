@@ -27,9 +27,9 @@ typedef struct
 enum { PROP_0, PROP_METHOD, PROP_CROP_TOP, PROP_CROP_BOTTOM, PROP_CROP_LEFT, PROP_CROP_RIGHT, PROP_DEVICE_ID };
 
 static GstStaticPadTemplate tr_sink_template = GST_STATIC_PAD_TEMPLATE ("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
-    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE (VFHIP_TR_FORMATS)));
+    GST_STATIC_CAPS (GST_VFHIP_CAPS (VFHIP_TR_FORMATS)));
 static GstStaticPadTemplate tr_src_template = GST_STATIC_PAD_TEMPLATE ("src", GST_PAD_SRC, GST_PAD_ALWAYS,
-    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE (VFHIP_TR_FORMATS)));
+    GST_STATIC_CAPS (GST_VFHIP_CAPS (VFHIP_TR_FORMATS)));
 
 static GType
 tr_method_type (void)
@@ -196,6 +196,9 @@ gst_vfhip_transform_class_init (GstVfHipTransformClass * klass)
   bc->decide_allocation = GST_DEBUG_FUNCPTR (tr_decide_allocation);
   GST_VIDEO_FILTER_CLASS (klass)->set_info = GST_DEBUG_FUNCPTR (tr_set_info);
   GST_VIDEO_FILTER_CLASS (klass)->transform_frame = GST_DEBUG_FUNCPTR (tr_transform_frame);
+  /* memory:HIPMemory on either pad (gstvfhipmemory.c): same video caps in both memories, device buffers mapped in place */
+  GST_BASE_TRANSFORM_CLASS (klass)->transform_caps = GST_DEBUG_FUNCPTR (gst_vfhip_filter_transform_caps);
+  GST_BASE_TRANSFORM_CLASS (klass)->transform = GST_DEBUG_FUNCPTR (gst_vfhip_filter_transform);
 
   g_object_class_install_property (oc, PROP_METHOD, g_param_spec_enum ("method", "Method", "Flip/rotation method", tr_method_type (),
           VFHIP_TRANSFORM_IDENTITY, f));

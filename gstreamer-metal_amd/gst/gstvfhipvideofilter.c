@@ -41,9 +41,9 @@ enum
 };
 
 static GstStaticPadTemplate vf_sink_template = GST_STATIC_PAD_TEMPLATE ("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
-    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE (VFHIP_VF_FORMATS)));
+    GST_STATIC_CAPS (GST_VFHIP_CAPS (VFHIP_VF_FORMATS)));
 static GstStaticPadTemplate vf_src_template = GST_STATIC_PAD_TEMPLATE ("src", GST_PAD_SRC, GST_PAD_ALWAYS,
-    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE (VFHIP_VF_FORMATS)));
+    GST_STATIC_CAPS (GST_VFHIP_CAPS (VFHIP_VF_FORMATS)));
 
 G_DEFINE_TYPE (GstVfHipVideoFilter, gst_vfhip_videofilter, GST_TYPE_VIDEO_FILTER);
 #define VF(obj) ((GstVfHipVideoFilter *) (obj))
@@ -268,6 +268,9 @@ gst_vfhip_videofilter_class_init (GstVfHipVideoFilterClass * klass)
   bc->stop = GST_DEBUG_FUNCPTR (vf_stop);
   fc->set_info = GST_DEBUG_FUNCPTR (vf_set_info);
   fc->transform_frame = GST_DEBUG_FUNCPTR (vf_transform_frame);
+  /* memory:HIPMemory on either pad (gstvfhipmemory.c): same video caps in both memories, device buffers mapped in place */
+  GST_BASE_TRANSFORM_CLASS (klass)->transform_caps = GST_DEBUG_FUNCPTR (gst_vfhip_filter_transform_caps);
+  GST_BASE_TRANSFORM_CLASS (klass)->transform = GST_DEBUG_FUNCPTR (gst_vfhip_filter_transform);
 
   DPROP (PROP_BRIGHTNESS, "brightness", "Brightness", "Brightness adjustment (-1.0 to 1.0)", -1.0, 1.0, 0.0);
   DPROP (PROP_CONTRAST, "contrast", "Contrast", "Contrast adjustment (0.0 to 2.0, 1.0 = normal)", 0.0, 2.0, 1.0);

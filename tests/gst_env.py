@@ -25,8 +25,9 @@ def env():
     return e
 
 
-def launch(pipeline, timeout=120):
-    return subprocess.run(f"{GST_LAUNCH} -q {pipeline}", shell=True, env=env(), capture_output=True, text=True, timeout=timeout)
+def launch(pipeline, timeout=120, verbose=False):
+    """verbose: gst-launch -v (prints every pad's negotiated caps) instead of -q"""
+    return subprocess.run(f"{GST_LAUNCH} {'-v' if verbose else '-q'} {pipeline}", shell=True, env=env(), capture_output=True, text=True, timeout=timeout)
 
 
 def inspect(what):

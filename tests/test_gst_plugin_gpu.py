@@ -159,3 +159,63 @@ def test_compositor_pixels_match_oracle(tmp_path):
                                                  ("NV12", 160, 120, fb[k * nb:(k + 1) * nb], 100, 60, 160, 120, 0.6, 2)], 1)
         got = fo[k * no:(k + 1) * no]
         assert np.array_equal(want, got), f"frame {k}: {(want != got).sum()} bytes differ, max {np.abs(want.astype(int) - got.astype(int)).max()}"
+
+
+# ---- memory:HIPMemory: chained vfhip elements keep frames in HBM ------------------------------
+def hipcaps(fmt, w, h):
+    return f"'video/x-raw(memory:HIPMemory),format={fmt},width={w},height={h}'"
+
+
+def test_hip_memory_negotiated_between_vfhip_elements():
+    r = gst_env.launch(f"{SRC} ! {caps('NV12', 640, 480)} ! vfhipdeinterlace method=greedyh name=d ! vfhipconvertscale name=c ! {caps('BGRA', 320, 240)} ! fakesink", verbose=True)
+    assert r.returncode == 0, r.stderr
+    link = [l for l in r.stdout.splitlines() if "c.GstPad:sink: caps" in l]
+    assert link and "video/x-raw(memory:HIPMemory)" in link[0], r.stdout[-2000:]
+    src = [l for l in r.stdout.splitlines() if "c.GstPad:src: caps" in l]
+    assert src and "memory:HIPMemory" not in src[0]              # the capsfilter without features means system memory
+
+
+def test_hip_memory_chain_matches_system_memory_chain(tmp_path):
+    """the same 4-element chain with device buffers between the elements and with system-memory caps forced between
+    them writes identical bytes"""
+    a, b = tmp_path / "hip.raw", tmp_path / "sys.raw"
+    chain = ["vfhipdeinterlace method=greedyh field-layout=top-field-first", "vfhipconvertscale numerics=metal", "vfhipvideofilter brightness=0.1 sharpness=0.4",
+             "vfhiptransform method=horizontal-flip"]
+    mid = [caps('NV12', 640, 480), caps('RGBA', 320, 240), caps('RGBA', 320, 240)]
+    hip = " ! ".join(chain[:1] + [f"{chain[1]} ! {hipcaps('RGBA', 320, 240)}"] + chain[2:])
+    sysm = " ! ".join(x for pair in zip(chain, mid + [""]) for x in pair if x)
+    src = f"videotestsrc num-buffers=4 pattern=ball ! {caps('NV12', 640, 480)}"
+    for path, body in ((a, hip), (b, sysm)):
+        r = gst_env.launch(f"{src} ! {body} ! {caps('RGBA', 320, 240)} ! filesink location={path}")
+        assert r.returncode == 0, f"{body}\n{r.stderr}"
+    x, y = np.fromfile(a, np.uint8), np.fromfile(b, np.uint8)
+    assert x.size == y.size == 4 * 320 * 240 * 4
+    assert np.array_equal(x, y)
+
+
+def test_hip_memory_is_cpu_mappable(tmp_path):
+    """a memory:HIPMemory buffer reaching an element that maps it for the CPU (filesink) reads back the frame"""
+    a, b = tmp_path / "hip.raw", tmp_path / "sys.raw"
+    r = gst_env.launch(f"videotestsrc num-buffers=2 ! {caps('NV12', 320, 240)} ! tee name=t "
+                       f"t. ! queue ! vfhipconvertscale ! {hipcaps('BGRA', 160, 120)} ! filesink location={a} "
+                       f"t. ! queue ! vfhipconvertscale ! {caps('BGRA', 160, 120)} ! filesink location={b}")
+    assert r.returncode == 0, r.stderr
+    x, y = np.fromfile(a, np.uint8), np.fromfile(b, np.uint8)
+    assert x.size >= 2 * 160 * 120 * 4 and np.array_equal(x.reshape(2, -1)[:, :160 * 120 * 4], y.reshape(2, -1))
+
+
+def test_hip_memory_to_fakesink_and_passthrough():
+    ok(f"{SRC} ! {caps('NV12', 1920, 1080)} ! vfhipconvertscale ! {hipcaps('BGRA', 640, 360)} ! vfhipvideofilter ! vfhiptransform ! fakesink")
+    ok(f"{SRC} ! {caps('I420', 320, 240)} ! vfhipdeinterlace ! vfhipdeinterlace method=weave ! vfhipconvertscale ! {caps('UYVY', 160, 120)} ! fakesink")
+
+
+def test_compositor_takes_hip_memory_pads(tmp_path):
+    """device buffers from upstream vfhip elements composite to the same bytes as system-memory ones"""
+    a, b = tmp_path / "hip.raw", tmp_path / "sys.raw"
+    for path, mid in ((a, hipcaps('BGRA', 160, 120)), (b, caps('BGRA', 160, 120))):
+        r = gst_env.launch(f"vfhipcompositor name=comp background=black sink_1::xpos=80 sink_1::ypos=60 sink_1::alpha=0.5 ! {caps('BGRA', 320, 240)} ! filesink location={path} "
+                           f"videotestsrc num-buffers=3 ! {caps('BGRA', 320, 240)} ! comp. "
+                           f"videotestsrc num-buffers=3 pattern=ball ! {caps('NV12', 320, 240)} ! vfhipconvertscale numerics=metal ! {mid} ! comp.")
+        assert r.returncode == 0, r.stderr
+    x, y = np.fromfile(a, np.uint8), np.fromfile(b, np.uint8)
+    assert x.size == y.size == 3 * 320 * 240 * 4 and np.array_equal(x, y)

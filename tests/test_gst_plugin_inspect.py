@@ -31,7 +31,9 @@ def test_convertscale_api():
     t = gst_env.inspect("vfhipconvertscale").stdout
     assert {"method", "add-borders", "border-color", "device-id", "numerics"} <= props(t)
     assert "GstBaseTransform" in t and "bilinear" in t and "nearest" in t
-    assert t.count("(string)BGRA, (string)RGBA, (string)NV12, (string)I420, (string)UYVY, (string)YUY2") == 2
+    # both pads: the six formats in system memory and as memory:HIPMemory (device-resident buffers between vfhip elements)
+    assert t.count("(string)BGRA, (string)RGBA, (string)NV12, (string)I420, (string)UYVY, (string)YUY2") == 4
+    assert t.count("video/x-raw(memory:HIPMemory)") == 2
     assert "Default: 4278190080" in t                       # border-color 0xFF000000
 
 
@@ -41,7 +43,7 @@ def test_videofilter_api():
             "chroma-key-enabled", "chroma-key-color", "chroma-key-tolerance", "chroma-key-smoothness", "lut-file"}
     assert want <= props(t) and len(want) == 15
     assert "GstVideoFilter" in t
-    assert t.count("(string)BGRA, (string)RGBA, (string)NV12, (string)I420 }") == 2
+    assert t.count("(string)BGRA, (string)RGBA, (string)NV12, (string)I420 }") == 4 and t.count("video/x-raw(memory:HIPMemory)") == 2
     assert "Range: 0.01 - 10 Default: 1 " in squeeze(t)      # gamma
     assert "Default: 4278255360" in t                       # chroma-key-color 0xFF00FF00
 
@@ -70,7 +72,7 @@ def test_compositor_api():
         assert nick in t
     assert "GstAggregator" in t and "GstChildProxy" in t and "sink_%u" in t and "On request" in t
     assert "primary + 2" in t
-    assert t.count("(string)BGRA, (string)RGBA, (string)NV12, (string)I420 }") == 2
+    assert t.count("(string)BGRA, (string)RGBA, (string)NV12, (string)I420 }") == 3          # src, sink_%u in both memories
     src = open(gst_env.PLUGIN_DIR + "/gstvfhipcompositor.c").read()
     for prop in ("xpos", "ypos", "width", "height", "alpha", "operator", "sizing-policy", "zorder"):
         assert f'("{prop}"' in src

@@ -154,11 +154,53 @@ def e2e():
     cs.close()
 
 
+def e2e_chain():
+    """C5 chain at the element level (synchronous *_process calls, pinned host frames at both ends): deinterlace ->
+    convertscale with the intermediate frame (a) in host memory — what a pipeline of system-memory elements does, four
+    PCIe crossings — and (b) device-resident (memory:HIPMemory between the elements), two crossings"""
+    import ctypes as C
+    import time
+    import numpy as np
+    w, h, ow, oh = 3840, 2160, 1920, 1080
+    in_size, out_size = vfhip.plane_layout("NV12", w, h)[1], 4 * ow * oh
+    d = vfhip.Deinterlace(0)
+    d.configure("NV12", w, h, colorimetry="bt709")
+    cs = vfhip.ConvertScale(0)
+    cs.configure("NV12", w, h, "BGRA", ow, oh, colorimetry="bt2020", chroma_site="mpeg2")
+    pi, pm, po = (vfhip.lib.vfhip_pinned_alloc(0, n) for n in (in_size, in_size, out_size))
+    src = np.ctypeslib.as_array((C.c_uint8 * in_size).from_address(pi))
+    src[:] = np.random.default_rng(0).integers(0, 256, in_size, dtype=np.uint8)
+    dev_mid = torch.zeros(in_size + 256, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    fi = vfhip.frame_from_base(d.info, "NV12", w, h, pi)
+    fm_host = vfhip.frame_from_base(d.info, "NV12", w, h, pm)
+    fm_dev = vfhip.frame_from_base(d.info, "NV12", w, h, dev_mid.data_ptr())
+    fm_dev.flags |= 2                                   # VFHIP_FRAME_FLAG_DEVICE
+    fo = vfhip.frame_from_base(cs.out_info, "BGRA", ow, oh, po)
+    prm = vfhip.DeinterlaceParams(vfhip.DEINTERLACE_METHODS["greedyh"], 1, 0.1, 0)
+    for kind, fm in (("host (system memory between the elements)", fm_host), ("device (memory:HIPMemory between the elements)", fm_dev)):
+        def once():
+            vfhip.check(vfhip.lib.vfhip_deinterlace_process(d.h, C.byref(fi), C.byref(fm), C.byref(prm)))
+            vfhip.check(vfhip.lib.vfhip_convertscale_process(cs.h, C.byref(fm), C.byref(fo)))
+        for _ in range(5):
+            once()
+        n, t0 = 100, time.perf_counter()
+        for _ in range(n):
+            once()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"config": f"C5 chain end-to-end deinterlace greedyh -> convertscale NV12 2160p -> BGRA 1080p, intermediate frame: {kind}",
+                          "frames_per_s": round(n / dt, 1), "ms_per_frame": round(dt / n * 1e3, 3)}), flush=True)
+    d.close()
+    cs.close()
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "main":
         main()
     elif len(sys.argv) > 1 and sys.argv[1] == "e2e":
         e2e()
+        e2e_chain()
     else:
         main()
         e2e()
+        e2e_chain()
