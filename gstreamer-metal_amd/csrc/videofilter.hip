@@ -6,7 +6,7 @@
 // The reference runs 1 render pass + (sharpness != 0) 3 compute passes + 1 RGBA->YUV pass, every one a full
 // trip through an 8-bit texture (metalvideofilterrenderer.m:523-681).  Here:
 //   k_vf_point : sharpness == 0 — one kernel, each lane owns a 2x2 block (needed by the 4:2:0 store epilogue);
-//   k_vf_sharp : sharpness != 0 — one kernel, a 64x16 output tile per workgroup; the colour-adjusted tile plus
+//   k_vf_sharp : sharpness != 0 — one kernel, a 128x32 output tile per workgroup; the colour-adjusted tile plus
 //                its 4-pixel halo is quantised to 8 bits into LDS exactly where the reference wrote its render
 //                target, the 9-tap horizontal and vertical Gaussians and the unsharp mask run out of LDS (with the
 //                reference's 8-bit requantisation between passes), and only the final frame goes to HBM.
@@ -189,20 +189,25 @@ __global__ __launch_bounds__ (256) void k_vf_point (const VfParams pp)
   metal::store_block (p.out, bx, by, q);
 }
 
-constexpr int VF_TW = 64, VF_TH = 16, VF_HALO = 4;
-constexpr int VF_RW = VF_TW + 2 * VF_HALO, VF_RH = VF_TH + 2 * VF_HALO;
+// Tile geometry of k_vf_sharp.  Pass 1 (colour adjustments + LUT, by far the most expensive part) has to be evaluated
+// for the tile AND its 4-pixel halo, so the tile is large: 128x32 + halo = 136x40 -> 1.33x redundancy with 512 lanes and
+// 42 KB of LDS per workgroup (the first version's 64x16 tile was 1.69x; 128x64 with 1024 lanes, 1.195x, measures the
+// same within noise and leaves a single frame with too few workgroups: profiles/r01y_vf_tile_ab.txt).
+constexpr int VF_HALO = 4;
 __constant__ float kBlurW[9] = { 0.028532f, 0.067234f, 0.124009f, 0.179044f, 0.20236f, 0.179044f, 0.124009f, 0.067234f, 0.028532f };
 
-__global__ __launch_bounds__ (256) void k_vf_sharp (const VfParams pp)
+template <int VF_TW, int VF_TH, int VF_THREADS, int MIN_WAVES>
+__global__ __launch_bounds__ (VF_THREADS, MIN_WAVES) void k_vf_sharp (const VfParams pp)
 {
+  constexpr int VF_RW = VF_TW + 2 * VF_HALO, VF_RH = VF_TH + 2 * VF_HALO;
+  constexpr int VF_PER_LANE = VF_TW * VF_TH / VF_THREADS;
   const VfParams p = vf_frame (pp);
   __shared__ uint32_t rt[VF_RH][VF_RW];       // pass-1 render target, tile + halo (clamped to the image like the blur's reads)
-  __shared__ uint32_t hb[VF_RH][VF_TW];       // horizontal blur (8-bit, like _blurTemp)
-  __shared__ uint32_t fin[VF_TH][VF_TW];      // unsharp result (8-bit)
+  __shared__ uint32_t hb[VF_RH][VF_TW];       // horizontal blur (8-bit, like _blurTemp); its first VF_TH rows are reused for the result
   const int x0 = blockIdx.x * VF_TW, y0 = blockIdx.y * VF_TH;
   const int tid = threadIdx.x;
   const int w = p.out.w, h = p.out.h;
-  for (int i = tid; i < VF_RW * VF_RH; i += 256) {
+  for (int i = tid; i < VF_RW * VF_RH; i += VF_THREADS) {
     const int rx = i % VF_RW, ry = i / VF_RW;
     rt[ry][rx] = vf_pass1 (p, x0 - VF_HALO + rx, y0 - VF_HALO + ry);
   }
@@ -210,7 +215,7 @@ __global__ __launch_bounds__ (256) void k_vf_sharp (const VfParams pp)
   // horizontal 9-tap on every row of the region, for the tile's columns.  Reads clamp to the IMAGE (not the region):
   // region column rx holds image column clamp(x0-4+rx), so an unclamped region read is the clamped image read,
   // except that columns right of the image edge inside the tile must not be produced at all.
-  for (int i = tid; i < VF_TW * VF_RH; i += 256) {
+  for (int i = tid; i < VF_TW * VF_RH; i += VF_THREADS) {
     const int tx = i % VF_TW, ry = i / VF_TW;
     F4 s; s.r = s.g = s.b = s.a = 0.0f;
 #pragma unroll
@@ -222,7 +227,10 @@ __global__ __launch_bounds__ (256) void k_vf_sharp (const VfParams pp)
   }
   __syncthreads ();
   const float amount = p.u.sharpness;
-  for (int i = tid; i < VF_TW * VF_TH; i += 256) {
+  uint32_t res[VF_PER_LANE];
+#pragma unroll
+  for (int j = 0; j < VF_PER_LANE; j++) {
+    const int i = tid + j * VF_THREADS;
     const int tx = i % VF_TW, ty = i / VF_TW;
     F4 s; s.r = s.g = s.b = s.a = 0.0f;
 #pragma unroll
@@ -240,11 +248,18 @@ __global__ __launch_bounds__ (256) void k_vf_sharp (const VfParams pp)
       r.r = mixf (o.r, b.r, t); r.g = mixf (o.g, b.g, t); r.b = mixf (o.b, b.b, t);
     }
     r.a = o.a;
-    fin[ty][tx] = metal::quant_rgba8 (r);
+    res[j] = metal::quant_rgba8 (r);
+  }
+  __syncthreads ();                                                      // every lane is done reading hb
+  uint32_t (*fin)[VF_TW] = hb;                                           // unsharp result (8-bit), tile rows only
+#pragma unroll
+  for (int j = 0; j < VF_PER_LANE; j++) {
+    const int i = tid + j * VF_THREADS;
+    fin[i / VF_TW][i % VF_TW] = res[j];
   }
   __syncthreads ();
-  // store epilogue: 2x2 blocks of the tile (512 blocks, two per lane)
-  for (int i = tid; i < (VF_TW / 2) * (VF_TH / 2); i += 256) {
+  // store epilogue: 2x2 blocks of the tile
+  for (int i = tid; i < (VF_TW / 2) * (VF_TH / 2); i += VF_THREADS) {
     const int lbx = i % (VF_TW / 2), lby = i / (VF_TW / 2);
     const int gx = x0 + 2 * lbx, gy = y0 + 2 * lby;
     if (gx >= w || gy >= h) continue;
@@ -281,8 +296,10 @@ static int vf_launch (VfHipVideoFilter *h, const VfHipFrame *in, VfHipFrame *out
   p.u = *prm; p.lut = h->d_lut; p.lut_size = h->lut_size;
   const int w = h->out.width, hh = h->out.height;
   if (prm->sharpness < -0.001f || prm->sharpness > 0.001f) {
-    dim3 grid ((unsigned) ((w + VF_TW - 1) / VF_TW), (unsigned) ((hh + VF_TH - 1) / VF_TH), (unsigned) n_frames);
-    hipLaunchKernelGGL (k_vf_sharp, grid, dim3 (256), 0, s, p);
+    static const int variant = [] { const char *e = getenv ("VFHIP_VF_TILE"); return e ? atoi (e) : 0; } ();     // tuning knob
+    auto grid = [&] (int tw, int th) { return dim3 ((unsigned) ((w + tw - 1) / tw), (unsigned) ((hh + th - 1) / th), (unsigned) n_frames); };
+    if (variant == 1) hipLaunchKernelGGL ((k_vf_sharp<128, 64, 1024, 4>), grid (128, 64), dim3 (1024), 0, s, p);
+    else hipLaunchKernelGGL ((k_vf_sharp<128, 32, 512, 4>), grid (128, 32), dim3 (512), 0, s, p);
   } else {
     const int bw = (w + 1) / 2, bh = (hh + 1) / 2;
     dim3 grid ((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4), (unsigned) n_frames);
