@@ -37,55 +37,71 @@ struct CompParams {
 
 using metal::F4;
 
-__device__ __forceinline__ uint32_t comp_pixel (const CompParams &p, int x, int y, unsigned z)
+__device__ __forceinline__ uint32_t comp_background (const CompParams &p, int x, int y)
 {
-  uint32_t q;
-  if (p.background < 0) q = p.prev[(size_t) y * p.prev_stride + x];
-  else if (p.background == VFHIP_BG_BLACK) q = 0xff000000u;
-  else if (p.background == VFHIP_BG_WHITE) q = 0xffffffffu;
-  else if (p.background == VFHIP_BG_TRANSPARENT) q = 0u;
-  else {      // checker: pos = int2(texcoord * size), 8x8 cells, grey 0.75 / 0.5 (metalcomprenderer.m:113-121)
-    const float tu = ((float) x + 0.5f) / (float) p.out.w, tv = ((float) y + 0.5f) / (float) p.out.h;
-    const int px = (int) (tu * (float) p.out.w), py = (int) (tv * (float) p.out.h);
-    const float gray = ((px / 8) + (py / 8)) % 2 ? 0.75f : 0.5f;
-    F4 c; c.r = c.g = c.b = gray; c.a = 1.0f;
-    q = metal::quant_rgba8 (c);
+  if (p.background < 0) return p.prev[(size_t) y * p.prev_stride + x];
+  if (p.background == VFHIP_BG_BLACK) return 0xff000000u;
+  if (p.background == VFHIP_BG_WHITE) return 0xffffffffu;
+  if (p.background == VFHIP_BG_TRANSPARENT) return 0u;
+  // checker: pos = int2(texcoord * size), 8x8 cells, grey 0.75 / 0.5 (metalcomprenderer.m:113-121)
+  const float tu = ((float) x + 0.5f) / (float) p.out.w, tv = ((float) y + 0.5f) / (float) p.out.h;
+  const int px = (int) (tu * (float) p.out.w), py = (int) (tv * (float) p.out.h);
+  const float gray = ((px / 8) + (py / 8)) % 2 ? 0.75f : 0.5f;
+  F4 c; c.r = c.g = c.b = gray; c.a = 1.0f;
+  return metal::quant_rgba8 (c);
+}
+
+// one layer drawn over the 8-bit target value q of pixel (x, y); the caller has checked coverage
+__device__ __forceinline__ uint32_t comp_blend (const CompLayer &L, const metal::Img &im, int x, int y, uint32_t q)
+{
+  F4 s;
+  if (L.width == L.img.w && L.height == L.img.h) {
+    // unscaled pad: texel centres are sampled, the linear sampler returns the exact texel (SURVEY.md Appendix B
+    // item 2); 4:2:0 chroma still interpolates at its .25/.75 phases.  One dword load instead of 16 byte taps.
+    s = metal::fetch_1to1 (im, x - L.xpos, y - L.ypos, true);
+  } else {
+    const float tu = (((float) x + 0.5f) - (float) L.xpos) / (float) L.width;
+    const float tv = (((float) y + 0.5f) - (float) L.ypos) / (float) L.height;
+    s = metal::sample_rgba (im, tu, tv, true);
   }
+  s.a *= L.alpha; s.r *= s.a; s.g *= s.a; s.b *= s.a;            // premultiply (compositorFragment, :58-59)
+  const F4 d = metal::unpack_rgba8 (q);
+  F4 o;
+  if (L.blend == VFHIP_BLEND_SOURCE) o = s;
+  else if (L.blend == VFHIP_BLEND_ADD) { o.r = s.r + d.r; o.g = s.g + d.g; o.b = s.b + d.b; o.a = s.a + d.a; }
+  else { const float k1 = 1.0f - s.a; o.r = s.r + d.r * k1; o.g = s.g + d.g * k1; o.b = s.b + d.b * k1; o.a = s.a + d.a * k1; }
+  return metal::quant_rgba8 (o);
+}
+
+// Workgroup = 64 x 4 lanes, one lane = a 2x2 block of output pixels, so a wave covers a 128 x 2 pixel strip.  Layers are
+// the OUTER loop: a layer's parameters are fetched once per wave (scalar loads), a layer that misses the wave's strip is
+// skipped by a wave-uniform branch, and the four pixels of a lane are blended in the same trip (the first version looped
+// over the layers per pixel: 4x the scalar traffic and no culling).
+__global__ __launch_bounds__ (256) void k_compositor (const CompParams p)
+{
+  const int bx = blockIdx.x * 64 + threadIdx.x;
+  const int by = __builtin_amdgcn_readfirstlane ((int) (blockIdx.y * 4 + threadIdx.y));      // one row of lanes = one wave
+  if (2 * by >= p.out.h) return;
+  const bool live = 2 * bx < p.out.w;
+  const int x0 = min (2 * bx, p.out.w - 1), x1 = min (2 * bx + 1, p.out.w - 1);
+  const int y0 = 2 * by, y1 = min (2 * by + 1, p.out.h - 1);
+  uint32_t q[2][2] = { { comp_background (p, x0, y0), comp_background (p, x1, y0) }, { comp_background (p, x0, y1), comp_background (p, x1, y1) } };
+  const int wx0 = (int) blockIdx.x * 128, wx1 = wx0 + 128;
+  const unsigned z = blockIdx.z;
   for (int k = 0; k < p.n; k++) {
     const CompLayer &L = p.layer[k];
     // a pixel is covered when its centre lies inside the quad [xpos, xpos+width) x [ypos, ypos+height)
-    if (x < L.xpos || x >= L.xpos + L.width || y < L.ypos || y >= L.ypos + L.height) continue;
-    F4 s;
-    if (L.width == L.img.w && L.height == L.img.h) {
-      // unscaled pad: texel centres are sampled, the linear sampler returns the exact texel (SURVEY.md Appendix B
-      // item 2); 4:2:0 chroma still interpolates at its .25/.75 phases.  One dword load instead of 16 byte taps.
-      s = metal::fetch_1to1 (metal::img_at (L.img, z * L.pitch), x - L.xpos, y - L.ypos, true);
-    } else {
-      const float tu = (((float) x + 0.5f) - (float) L.xpos) / (float) L.width;
-      const float tv = (((float) y + 0.5f) - (float) L.ypos) / (float) L.height;
-      s = metal::sample_rgba (metal::img_at (L.img, z * L.pitch), tu, tv, true);
-    }
-    s.a *= L.alpha; s.r *= s.a; s.g *= s.a; s.b *= s.a;            // premultiply (compositorFragment, :58-59)
-    const F4 d = metal::unpack_rgba8 (q);
-    F4 o;
-    if (L.blend == VFHIP_BLEND_SOURCE) o = s;
-    else if (L.blend == VFHIP_BLEND_ADD) { o.r = s.r + d.r; o.g = s.g + d.g; o.b = s.b + d.b; o.a = s.a + d.a; }
-    else { const float k1 = 1.0f - s.a; o.r = s.r + d.r * k1; o.g = s.g + d.g * k1; o.b = s.b + d.b * k1; o.a = s.a + d.a * k1; }
-    q = metal::quant_rgba8 (o);
+    const int lx1 = L.xpos + L.width, ly1 = L.ypos + L.height;
+    if (wx1 <= L.xpos || wx0 >= lx1 || y1 < L.ypos || y0 >= ly1) continue;                   // wave-uniform
+    const metal::Img im = metal::img_at (L.img, z * L.pitch);
+    const bool cx0 = x0 >= L.xpos && x0 < lx1, cx1 = x1 >= L.xpos && x1 < lx1;
+    const bool cy0 = y0 >= L.ypos && y0 < ly1, cy1 = y1 >= L.ypos && y1 < ly1;
+    if (cx0 && cy0) q[0][0] = comp_blend (L, im, x0, y0, q[0][0]);
+    if (cx1 && cy0) q[0][1] = comp_blend (L, im, x1, y0, q[0][1]);
+    if (cx0 && cy1) q[1][0] = comp_blend (L, im, x0, y1, q[1][0]);
+    if (cx1 && cy1) q[1][1] = comp_blend (L, im, x1, y1, q[1][1]);
   }
-  return q;
-}
-
-__global__ __launch_bounds__ (256) void k_compositor (const CompParams p)
-{
-  const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
-  if (2 * bx >= p.out.w || 2 * by >= p.out.h) return;
-  uint32_t q[2][2];
-#pragma unroll
-  for (int dy = 0; dy < 2; dy++)
-#pragma unroll
-    for (int dx = 0; dx < 2; dx++)
-      q[dy][dx] = comp_pixel (p, min (2 * bx + dx, p.out.w - 1), min (2 * by + dy, p.out.h - 1), blockIdx.z);
+  if (!live) return;
   if (p.scratch) {
 #pragma unroll
     for (int dy = 0; dy < 2; dy++)
@@ -94,7 +110,7 @@ __global__ __launch_bounds__ (256) void k_compositor (const CompParams p)
         if (2 * bx + dx < p.out.w && 2 * by + dy < p.out.h) p.scratch[(size_t) (2 * by + dy) * p.scratch_stride + 2 * bx + dx] = q[dy][dx];
     return;
   }
-  metal::store_block (metal::out_at (p.out, blockIdx.z * p.out_pitch), bx, by, q);
+  metal::store_block (metal::out_at (p.out, z * p.out_pitch), bx, by, q);
 }
 
 }  // namespace vfhip
