@@ -50,8 +50,42 @@ def cpu_baseline(seconds_budget=20.0):
         el = time.perf_counter() - t0
         if el > seconds_budget or n >= 400:
             break
-    return {"value": round(n / el, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} frames NV12 {IN_W}x{IN_H} -> BGRA {OUT_W}x{OUT_H}, oracle/gst114.c -O3 -march=native OpenMP x{cores}"}
+    out = {"value": round(n / el, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": f"{n} frames NV12 {IN_W}x{IN_H} -> BGRA {OUT_W}x{OUT_H}, oracle/gst114.c -O3 -march=native OpenMP x{cores}"}
+    g = gstreamer_cpu_pipeline(cores)
+    if g:
+        out["gstreamer"] = g
+    return out
+
+
+def gstreamer_cpu_pipeline(threads, frames=48):
+    """When the image's GStreamer 1.14 is present (it is on the GPU box), also time the real CPU elements on the same
+    conversion: BASELINE configs[1] verbatim, wall clock minus a source-only run (SURVEY.md §8d CPU baseline)."""
+    import gst_env                     # tests/gst_env.py: environment for /opt/conda's GStreamer (no oracle code)
+    if not os.path.exists(gst_env.GST_LAUNCH):
+        return None
+    src = f"videotestsrc num-buffers={frames} ! video/x-raw,format=NV12,width={IN_W},height={IN_H}"
+    res = {}
+    try:
+        gst_env.launch("videotestsrc num-buffers=1 ! videoconvert ! videoscale ! fakesink", timeout=120)   # registry scan, page-in
+        t0 = time.perf_counter()
+        if gst_env.launch(f"{src} ! fakesink sync=false", timeout=120).returncode != 0:
+            return None
+        t_src = time.perf_counter() - t0
+        for label, n in (("1_thread", 1), (f"{threads}_threads", threads)):
+            t0 = time.perf_counter()
+            r = gst_env.launch(f"{src} ! videoconvert n-threads={n} ! videoscale n-threads={n} ! "
+                               f"video/x-raw,format=BGRA,width={OUT_W},height={OUT_H} ! fakesink sync=false", timeout=300)
+            if r.returncode != 0:
+                return None
+            dt = time.perf_counter() - t0 - t_src
+            if dt <= 0:
+                return None
+            res[label] = round(frames / dt, 2)
+    except Exception:
+        return None
+    return {"frames_per_s": res, "pipeline": "videotestsrc ! NV12 2160p ! videoconvert ! videoscale ! BGRA 1080p ! fakesink (GStreamer 1.14.0), source-only time subtracted",
+            "sample": f"{frames} frames"}
 
 
 def load_traffic(frames):
@@ -135,11 +169,11 @@ def main():
             for _ in range(3):
                 scratch.copy_(ring_in)
             c0.record(stream)
-            for _ in range(10):
+            for _ in range(30):
                 scratch.copy_(ring_in)
             c1.record(stream)
         torch.cuda.synchronize()
-        copy_gbs = 2 * ring_in.numel() * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        copy_gbs = 2 * ring_in.numel() * 30 / (c0.elapsed_time(c1) * 1e-3) / 1e9
         del scratch
 
     if rank == 0:
