@@ -78,6 +78,7 @@ int Staging::init (Device *d)
   VFHIP_CHECK_HIP (hipStreamCreateWithFlags (&s_d2h, hipStreamNonBlocking));
   VFHIP_CHECK_HIP (hipEventCreateWithFlags (&ev_h2d, hipEventDisableTiming));
   VFHIP_CHECK_HIP (hipEventCreateWithFlags (&ev_compute, hipEventDisableTiming));
+  for (auto &e : ev_done) VFHIP_CHECK_HIP (hipEventCreateWithFlags (&e, hipEventDisableTiming));
   return VFHIP_OK;
 }
 
@@ -107,6 +108,7 @@ void Staging::destroy ()
   slots.clear ();
   if (ev_h2d) (void) hipEventDestroy (ev_h2d);
   if (ev_compute) (void) hipEventDestroy (ev_compute);
+  for (auto &e : ev_done) { if (e) (void) hipEventDestroy (e); e = nullptr; }
   if (s_h2d) (void) hipStreamDestroy (s_h2d);
   if (s_compute) (void) hipStreamDestroy (s_compute);
   if (s_d2h) (void) hipStreamDestroy (s_d2h);
@@ -247,18 +249,17 @@ int upload_frame (Staging &st, size_t slot, const VfHipFrame *host, VfHipFrame *
   return VFHIP_OK;
 }
 
-int download_frame (Staging &st, size_t slot, const VfHipFrame *df, VfHipFrame *host)
+int download_begin (Staging &st, size_t slot, VfHipFrame *host, bool staged[VFHIP_MAX_PLANES], hipEvent_t done)
 {
+  for (int p = 0; p < VFHIP_MAX_PLANES; p++) staged[p] = false;
   if (host->flags & VFHIP_FRAME_FLAG_DEVICE) {            // the kernel wrote the caller's device frame in place (output_frame)
-    VFHIP_CHECK_HIP (hipStreamSynchronize (st.s_compute));
+    VFHIP_CHECK_HIP (hipEventRecord (done, st.s_compute));
     return VFHIP_OK;
   }
   size_t off[VFHIP_MAX_PLANES], total; int stride[VFHIP_MAX_PLANES];
   int np = device_layout (&host->info, off, stride, &total);
   if (np < 0) return np;
   Staging::Buf &b = st.slots[slot];
-  (void) df;
-  bool staged[VFHIP_MAX_PLANES] = { false, false, false, false };
   VFHIP_CHECK_HIP (hipStreamWaitEvent (st.s_d2h, st.ev_compute, 0));
   for (int p = 0; p < np; p++) {
     if (!host->data[p]) return set_error (VFHIP_ERR_INVALID, "output plane %d is NULL", p);
@@ -274,7 +275,18 @@ int download_frame (Staging &st, size_t slot, const VfHipFrame *df, VfHipFrame *
       VFHIP_CHECK_HIP (hipMemcpyAsync ((uint8_t *) b.host + off[p], dsrc, (size_t) stride[p] * (ph - 1) + wb, hipMemcpyDeviceToHost, st.s_d2h));
     }
   }
-  VFHIP_CHECK_HIP (hipStreamSynchronize (st.s_d2h));
+  VFHIP_CHECK_HIP (hipEventRecord (done, st.s_d2h));
+  return VFHIP_OK;
+}
+
+int download_finish (Staging &st, size_t slot, VfHipFrame *host, const bool staged[VFHIP_MAX_PLANES], hipEvent_t done)
+{
+  VFHIP_CHECK_HIP (hipEventSynchronize (done));
+  if (host->flags & VFHIP_FRAME_FLAG_DEVICE) return VFHIP_OK;
+  size_t off[VFHIP_MAX_PLANES], total; int stride[VFHIP_MAX_PLANES];
+  int np = device_layout (&host->info, off, stride, &total);
+  if (np < 0) return np;
+  Staging::Buf &b = st.slots[slot];
   for (int p = 0; p < np; p++) {
     if (!staged[p]) continue;
     int wb = plane_width_bytes (host->info.format, p, host->info.width);
@@ -284,6 +296,15 @@ int download_frame (Staging &st, size_t slot, const VfHipFrame *df, VfHipFrame *
     for (int y = 0; y < ph; y++) memcpy (dst + (size_t) y * host->stride[p], src + (size_t) y * stride[p], wb);
   }
   return VFHIP_OK;
+}
+
+int download_frame (Staging &st, size_t slot, const VfHipFrame *df, VfHipFrame *host)
+{
+  (void) df;
+  bool staged[VFHIP_MAX_PLANES];
+  int rc = download_begin (st, slot, host, staged, st.ev_done[0]);
+  if (rc) return rc;
+  return download_finish (st, slot, host, staged, st.ev_done[0]);
 }
 
 size_t frame_plane_bytes (const VfHipFrame *f, int plane)

@@ -37,6 +37,7 @@ struct Staging {
   Device *dev = nullptr;
   hipStream_t s_h2d = nullptr, s_compute = nullptr, s_d2h = nullptr;
   hipEvent_t ev_h2d = nullptr, ev_compute = nullptr;
+  hipEvent_t ev_done[2] = { nullptr, nullptr };    // one per frame in flight (pipelined submit / wait entry points)
   struct Buf { void *host = nullptr; void *devp = nullptr; size_t bytes = 0; };
   std::vector<Buf> slots;                    // slot-indexed like the reference's texture cache
   int init (Device *d);
@@ -61,6 +62,10 @@ int alloc_device_frame (Staging &st, size_t slot, const VfHipVideoInfo *info, Vf
 int output_frame (Staging &st, size_t slot, const VfHipVideoInfo *info, const VfHipFrame *out, VfHipFrame *dev_frame);
 // download a device image into host frame planes (honours the host strides); synchronises
 int download_frame (Staging &st, size_t slot, const VfHipFrame *dev_frame, VfHipFrame *host);
+// the same in two halves for the pipelined entry points: _begin enqueues the copies behind st.ev_compute and records
+// `done`; _finish waits for `done` and moves staged planes (pageable destinations) into the caller's frame
+int download_begin (Staging &st, size_t slot, VfHipFrame *host, bool staged[VFHIP_MAX_PLANES], hipEvent_t done);
+int download_finish (Staging &st, size_t slot, VfHipFrame *host, const bool staged[VFHIP_MAX_PLANES], hipEvent_t done);
 
 }  // namespace vfhip
 

@@ -63,6 +63,9 @@ def _load():
     lib.vfhip_convertscale_configure.argtypes = [C.c_void_p, C.POINTER(VideoInfo), C.POINTER(VideoInfo), C.c_int, C.c_int,
                                                  C.c_uint32, C.c_int]
     lib.vfhip_convertscale_process.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(Frame)]
+    lib.vfhip_convertscale_submit.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(Frame)]
+    lib.vfhip_convertscale_wait.argtypes = [C.c_void_p]
+    lib.vfhip_convertscale_in_flight.argtypes = [C.c_void_p]
     lib.vfhip_convertscale_process_device.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(Frame), C.c_void_p]
     lib.vfhip_convertscale_process_device_batch.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(Frame), C.c_size_t,
                                                             C.c_size_t, C.c_int, C.c_void_p]

@@ -140,6 +140,14 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
 /* -processFrame:output: (metalconvertscalerenderer.m:332-512): host frames, synchronous */
 int vfhip_convertscale_process (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame *out);
 /* device-resident frames, asynchronous on `stream` (a hipStream_t, NULL = the handle's own compute stream) */
+/* Pipelined variant of _process for host frames: _submit enqueues upload -> kernel -> download of one frame on the handle's
+ * three streams and returns at once (pageable planes are copied into pinned staging before it returns; pinned planes and
+ * the whole output frame stay borrowed until the frame's _wait returns); at most two frames may be in flight; _wait blocks
+ * until the OLDEST submitted frame's output is complete.  With two frames in flight the upload of frame n+1 overlaps the
+ * kernel and the download of frame n (PCIe is full duplex).  cleanup / configure require an empty pipeline. */
+int vfhip_convertscale_submit (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame *out);
+int vfhip_convertscale_wait (VfHipConvertScale *h);
+int vfhip_convertscale_in_flight (VfHipConvertScale *h);
 int vfhip_convertscale_process_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame *out, void *stream);
 /* n_frames frames laid out at a constant pitch: plane p of frame k lives at data[p] + k * pitch */
 int vfhip_convertscale_process_device_batch (VfHipConvertScale *h, const VfHipFrame *in0, VfHipFrame *out0,

@@ -131,3 +131,48 @@ def test_compositor_device_pads_and_misaligned_device_frame(vfhip, metalref):
     rc = vfhip.lib.vfhip_compositor_composite(comp.h, arr, 2, vfhip.BACKGROUNDS["black"], C.byref(bad))
     assert rc == -1 and b"aligned" in vfhip.lib.vfhip_last_error_string()
     comp.close()
+
+
+def test_convertscale_submit_wait_pipeline(vfhip, oracle):
+    """pipelined host path: frames submitted two deep come back in order and equal the synchronous result, for pageable
+    and pinned buffers; misuse is reported, not crashed"""
+    w, h, ow, oh, n = 256, 128, 128, 64, 7
+    in_size = vfhip.plane_layout("NV12", w, h)[1]
+    out_size = ow * oh * 4
+    cs = vfhip.ConvertScale(0)
+    cs.configure("NV12", w, h, "BGRA", ow, oh, colorimetry="bt601", chroma_site="jpeg")
+    frames = [smooth("NV12", w, h, 50 + k) for k in range(n)]
+    want = [cs.process(f) for f in frames]
+    lib = vfhip.lib
+    assert lib.vfhip_convertscale_wait(cs.h) == -1 and lib.vfhip_convertscale_in_flight(cs.h) == 0
+    for kind in ("pageable", "pinned"):
+        if kind == "pinned":
+            ins = [np.ctypeslib.as_array((C.c_uint8 * in_size).from_address(lib.vfhip_pinned_alloc(0, in_size))) for _ in range(n)]
+            outs = [np.ctypeslib.as_array((C.c_uint8 * out_size).from_address(lib.vfhip_pinned_alloc(0, out_size))) for _ in range(n)]
+        else:
+            ins, outs = [np.empty(in_size, np.uint8) for _ in range(n)], [np.empty(out_size, np.uint8) for _ in range(n)]
+        for a, f in zip(ins, frames):
+            a[:] = f
+        for o in outs:
+            o[:] = 0
+        fi = [vfhip.frame_from_base(cs.in_info, "NV12", w, h, a.ctypes.data) for a in ins]
+        fo = [vfhip.frame_from_base(cs.out_info, "BGRA", ow, oh, o.ctypes.data) for o in outs]
+        done = 0
+        for k in range(n):
+            vfhip.check(lib.vfhip_convertscale_submit(cs.h, C.byref(fi[k]), C.byref(fo[k])))
+            if lib.vfhip_convertscale_in_flight(cs.h) == 2:
+                if k == 1:                                   # a third submit / a synchronous call with a full pipeline are refused
+                    assert lib.vfhip_convertscale_submit(cs.h, C.byref(fi[k]), C.byref(fo[k])) == -1
+                    assert lib.vfhip_convertscale_process(cs.h, C.byref(fi[k]), C.byref(fo[k])) == -1
+                vfhip.check(lib.vfhip_convertscale_wait(cs.h))
+                assert np.array_equal(outs[done].reshape(want[done].shape), want[done]), f"{kind} frame {done}"
+                done += 1
+        while lib.vfhip_convertscale_in_flight(cs.h):
+            vfhip.check(lib.vfhip_convertscale_wait(cs.h))
+            assert np.array_equal(outs[done].reshape(want[done].shape), want[done]), f"{kind} frame {done}"
+            done += 1
+        assert done == n
+        if kind == "pinned":
+            for a in ins + outs:
+                lib.vfhip_pinned_free(a.ctypes.data)
+    cs.close()

@@ -219,3 +219,22 @@ def test_compositor_takes_hip_memory_pads(tmp_path):
         assert r.returncode == 0, r.stderr
     x, y = np.fromfile(a, np.uint8), np.fromfile(b, np.uint8)
     assert x.size == y.size == 3 * 320 * 240 * 4 and np.array_equal(x, y)
+
+
+# ---- async-depth=1: one frame in flight across buffers ----------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 5])
+def test_async_depth_same_frames_in_order(tmp_path, n):
+    """every frame comes out, in order, byte-identical to the synchronous element — including the ones still in flight at EOS"""
+    a, b = tmp_path / "async.raw", tmp_path / "sync.raw"
+    for path, depth in ((a, 1), (b, 0)):
+        r = gst_env.launch(f"videotestsrc num-buffers={n} pattern=ball ! {caps('NV12', 640, 480)} ! vfhipconvertscale async-depth={depth} ! "
+                           f"{caps('BGRA', 320, 240)} ! filesink location={path}")
+        assert r.returncode == 0, r.stderr
+    x, y = np.fromfile(a, np.uint8), np.fromfile(b, np.uint8)
+    assert x.size == y.size == n * 320 * 240 * 4 and np.array_equal(x, y)
+
+
+def test_async_depth_in_chains():
+    ok(f"{SRC} ! {caps('NV12', 1920, 1080)} ! vfhipdeinterlace ! vfhipconvertscale async-depth=1 ! {caps('BGRA', 640, 360)} ! vfhipvideofilter sepia=0.4 ! fakesink")
+    ok(f"{SRC} ! {caps('BGRA', 320, 240)} ! vfhipconvertscale async-depth=1 ! {hipcaps('NV12', 160, 120)} ! vfhiptransform method=vertical-flip ! fakesink")
+    ok(f"{SRC} ! {caps('BGRA', 320, 240)} ! vfhipconvertscale async-depth=1 ! {caps('BGRA', 320, 240)} ! fakesink")       # passthrough

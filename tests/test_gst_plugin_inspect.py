@@ -29,7 +29,7 @@ def test_plugin_registers_elements():
 
 def test_convertscale_api():
     t = gst_env.inspect("vfhipconvertscale").stdout
-    assert {"method", "add-borders", "border-color", "device-id", "numerics"} <= props(t)
+    assert {"method", "add-borders", "border-color", "device-id", "numerics", "async-depth"} <= props(t)
     assert "GstBaseTransform" in t and "bilinear" in t and "nearest" in t
     # both pads: the six formats in system memory and as memory:HIPMemory (device-resident buffers between vfhip elements)
     assert t.count("(string)BGRA, (string)RGBA, (string)NV12, (string)I420, (string)UYVY, (string)YUY2") == 4

@@ -151,6 +151,18 @@ def e2e():
         print(json.dumps({"config": f"C2 end-to-end vfhip_convertscale_process, {kind} host frames (sync per frame)",
                           "frames_per_s": round(n / dt, 1), "ms_per_frame": round(dt / n * 1e3, 3),
                           "pcie_GBps": round((in_size + out_size) * n / dt / 1e9, 2)}), flush=True)
+        # the same frames two deep through submit / wait: upload of frame n+1 overlaps kernel + download of frame n
+        n, t0 = 200, time.perf_counter()
+        for k in range(n):
+            vfhip.check(vfhip.lib.vfhip_convertscale_submit(cs.h, C.byref(fi), C.byref(fo)))
+            if vfhip.lib.vfhip_convertscale_in_flight(cs.h) == 2:
+                vfhip.check(vfhip.lib.vfhip_convertscale_wait(cs.h))
+        while vfhip.lib.vfhip_convertscale_in_flight(cs.h):
+            vfhip.check(vfhip.lib.vfhip_convertscale_wait(cs.h))
+        dt = time.perf_counter() - t0
+        print(json.dumps({"config": f"C2 end-to-end vfhip_convertscale_submit/_wait, {kind} host frames (two frames in flight)",
+                          "frames_per_s": round(n / dt, 1), "ms_per_frame": round(dt / n * 1e3, 3),
+                          "pcie_GBps": round((in_size + out_size) * n / dt / 1e9, 2)}), flush=True)
     cs.close()
 
 
