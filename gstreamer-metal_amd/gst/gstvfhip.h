@@ -30,6 +30,10 @@ gboolean gst_vfhip_propose_allocation (struct _GstBaseTransform * trans, GstQuer
 gboolean gst_vfhip_decide_allocation (struct _GstBaseTransform * trans, GstQuery * query,
     gboolean (*parent) (struct _GstBaseTransform *, GstQuery *));
 
+/* hipHostRegister of recurring upstream system memories (gstvfhipallocator.c) */
+typedef struct { guint registered, reused; gboolean disabled; } GstVfHipPinStats;
+void gst_vfhip_pin_foreign_memory (GstBuffer * buf, GstVfHipPinStats * stats);
+
 /* device-resident buffers: caps feature memory:HIPMemory (gstvfhipmemory.c) */
 #define GST_CAPS_FEATURE_MEMORY_HIP "memory:HIPMemory"
 #define GST_MAP_VFHIP ((GstMapFlags) (GST_MAP_FLAG_LAST << 3))     /* map a device GstMemory to its DEVICE pointer */

@@ -155,3 +155,58 @@ gst_vfhip_decide_allocation (GstBaseTransform * trans, GstQuery * query, gboolea
   gst_object_unref (a);
   return parent (trans, query);
 }
+
+
+/* ---- hipHostRegister for buffers we did not allocate -------------------------------------------------------------
+ * Upstream elements that ignore the proposed allocator (their own pools, appsrc with application memory) hand us
+ * pageable system memory, which libvfhip has to copy into its pinned staging buffer before the DMA.  Pools recycle
+ * their memories, so a system-memory GstMemory is page-locked in place the first time it is seen (hipHostRegister)
+ * and from then on its planes are DMA'd directly, like the pinned allocator's.  Lifetime is tied to the GstMemory:
+ * a qdata destroy-notify unregisters the range before the memory is freed, so a recycled virtual address can never
+ * alias a stale registration.  Registration costs ~1 ms per 12 MB, which only pays off when memories recur: after
+ * VFHIP_REGISTER_PROBE registrations without a single re-use the element stops trying (fresh malloc per buffer). */
+#define VFHIP_REGISTER_PROBE 12
+
+static void
+unregister_host_range (gpointer data)
+{
+  vfhip_host_unregister (data);
+}
+
+void
+gst_vfhip_pin_foreign_memory (GstBuffer * buf, GstVfHipPinStats * stats)
+{
+  static GQuark quark = 0;
+  guint i, n;
+  if (!quark)
+    quark = g_quark_from_static_string ("vfhip-host-registered");
+  if (stats->disabled)
+    return;
+  n = gst_buffer_n_memory (buf);
+  for (i = 0; i < n; i++) {
+    GstMemory *mem = gst_buffer_peek_memory (buf, i);
+    GstMapInfo info;
+    if (!mem->allocator || !gst_memory_is_type (mem, GST_ALLOCATOR_SYSMEM) || mem->parent != NULL)
+      continue;                                               /* ours (pinned / device), foreign types, or a sub-memory */
+    if (gst_mini_object_get_qdata (GST_MINI_OBJECT_CAST (mem), quark)) {
+      stats->reused++;
+      continue;
+    }
+    if (stats->registered >= VFHIP_REGISTER_PROBE && stats->reused == 0) {
+      GST_INFO ("upstream memory never recurs: giving up on hipHostRegister for this element");
+      stats->disabled = TRUE;
+      return;
+    }
+    if (mem->maxsize < 256 * 1024 || !gst_memory_map (mem, &info, GST_MAP_READ))
+      continue;
+    if (vfhip_host_register (info.data - mem->offset, mem->maxsize) == VFHIP_OK) {
+      gst_mini_object_set_qdata (GST_MINI_OBJECT_CAST (mem), quark, info.data - mem->offset, unregister_host_range);
+      stats->registered++;
+      GST_INFO ("page-locked upstream memory %p (%" G_GSIZE_FORMAT " bytes) in place", info.data - mem->offset, mem->maxsize);
+    } else {
+      GST_DEBUG ("hipHostRegister failed: %s", vfhip_last_error_string ());
+      stats->disabled = TRUE;
+    }
+    gst_memory_unmap (mem, &info);
+  }
+}

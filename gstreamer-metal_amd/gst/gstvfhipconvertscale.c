@@ -29,6 +29,7 @@ typedef struct
   gboolean add_borders;
   guint border_color;
   /* async-depth=1: one frame stays in flight across chain calls (cs_generate_output) */
+  GstVfHipPinStats pin;
   gint async_depth;
   gboolean reconfigure_pending;
   struct
@@ -238,6 +239,7 @@ cs_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
     GST_WARNING_OBJECT (self, "no HIP renderer");
     return GST_FLOW_ERROR;
   }
+  gst_vfhip_pin_foreign_memory (inbuf, &self->pin);         /* recurring pageable upstream memory: page-lock it in place */
   if (!gst_video_frame_map (&in, &self->in_info, inbuf, (GstMapFlags) (GST_MAP_READ | GST_MAP_VFHIP)))
     return GST_FLOW_ERROR;
   if (!gst_video_frame_map (&out, &self->out_info, outbuf, (GstMapFlags) (GST_MAP_WRITE | GST_MAP_VFHIP))) {
@@ -341,6 +343,7 @@ cs_generate_output (GstBaseTransform * trans, GstBuffer ** outbuf)
     return ret != GST_FLOW_OK ? ret : GST_FLOW_ERROR;
   }
   k = (self->pending_head + self->n_pending) & 1;
+  gst_vfhip_pin_foreign_memory (inbuf, &self->pin);
   if (!gst_video_frame_map (&self->pending[k].in, &self->in_info, inbuf, (GstMapFlags) (GST_MAP_READ | GST_MAP_VFHIP))) {
     gst_buffer_unref (inbuf); gst_buffer_unref (out);
     return GST_FLOW_ERROR;

@@ -205,8 +205,14 @@ gst_vfhip_filter_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuff
   GstVideoFilterClass *fclass = GST_VIDEO_FILTER_GET_CLASS (filter);
   GstVideoFrame in, out;
   GstFlowReturn res;
+  GstVfHipPinStats *pin;
   if (G_UNLIKELY (!filter->negotiated))
     return GST_FLOW_NOT_NEGOTIATED;
+  if (!(pin = g_object_get_data (G_OBJECT (trans), "vfhip-pin-stats"))) {
+    pin = g_new0 (GstVfHipPinStats, 1);
+    g_object_set_data_full (G_OBJECT (trans), "vfhip-pin-stats", pin, g_free);
+  }
+  gst_vfhip_pin_foreign_memory (inbuf, pin);                 /* recurring pageable upstream memory: page-lock it in place */
   if (!gst_video_frame_map (&in, &filter->in_info, inbuf, (GstMapFlags) (GST_MAP_READ | GST_MAP_VFHIP | GST_VIDEO_FRAME_MAP_FLAG_NO_REF)))
     return GST_FLOW_ERROR;
   if (!gst_video_frame_map (&out, &filter->out_info, outbuf, (GstMapFlags) (GST_MAP_WRITE | GST_MAP_VFHIP | GST_VIDEO_FRAME_MAP_FLAG_NO_REF))) {

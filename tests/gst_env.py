@@ -25,9 +25,12 @@ def env():
     return e
 
 
-def launch(pipeline, timeout=120, verbose=False):
-    """verbose: gst-launch -v (prints every pad's negotiated caps) instead of -q"""
-    return subprocess.run(f"{GST_LAUNCH} {'-v' if verbose else '-q'} {pipeline}", shell=True, env=env(), capture_output=True, text=True, timeout=timeout)
+def launch(pipeline, timeout=120, verbose=False, debug=None):
+    """verbose: gst-launch -v (prints every pad's negotiated caps) instead of -q; debug: a GST_DEBUG spec (log on stderr)"""
+    e = env()
+    if debug:
+        e.update(GST_DEBUG=debug, GST_DEBUG_NO_COLOR="1")
+    return subprocess.run(f"{GST_LAUNCH} {'-v' if verbose else '-q'} {pipeline}", shell=True, env=e, capture_output=True, text=True, timeout=timeout)
 
 
 def inspect(what):

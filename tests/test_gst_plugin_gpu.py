@@ -238,3 +238,18 @@ def test_async_depth_in_chains():
     ok(f"{SRC} ! {caps('NV12', 1920, 1080)} ! vfhipdeinterlace ! vfhipconvertscale async-depth=1 ! {caps('BGRA', 640, 360)} ! vfhipvideofilter sepia=0.4 ! fakesink")
     ok(f"{SRC} ! {caps('BGRA', 320, 240)} ! vfhipconvertscale async-depth=1 ! {hipcaps('NV12', 160, 120)} ! vfhiptransform method=vertical-flip ! fakesink")
     ok(f"{SRC} ! {caps('BGRA', 320, 240)} ! vfhipconvertscale async-depth=1 ! {caps('BGRA', 320, 240)} ! fakesink")       # passthrough
+
+
+def test_recurring_upstream_memory_is_page_locked_in_place(tmp_path):
+    """upstream ignores the proposed pinned allocator (identity drop-allocation): its pool's system memories are
+    hipHostRegister'ed once each and re-used — same bytes out, only a few registrations for 12 buffers"""
+    a, b = tmp_path / "reg.raw", tmp_path / "ref.raw"
+    r = gst_env.launch(f"videotestsrc num-buffers=12 pattern=ball ! {caps('NV12', 1280, 720)} ! identity drop-allocation=true ! vfhipconvertscale ! "
+                       f"{caps('BGRA', 640, 360)} ! filesink location={a}", debug="vfhip:4")
+    assert r.returncode == 0, r.stderr[-2000:]
+    n_reg = r.stderr.count("page-locked upstream memory")
+    assert 1 <= n_reg < 12, r.stderr[-2000:]
+    r = gst_env.launch(f"videotestsrc num-buffers=12 pattern=ball ! {caps('NV12', 1280, 720)} ! vfhipconvertscale ! {caps('BGRA', 640, 360)} ! filesink location={b}")
+    assert r.returncode == 0, r.stderr
+    x, y = np.fromfile(a, np.uint8), np.fromfile(b, np.uint8)
+    assert x.size == y.size == 12 * 640 * 360 * 4 and np.array_equal(x, y)
