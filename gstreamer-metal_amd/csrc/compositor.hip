@@ -51,19 +51,31 @@ __device__ __forceinline__ uint32_t comp_background (const CompParams &p, int x,
   return metal::quant_rgba8 (c);
 }
 
-// one layer drawn over the 8-bit target value q of pixel (x, y); the caller has checked coverage
-__device__ __forceinline__ uint32_t comp_blend (const CompLayer &L, const metal::Img &im, int x, int y, uint32_t q)
+// the layer's colour at output pixel (x, y); the caller has checked coverage
+__device__ __forceinline__ F4 comp_sample (const CompLayer &L, const metal::Img &im, int x, int y)
 {
-  F4 s;
   if (L.width == L.img.w && L.height == L.img.h) {
     // unscaled pad: texel centres are sampled, the linear sampler returns the exact texel (SURVEY.md Appendix B
     // item 2); 4:2:0 chroma still interpolates at its .25/.75 phases.  One dword load instead of 16 byte taps.
-    s = metal::fetch_1to1 (im, x - L.xpos, y - L.ypos, true);
-  } else {
-    const float tu = (((float) x + 0.5f) - (float) L.xpos) / (float) L.width;
-    const float tv = (((float) y + 0.5f) - (float) L.ypos) / (float) L.height;
-    s = metal::sample_rgba (im, tu, tv, true);
+    return metal::fetch_1to1 (im, x - L.xpos, y - L.ypos, true);
   }
+  const float tu = (((float) x + 0.5f) - (float) L.xpos) / (float) L.width;
+  const float tv = (((float) y + 0.5f) - (float) L.ypos) / (float) L.height;
+  return metal::sample_rgba (im, tu, tv, true);
+}
+
+__device__ __forceinline__ F4 comp_texel (uint32_t t, bool rgba)
+{
+  F4 o;
+  o.g = metal::un8 ((t >> 8) & 0xff); o.a = metal::un8 (t >> 24);
+  if (rgba) { o.r = metal::un8 (t & 0xff); o.b = metal::un8 ((t >> 16) & 0xff); }
+  else { o.b = metal::un8 (t & 0xff); o.r = metal::un8 ((t >> 16) & 0xff); }
+  return o;
+}
+
+// colour s of one layer drawn over the 8-bit target value q
+__device__ __forceinline__ uint32_t comp_blend (const CompLayer &L, F4 s, uint32_t q)
+{
   s.a *= L.alpha; s.r *= s.a; s.g *= s.a; s.b *= s.a;            // premultiply (compositorFragment, :58-59)
   const F4 d = metal::unpack_rgba8 (q);
   F4 o;
@@ -72,6 +84,8 @@ __device__ __forceinline__ uint32_t comp_blend (const CompLayer &L, const metal:
   else { const float k1 = 1.0f - s.a; o.r = s.r + d.r * k1; o.g = s.g + d.g * k1; o.b = s.b + d.b * k1; o.a = s.a + d.a * k1; }
   return metal::quant_rgba8 (o);
 }
+
+typedef uint2 __attribute__ ((aligned (4))) uint2_a4;
 
 // Workgroup = 64 x 4 lanes, one lane = a 2x2 block of output pixels, so a wave covers a 128 x 2 pixel strip.  Layers are
 // the OUTER loop: a layer's parameters are fetched once per wave (scalar loads), a layer that misses the wave's strip is
@@ -96,10 +110,30 @@ __global__ __launch_bounds__ (256) void k_compositor (const CompParams p)
     const metal::Img im = metal::img_at (L.img, z * L.pitch);
     const bool cx0 = x0 >= L.xpos && x0 < lx1, cx1 = x1 >= L.xpos && x1 < lx1;
     const bool cy0 = y0 >= L.ypos && y0 < ly1, cy1 = y1 >= L.ypos && y1 < ly1;
-    if (cx0 && cy0) q[0][0] = comp_blend (L, im, x0, y0, q[0][0]);
-    if (cx1 && cy0) q[0][1] = comp_blend (L, im, x1, y0, q[0][1]);
-    if (cx0 && cy1) q[1][0] = comp_blend (L, im, x0, y1, q[1][0]);
-    if (cx1 && cy1) q[1][1] = comp_blend (L, im, x1, y1, q[1][1]);
+    const bool rgba_in = im.fmt == VFHIP_FORMAT_RGBA;
+    // unscaled RGBA / BGRA pad with both pixels of the pair inside: their texels are 8 adjacent bytes -> one load per row
+    const bool pair = cx0 && cx1 && x1 == x0 + 1 && (rgba_in || im.fmt == VFHIP_FORMAT_BGRA) && L.width == L.img.w && L.height == L.img.h;
+    if (pair) {
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        const int y = r ? y1 : y0;
+        if (!(r ? cy1 : cy0)) continue;
+        const uint2 t = *reinterpret_cast<const uint2_a4 *> (im.p[0] + (size_t) (y - L.ypos) * im.s[0] + 4 * (x0 - L.xpos));
+        q[r][0] = comp_blend (L, comp_texel (t.x, rgba_in), q[r][0]);
+        q[r][1] = comp_blend (L, comp_texel (t.y, rgba_in), q[r][1]);
+      }
+    } else {
+      // general path (scaled pads, 4:2:0 pads, quad edges): ONE instance of the sampler, the four pixels take turns
+      // (unrolled, the four inlined samplers push the kernel to 132 VGPRs = 3 waves per SIMD)
+#pragma unroll 1
+      for (int i = 0; i < 4; i++) {
+        const bool c = i & 1, r = i >> 1;
+        if (!((c ? cx1 : cx0) && (r ? cy1 : cy0))) continue;
+        const uint32_t cur = r ? (c ? q[1][1] : q[1][0]) : (c ? q[0][1] : q[0][0]);
+        const uint32_t v = comp_blend (L, comp_sample (L, im, c ? x1 : x0, r ? y1 : y0), cur);
+        q[0][0] = i == 0 ? v : q[0][0]; q[0][1] = i == 1 ? v : q[0][1]; q[1][0] = i == 2 ? v : q[1][0]; q[1][1] = i == 3 ? v : q[1][1];
+      }
+    }
   }
   if (!live) return;
   if (p.scratch) {
