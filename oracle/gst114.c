@@ -167,9 +167,123 @@ static void hscale (const uint8_t *in, int is, int w, int h, uint8_t *out, int o
   }
 }
 
+/* ---- videoscale method=catrom ("bicubic"): GstVideoResampler's cubic set-up + GstVideoScaler's 6-bit n-tap path.
+ * Not in the reference (it has no bicubic, gstvfmetalconvertscale.m:81-85) but named by north_star; pinned by probing the
+ * real element (impulse responses give every 6-bit tap exactly; random frames confirm arithmetic and pass order;
+ * tests/golden/convertscale_gst114_bicubic.npz):
+ *   scale = in / out; fx = min (1, 1 / scale); n_taps = ceil (4 / fx); fx = 4 / n_taps        (envelope 2)
+ *   x = clamp ((j + .5) * in / out - .5, 0, in - 1); first tap at floor (x) - (n_taps - 1) / 2
+ *   w_l = k ((x - x_l) * fx), Mitchell-Netravali form with b = 0, c = .5, normalised by their sum; taps that fall outside
+ *   the line are ADDED to the edge tap in double precision; then t_l = floor (offset + 64 w_l) with the offset found by
+ *   bisection from .5 so that the taps sum to 64 (<= 64 steps);
+ *   each pass: out = clamp ((sum p_l t_l + 32) >> 6, 0, 255) on u8 lines; vertical pass first iff in_h > out_h + n_taps_v. */
+static double cubic_k (double a)
+{
+  const double b = 0.0, c = 0.5;
+  a = a < 0 ? -a : a;
+  const double a2 = a * a, a3 = a2 * a;
+  if (a <= 1.0) return ((12.0 - 9.0 * b - 6.0 * c) * a3 + (-18.0 + 12.0 * b + 6.0 * c) * a2 + (6.0 - 2.0 * b)) / 6.0;
+  if (a <= 2.0) return ((-b - 6.0 * c) * a3 + (6.0 * b + 30.0 * c) * a2 + (-12.0 * b - 48.0 * c) * a + (8.0 * b + 24.0 * c)) / 6.0;
+  return 0.0;
+}
+
+static int cubic_n_taps (int in, int out)
+{
+  const double scale = (double) in / (double) out;
+  const double fx = scale > 1.0 ? 1.0 / scale : 1.0;
+  return (int) __builtin_ceil (2.0 * 2.0 / fx);
+}
+
+/* pinned domain: the line is at least as long as the filter (n_taps <= in) and n_taps <= 64; GstVideoResampler's handling
+ * of shorter lines (it truncates the filter) is not restated */
+int gst114_cubic_taps (int in, int out, int *idx, int *taps, int max_entries)
+{
+  const int n = cubic_n_taps (in, out);
+  if (n > 64 || n > in || (long) n * out > max_entries) return -1;
+  const double fx = 2.0 * 2.0 / n;
+  for (int j = 0; j < out; j++) {
+    double x = (j + 0.5) * in / out - 0.5;
+    x = x < 0.0 ? 0.0 : (x > in - 1.0 ? in - 1.0 : x);
+    const int xi = (int) __builtin_floor (x) - (n - 1) / 2;
+    double w[64], sum = 0.0, m[64];
+    int pos[64], cnt = 0;
+    for (int l = 0; l < n; l++) { w[l] = cubic_k ((x - (xi + l)) * fx); sum += w[l]; }
+    for (int l = 0; l < n; l++) {                    /* merge clamped taps (in tap order: left edge first) */
+      const int k = clampi (xi + l, 0, in - 1);
+      if (cnt > 0 && pos[cnt - 1] == k) m[cnt - 1] += w[l] / sum;
+      else { pos[cnt] = k; m[cnt] = w[l] / sum; cnt++; }
+    }
+    double lo = 0.0, hi = 1.0, off = 0.5;
+    for (int it = 0; it < 64; it++) {
+      int s = 0;
+      for (int l = 0; l < cnt; l++) s += (int) __builtin_floor (off + m[l] * 64.0);
+      if (s == 64) break;
+      if (lo == hi) break;
+      if (s < 64) { if (off > lo) lo = off; off += (hi - lo) / 2; }
+      else { if (off < hi) hi = off; off -= (hi - lo) / 2; }
+    }
+    for (int l = 0; l < n; l++) {
+      idx[j * n + l] = l < cnt ? pos[l] : pos[cnt - 1];
+      taps[j * n + l] = l < cnt ? (int) __builtin_floor (off + m[l] * 64.0) : 0;
+    }
+  }
+  return n;
+}
+
+static int cubic_pass (const uint8_t *in, int is, int w, int h, uint8_t *out, int os, int on, int vertical)
+{
+  const int len = vertical ? h : w;
+  const int n = cubic_n_taps (len, on);
+  int *idx = malloc (sizeof (int) * (size_t) n * on), *tp = malloc (sizeof (int) * (size_t) n * on);
+  if (!idx || !tp || gst114_cubic_taps (len, on, idx, tp, n * on) < 0) { free (idx); free (tp); return -2; }
+  if (vertical) {
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < on; y++)
+      for (int k = 0; k < 4 * w; k++) {
+        int acc = 0;
+        for (int l = 0; l < n; l++) acc += in[(size_t) idx[y * n + l] * is + k] * tp[y * n + l];
+        out[(size_t) y * os + k] = (uint8_t) clampi ((acc + 32) >> 6, 0, 255);
+      }
+  } else {
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < on; x++)
+        for (int c = 0; c < 4; c++) {
+          int acc = 0;
+          for (int l = 0; l < n; l++) acc += in[(size_t) y * is + 4 * idx[x * n + l] + c] * tp[x * n + l];
+          out[(size_t) y * os + 4 * x + c] = (uint8_t) clampi ((acc + 32) >> 6, 0, 255);
+        }
+  }
+  free (idx); free (tp);
+  return 0;
+}
+
+static int scale_cubic_4u8 (const uint8_t *in, int is, int w, int h, uint8_t *out, int os, int ow, int oh)
+{
+  if ((ow != w && (cubic_n_taps (w, ow) > w || cubic_n_taps (w, ow) > 64)) || (oh != h && (cubic_n_taps (h, oh) > h || cubic_n_taps (h, oh) > 64)))
+    return -3;                                         /* outside the pinned domain */
+  if (ow == w && oh == h) { for (int y = 0; y < h; y++) memcpy (out + (size_t) y * os, in + (size_t) y * is, 4 * (size_t) w); return 0; }
+  if (ow == w) return cubic_pass (in, is, w, h, out, os, oh, 1);
+  if (oh == h) return cubic_pass (in, is, w, h, out, os, ow, 0);
+  int rc;
+  if (h > oh + cubic_n_taps (h, oh)) {                /* vertical first */
+    uint8_t *tmp = malloc ((size_t) oh * w * 4); if (!tmp) return -2;
+    rc = cubic_pass (in, is, w, h, tmp, w * 4, oh, 1);
+    if (!rc) rc = cubic_pass (tmp, w * 4, w, oh, out, os, ow, 0);
+    free (tmp);
+  } else {
+    uint8_t *tmp = malloc ((size_t) h * ow * 4); if (!tmp) return -2;
+    rc = cubic_pass (in, is, w, h, tmp, ow * 4, ow, 0);
+    if (!rc) rc = cubic_pass (tmp, ow * 4, ow, h, out, os, oh, 1);
+    free (tmp);
+  }
+  return rc;
+}
+
 int gst114_scale_4u8 (const uint8_t *in, int is, int w, int h, uint8_t *out, int os, int ow, int oh, int method)
 {
   if (w <= 0 || h <= 0 || ow <= 0 || oh <= 0) return -1;
+  if (method == GST114_BICUBIC) return scale_cubic_4u8 (in, is, w, h, out, os, ow, oh);
   if (method == GST114_NEAREST) {
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < oh; y++) {

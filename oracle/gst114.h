@@ -7,7 +7,7 @@ extern "C" {
 #endif
 enum { GST114_BT601 = 0, GST114_BT709 = 1, GST114_BT2020 = 2 };
 enum { GST114_BGRA = 0, GST114_RGBA = 1 };
-enum { GST114_BILINEAR = 0, GST114_NEAREST = 1 };
+enum { GST114_BILINEAR = 0, GST114_NEAREST = 1, GST114_BICUBIC = 2 };   /* BICUBIC = videoscale method=catrom */
 
 int gst114_set_threads (int n);
 void gst114_yuv_to_rgb (int matrix, int Y, int U, int V, int *r, int *g, int *b);
@@ -16,6 +16,8 @@ int gst114_yuv420_to_rgb (const uint8_t *yp, int ys, const uint8_t *up, int us, 
 void gst114_vtaps (int in_h, int out_h, int y, int *i0, int *i1, int *w);
 uint32_t gst114_hinc (int in_w, int out_w);
 int gst114_nearest_index (int in, int out, int j);
+/* n-tap set-up of GstVideoResampler (cubic, b = 0, c = 0.5), 6-bit taps: returns n_taps; idx / taps: out * n_taps entries */
+int gst114_cubic_taps (int in, int out, int *idx, int *taps, int max_entries);
 int gst114_scale_4u8 (const uint8_t *in, int is, int w, int h, uint8_t *out, int os, int ow, int oh, int method);
 int gst114_rgb_to_yuv420 (const uint8_t *in, int is, int in_format, int w, int h, int matrix, int cosited,
     int planar, uint8_t *yp, int ys, uint8_t *up, int us, uint8_t *vp, int vs);

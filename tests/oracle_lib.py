@@ -64,7 +64,7 @@ class Oracle:
         raw = np.ascontiguousarray(np.frombuffer(raw, np.uint8) if isinstance(raw, (bytes, bytearray)) else raw, dtype=np.uint8)
         pl = planes(fmt, w, h, raw)
         cos = 1 if chroma_site == "mpeg2" else 0
-        meth = 1 if method == "nearest" else 0
+        meth = {"bilinear": 0, "nearest": 1, "bicubic": 2}[method]
         mat = MATRIX[colorimetry]
         L = self.lib
         yuv_in, yuv_out = fmt in ("NV12", "I420"), out_format in ("NV12", "I420")

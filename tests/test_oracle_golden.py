@@ -71,3 +71,49 @@ def test_oracle_matches_gstreamer_yuv_outputs(oracle, case):
                               c["method"], c["out_format"], c["ow"], c["oh"])
     want = ZY[c["name"] + "_out"]
     assert np.array_equal(meaningful(c["out_format"], c["ow"], c["oh"], got), meaningful(c["out_format"], c["ow"], c["oh"], want))
+
+
+# ---- bicubic (videoscale method=catrom): 76 vectors from the real elements ------------------------------------------
+MANIFEST_B, ZB = oracle_lib.load_golden("convertscale_gst114_bicubic.npz")
+
+
+def cubic_in_domain(c):
+    """the restated domain: every scaled axis is at least as long as its filter (n_taps = ceil(4 * max(1, in / out)) <= min(in, 64))"""
+    import math
+    return all(i == o or math.ceil(4 * max(1.0, i / o)) <= min(i, 64) for i, o in ((c["w"], c["ow"]), (c["h"], c["oh"])))
+
+
+def test_bicubic_fixture_domain():
+    inside = [c for c in MANIFEST_B if cubic_in_domain(c)]
+    assert len(MANIFEST_B) >= 76 and len(inside) >= 64
+
+
+@pytest.mark.parametrize("case", MANIFEST_B, ids=[c["name"] for c in MANIFEST_B])
+def test_oracle_matches_gstreamer_bicubic(oracle, case):
+    if not cubic_in_domain(case):
+        with pytest.raises(RuntimeError):            # degenerate sizes (line shorter than the filter) are refused, not approximated
+            oracle.convertscale(case["in_format"], case["w"], case["h"], ZB[case["name"] + "_in"], case["colorimetry"], case["chroma_site"], "bicubic",
+                                case["out_format"], case["ow"], case["oh"])
+        return
+    raw, want = ZB[case["name"] + "_in"], ZB[case["name"] + "_out"]
+    assert hashlib.sha256(raw.tobytes()).hexdigest() == case["in_sha256"]
+    got = oracle.convertscale(case["in_format"], case["w"], case["h"], raw, case["colorimetry"], case["chroma_site"], "bicubic",
+                              case["out_format"], case["ow"], case["oh"])
+    assert np.array_equal(got.reshape(-1), want), f"{(got.reshape(-1) != want).sum()} bytes differ"
+
+
+def test_cubic_taps_known_answers(oracle):
+    """taps read off the real element's impulse responses (6-bit, sum 64): 2:1 down, 2x up (incl. its exact .5 ties), 3:2 down"""
+    import ctypes as C
+    def taps(i, o):
+        idx, tp = (C.c_int * 4096)(), (C.c_int * 4096)()
+        n = oracle.lib.gst114_cubic_taps(i, o, idx, tp, 4096)
+        return n, [list(tp[j * n:(j + 1) * n]) for j in range(o)], [list(idx[j * n:(j + 1) * n]) for j in range(o)]
+    n, t, ix = taps(16, 8)
+    assert n == 8 and t[3] == [-1, -2, 7, 28, 28, 7, -2, -1] and ix[3] == [3, 4, 5, 6, 7, 8, 9, 10]
+    assert t[0][:5] == [32, 28, 7, -2, -1] and ix[0][:5] == [0, 1, 2, 3, 4]            # three taps merged into the left edge
+    n, t, ix = taps(8, 16)
+    assert n == 4 and t[3] == [-5, 56, 15, -2] and t[4] == [-2, 15, 56, -5] and t[0][0] == 64 and t[15][:3] == [0, 0, 64][:0] + t[15][:3]
+    n, t, ix = taps(16, 12)
+    assert n == 6 and t[4] == [-2, 0, 34, 34, 0, -2]
+    assert all(sum(r) == 64 for r in t)

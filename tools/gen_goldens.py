@@ -121,6 +121,46 @@ def rgb_layout_size(w, h):
     return 4 * w * h
 
 
+def gen_bicubic():
+    """`videoconvert ! videoscale method=catrom` -> tests/golden/convertscale_gst114_bicubic.npz (RGB outputs)"""
+    cases, arrays = [], {}
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = build_helper(tmp)
+        rng = np.random.default_rng(20261005)
+        cols, sites = ["bt601", "bt709", "bt2020"], ["jpeg", "mpeg2"]
+        sizes = [(64, 36, 32, 18), (64, 36, 128, 72), (48, 40, 20, 37), (48, 40, 96, 38), (33, 17, 16, 8), (200, 8, 100, 4), (8, 200, 4, 100),
+                 (64, 16, 32, 8), (64, 18, 32, 9), (17, 13, 11, 29), (96, 54, 96, 20), (96, 54, 31, 54), (3, 3, 7, 5), (40, 30, 9, 7), (16, 16, 1, 1)]
+        sizes += [tuple(int(v) for v in rng.integers(2, 97, 4)) for _ in range(10)]
+        t = 0
+        for fmt in ["NV12", "I420", "BGRA", "RGBA"]:
+            for (w, h, ow, oh) in sizes:
+                if t % 2 == 1 and fmt in ("BGRA", "RGBA") and t > 8:
+                    t += 1
+                    continue
+                col, site = cols[t % 3], sites[(t // 3) % 2]
+                ofmt = "RGBA" if t % 5 == 1 else "BGRA"
+                raw = rand_frame(rng, fmt, w, h) if fmt in ("NV12", "I420") else rng.integers(0, 256, 4 * w * h, dtype=np.uint8).tobytes()
+                caps = f"video/x-raw,format={fmt},width={w},height={h},framerate=1/1,colorimetry={col},chroma-site={site}"
+                out = gst_run(exe, tmp, raw, len(raw), caps, "videoconvert ! videoscale method=catrom", f"video/x-raw,format={ofmt},width={ow},height={oh}")
+                assert len(out) == ow * oh * 4
+                name = f"bc_{fmt.lower()}_{t:03d}_{w}x{h}_to_{ow}x{oh}"
+                arrays[name + "_in"] = np.frombuffer(raw, np.uint8)
+                arrays[name + "_out"] = np.frombuffer(out, np.uint8)
+                cases.append(dict(name=name, in_format=fmt, w=w, h=h, colorimetry=col, chroma_site=site, method="bicubic", out_format=ofmt, ow=ow, oh=oh,
+                                  in_sha256=hashlib.sha256(raw).hexdigest(), out_sha256=hashlib.sha256(out).hexdigest()))
+                t += 1
+        # the headline shape, smaller: videotestsrc 1080p -> 540p (vertical pass first)
+        raw = videotestsrc(tmp, "NV12", 960, 540)
+        out = gst_run(exe, tmp, raw, len(raw), "video/x-raw,format=NV12,width=960,height=540,framerate=1/1", "videoconvert ! videoscale method=catrom",
+                      "video/x-raw,format=BGRA,width=480,height=270")
+        arrays["bc_vts_in"], arrays["bc_vts_out"] = np.frombuffer(raw, np.uint8), np.frombuffer(out, np.uint8)
+        cases.append(dict(name="bc_vts", in_format="NV12", w=960, h=540, colorimetry=None, chroma_site=None, method="bicubic", out_format="BGRA", ow=480, oh=270,
+                          in_sha256=hashlib.sha256(raw).hexdigest(), out_sha256=hashlib.sha256(out).hexdigest()))
+    arrays["manifest"] = np.frombuffer(json.dumps(cases).encode(), np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "convertscale_gst114_bicubic.npz"), **arrays)
+    print("wrote", len(cases), "bicubic cases")
+
+
 def gen_yuv_outputs():
     """cells whose OUTPUT is NV12 / I420 (videoconvert's RGB->YUV matrix + chroma averaging, NV12<->I420 re-packing,
     per-plane videoscale): tests/golden/convertscale_gst114_yuvout.npz"""
@@ -155,6 +195,9 @@ def gen_yuv_outputs():
     print("wrote", len(cases), "yuv-output cases")
 
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "bicubic":
+    gen_bicubic()
+    sys.exit(0)
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "yuvout":
         gen_yuv_outputs()
