@@ -8,6 +8,7 @@
 #include "convertscale_kernels.h"
 #include "convertscale_metal_kernels.h"
 #include "convertscale_planar_kernels.h"
+#include "convertscale_ntap_kernels.h"
 #include <cmath>
 #include <cstdlib>
 
@@ -44,13 +45,17 @@ struct VfHipConvertScale {
   int *d_vtab = nullptr, *d_htab = nullptr;
   int vfirst = 1, hscale_on = 0;
   uint32_t hinc = 0;
-  enum Kernel { K_NONE, K_HALF, K_GENERIC, K_TAPS, K_METAL, K_STAGED } kernel = K_NONE;
+  enum Kernel { K_NONE, K_HALF, K_GENERIC, K_TAPS, K_METAL, K_STAGED, K_NTAP } kernel = K_NONE;
   const char *kernel_name = "none";
   // K_STAGED: videoconvert at the input size into `mid` (when the format changes), then per-plane videoscale
   PlaneCfg plane[3];
   int n_out_planes = 0;
   bool need_convert = false, need_scale = false;
   void *mid = nullptr; size_t mid_bytes = 0;
+  // K_NTAP (method=bicubic): optional conversion at the input size by a private child handle, then the n-tap passes
+  VfHipConvertScale *conv = nullptr;
+  int2 *d_nt_h = nullptr, *d_nt_v = nullptr; int nt_h = 0, nt_v = 0;
+  void *nt_mid0 = nullptr, *nt_mid1 = nullptr;
   // pipelined host path (submit / wait): up to two frames in flight, flight k uses staging slots 2k (in) and 2k+1 (out)
   struct Flight { VfHipFrame out; bool staged[VFHIP_MAX_PLANES]; } flight[2];
   int fl_head = 0, fl_count = 0;
@@ -68,6 +73,72 @@ static void free_tables (VfHipConvertScale *h)
   }
   if (h->mid) (void) hipFree (h->mid);
   h->mid = nullptr; h->mid_bytes = 0;
+  if (h->d_nt_h) (void) hipFree (h->d_nt_h);
+  if (h->d_nt_v) (void) hipFree (h->d_nt_v);
+  if (h->nt_mid0) (void) hipFree (h->nt_mid0);
+  if (h->nt_mid1) (void) hipFree (h->nt_mid1);
+  h->d_nt_h = h->d_nt_v = nullptr; h->nt_mid0 = h->nt_mid1 = nullptr; h->nt_h = h->nt_v = 0;
+  if (h->conv) { vfhip_convertscale_free (h->conv); h->conv = nullptr; }
+}
+
+// ---- method=bicubic: GstVideoResampler's cubic set-up (b = 0, c = .5), the same double-precision operations in the same
+// order as oracle/gst114.c gst114_cubic_taps (which is pinned against the real element) -------------------------------
+static double cubic_k (double a)
+{
+  const double b = 0.0, c = 0.5;
+  a = a < 0 ? -a : a;
+  const double a2 = a * a, a3 = a2 * a;
+  if (a <= 1.0) return ((12.0 - 9.0 * b - 6.0 * c) * a3 + (-18.0 + 12.0 * b + 6.0 * c) * a2 + (6.0 - 2.0 * b)) / 6.0;
+  if (a <= 2.0) return ((-b - 6.0 * c) * a3 + (6.0 * b + 30.0 * c) * a2 + (-12.0 * b - 48.0 * c) * a + (8.0 * b + 24.0 * c)) / 6.0;
+  return 0.0;
+}
+
+static int cubic_n_taps (int in, int out)
+{
+  const double scale = (double) in / (double) out;
+  const double fx = scale > 1.0 ? 1.0 / scale : 1.0;
+  return (int) std::ceil (2.0 * 2.0 / fx);
+}
+
+static bool cubic_in_domain (int in, int out) { const int n = cubic_n_taps (in, out); return in == out || (n <= in && n <= 64); }
+
+static int cubic_table (int in, int out, std::vector<int2> &tab)
+{
+  const int n = cubic_n_taps (in, out);
+  const double fx = 2.0 * 2.0 / n;
+  tab.assign ((size_t) n * out, make_int2 (0, 0));
+  for (int j = 0; j < out; j++) {
+    double x = (j + 0.5) * in / out - 0.5;
+    x = x < 0.0 ? 0.0 : (x > in - 1.0 ? in - 1.0 : x);
+    const int xi = (int) std::floor (x) - (n - 1) / 2;
+    double w[64], sum = 0.0, m[64];
+    int pos[64], cnt = 0;
+    for (int l = 0; l < n; l++) { w[l] = cubic_k ((x - (xi + l)) * fx); sum += w[l]; }
+    for (int l = 0; l < n; l++) {                    // taps outside the line are added to the edge tap, in double
+      const int k = xi + l < 0 ? 0 : (xi + l > in - 1 ? in - 1 : xi + l);
+      if (cnt > 0 && pos[cnt - 1] == k) m[cnt - 1] += w[l] / sum;
+      else { pos[cnt] = k; m[cnt] = w[l] / sum; cnt++; }
+    }
+    double lo = 0.0, hi = 1.0, off = 0.5;            // rounding offset that makes the 6-bit taps sum to 64
+    for (int it = 0; it < 64; it++) {
+      int s = 0;
+      for (int l = 0; l < cnt; l++) s += (int) std::floor (off + m[l] * 64.0);
+      if (s == 64) break;
+      if (lo == hi) break;
+      if (s < 64) { if (off > lo) lo = off; off += (hi - lo) / 2; }
+      else { if (off < hi) hi = off; off -= (hi - lo) / 2; }
+    }
+    for (int l = 0; l < n; l++)
+      tab[(size_t) j * n + l] = l < cnt ? make_int2 (pos[l], (int) std::floor (off + m[l] * 64.0)) : make_int2 (pos[cnt - 1], 0);
+  }
+  return n;
+}
+
+static int upload_int2 (const std::vector<int2> &v, int2 **dst)
+{
+  VFHIP_CHECK_HIP (hipMalloc (dst, v.size () * sizeof (int2)));
+  VFHIP_CHECK_HIP (hipMemcpy (*dst, v.data (), v.size () * sizeof (int2), hipMemcpyHostToDevice));
+  return VFHIP_OK;
 }
 
 static int upload_ints (const std::vector<int> &v, int **dst)
@@ -205,7 +276,8 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
       out->width > 32768 || out->height > 32768)
     return set_error (VFHIP_ERR_INVALID, "bad frame size %dx%d -> %dx%d", in->width, in->height, out->width, out->height);
   if (format_n_planes (in->format) < 0 || format_n_planes (out->format) < 0) return VFHIP_ERR_INVALID;
-  if (method != VFHIP_SCALE_BILINEAR && method != VFHIP_SCALE_NEAREST) return set_error (VFHIP_ERR_INVALID, "bad method %d", method);
+  if (method != VFHIP_SCALE_BILINEAR && method != VFHIP_SCALE_NEAREST && method != VFHIP_SCALE_BICUBIC)
+    return set_error (VFHIP_ERR_INVALID, "bad method %d", method);
   if (numerics != VFHIP_NUMERICS_GST_EXACT && numerics != VFHIP_NUMERICS_METAL) return set_error (VFHIP_ERR_INVALID, "bad numerics %d", numerics);
   if (in->color_matrix < 0 || in->color_matrix > 2 || out->color_matrix < 0 || out->color_matrix > 2)
     return set_error (VFHIP_ERR_INVALID, "bad colour matrix");
@@ -226,6 +298,30 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
   // 4:2:0 outputs: pinned for the 2-tap method, no borders, and (YUV -> YUV) an unchanged matrix (no re-matrixing step)
   const bool staged = numerics == VFHIP_NUMERICS_GST_EXACT && in_420_or_rgb && out_420 && method == VFHIP_SCALE_BILINEAR &&
                       !h->add_borders && (!in_yuv || (in->color_matrix == out->color_matrix && in->chroma_site == out->chroma_site));
+  if (method == VFHIP_SCALE_BICUBIC) {
+    const int iw = in->width, ih = in->height, ow = out->width, oh = out->height;
+    if (numerics != VFHIP_NUMERICS_GST_EXACT || !in_420_or_rgb || !out_rgb || h->add_borders)
+      return set_error (VFHIP_ERR_UNSUPPORTED, "method=bicubic needs numerics=gst-exact, an NV12 / I420 / BGRA / RGBA input, a BGRA / RGBA output and no borders");
+    if (!cubic_in_domain (iw, ow) || !cubic_in_domain (ih, oh))
+      return set_error (VFHIP_ERR_UNSUPPORTED, "method=bicubic: %dx%d -> %dx%d has a line shorter than its filter (or more than 64 taps)", iw, ih, ow, oh);
+    if (in->format != out->format) {                  // videoconvert at the input size: the existing gst-exact kernels
+      h->conv = vfhip_convertscale_new (h->dev->ordinal);
+      if (!h->conv) return VFHIP_ERR_HIP;
+      VfHipVideoInfo mid = *out;
+      mid.width = iw; mid.height = ih;
+      int rc = vfhip_convertscale_configure (h->conv, in, &mid, VFHIP_SCALE_BILINEAR, 0, 0, VFHIP_NUMERICS_GST_EXACT);
+      if (rc) return rc;
+      VFHIP_CHECK_HIP (hipMalloc (&h->nt_mid0, (size_t) iw * ih * 4 + 256));
+    }
+    std::vector<int2> t;
+    if (ow != iw) { h->nt_h = cubic_table (iw, ow, t); int rc = upload_int2 (t, &h->d_nt_h); if (rc) return rc; }
+    if (oh != ih) { h->nt_v = cubic_table (ih, oh, t); int rc = upload_int2 (t, &h->d_nt_v); if (rc) return rc; }
+    h->vfirst = ih > oh + h->nt_v ? 1 : 0;           // GstVideoScaler pass order for n taps (oracle/gst114.c)
+    if (h->nt_h && h->nt_v) VFHIP_CHECK_HIP (hipMalloc (&h->nt_mid1, (h->vfirst ? (size_t) iw * oh : (size_t) ow * ih) * 4 + 256));
+    h->kernel = VfHipConvertScale::K_NTAP; h->kernel_name = "k_cs_ntap";
+    h->configured = true;
+    return VFHIP_OK;
+  }
   if (staged) {
     const int iw = in->width, ih = in->height, ow = out->width, oh = out->height;
     h->need_convert = in->format != out->format;
@@ -370,10 +466,64 @@ static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
 
 // launch on device frames; caller holds the mutex
 static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame *out, size_t in_pitch, size_t out_pitch,
+    int n_frames, hipStream_t s);
+
+// method=bicubic: [conversion at the input size ->] n-tap pass -> n-tap pass, in GstVideoScaler's order
+static int ntap_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame *out, hipStream_t s)
+{
+  const int iw = h->in.width, ih = h->in.height, ow = h->out.width, oh = h->out.height;
+  const uint8_t *src = (const uint8_t *) in->data[0];
+  int ss = in->stride[0];
+  if (h->conv) {
+    VfHipFrame mid {};
+    mid.info = h->conv->out;
+    mid.data[0] = h->nt_mid0; mid.stride[0] = iw * 4;
+    int rc = launch_device (h->conv, in, &mid, 0, 0, 1, s);
+    if (rc) return rc;
+    src = (const uint8_t *) h->nt_mid0; ss = iw * 4;
+  }
+  auto pass = [&] (bool vertical, const uint8_t *pin, int pis, uint8_t *pout, int pos, int w, int hh) {
+    NtapParams p {};
+    p.in = pin; p.is = pis; p.out = pout; p.os = pos; p.w = w; p.h = hh;
+    p.n = vertical ? h->nt_v : h->nt_h; p.tab = vertical ? h->d_nt_v : h->d_nt_h;
+    dim3 grid ((unsigned) ((w + 63) / 64), (unsigned) ((hh + 3) / 4));
+    if (vertical) hipLaunchKernelGGL (k_ntap_v, grid, dim3 (64, 4), 0, s, p);
+    else hipLaunchKernelGGL (k_ntap_h, grid, dim3 (64, 4), 0, s, p);
+  };
+  uint8_t *dst = (uint8_t *) out->data[0];
+  const int ds = out->stride[0];
+  if (!h->nt_h && !h->nt_v) {                         // same size: the conversion is everything (or a plain copy)
+    VFHIP_CHECK_HIP (hipMemcpy2DAsync (dst, (size_t) ds, src, (size_t) ss, (size_t) iw * 4, (size_t) ih, hipMemcpyDeviceToDevice, s));
+  } else if (!h->nt_h) pass (true, src, ss, dst, ds, iw, oh);
+  else if (!h->nt_v) pass (false, src, ss, dst, ds, ow, ih);
+  else if (h->vfirst) {
+    pass (true, src, ss, (uint8_t *) h->nt_mid1, iw * 4, iw, oh);
+    pass (false, (const uint8_t *) h->nt_mid1, iw * 4, dst, ds, ow, oh);
+  } else {
+    pass (false, src, ss, (uint8_t *) h->nt_mid1, ow * 4, ow, ih);
+    pass (true, (const uint8_t *) h->nt_mid1, ow * 4, dst, ds, ow, oh);
+  }
+  VFHIP_CHECK_HIP (hipGetLastError ());
+  return VFHIP_OK;
+}
+
+static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame *out, size_t in_pitch, size_t out_pitch,
     int n_frames, hipStream_t s)
 {
   if (n_frames <= 0) return VFHIP_OK;
   if (n_frames > 65535) return set_error (VFHIP_ERR_INVALID, "batch of %d frames exceeds 65535", n_frames);
+  if (h->kernel == VfHipConvertScale::K_NTAP) {
+    for (int k = 0; k < n_frames; k++) {
+      VfHipFrame fi = *in, fo = *out;
+      for (int p = 0; p < 3; p++) {
+        if (fi.data[p]) fi.data[p] = (uint8_t *) fi.data[p] + (size_t) k * in_pitch;
+        if (fo.data[p]) fo.data[p] = (uint8_t *) fo.data[p] + (size_t) k * out_pitch;
+      }
+      int rc = ntap_launch (h, &fi, &fo, s);
+      if (rc) return rc;
+    }
+    return VFHIP_OK;
+  }
   if (h->kernel == VfHipConvertScale::K_STAGED) {
     for (int k = 0; k < n_frames; k++) {
       VfHipFrame fi = *in, fo = *out;

@@ -59,6 +59,7 @@ scale_method_type (void)
   static const GEnumValue v[] = {
     {VFHIP_SCALE_BILINEAR, "Bilinear interpolation", "bilinear"},
     {VFHIP_SCALE_NEAREST, "Nearest-neighbor", "nearest"},
+    {VFHIP_SCALE_BICUBIC, "Bicubic (Catmull-Rom: GStreamer's videoscale method=catrom, bit-exact; RGB outputs)", "bicubic"},
     {0, NULL, NULL}
   };
   if (g_once_init_enter (&t))

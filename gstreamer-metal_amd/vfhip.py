@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libvfhip.so")
 FORMATS = {"BGRA": 0, "RGBA": 1, "NV12": 2, "I420": 3, "UYVY": 4, "YUY2": 5}
 MATRICES = {"bt601": 0, "bt709": 1, "bt2020": 2}
 CHROMA_SITES = {"jpeg": 0, "none": 0, "center": 0, "mpeg2": 1}
-METHODS = {"bilinear": 0, "nearest": 1}
+METHODS = {"bilinear": 0, "nearest": 1, "bicubic": 2}
 NUMERICS = {"gst-exact": 0, "metal": 1}
 FRAME_FLAG_TFF = 1
 

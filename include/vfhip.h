@@ -127,7 +127,11 @@ int vfhip_plane_height (int format, int plane, int height);
 /* ---- convertscale (reference: MetalConvertScaleRenderer) ------------------------------------------ */
 typedef enum {
   VFHIP_SCALE_BILINEAR = 0,      /* VF_METAL_SCALE_BILINEAR, convertscale/metalconvertscalerenderer.h:30-33 */
-  VFHIP_SCALE_NEAREST = 1
+  VFHIP_SCALE_NEAREST = 1,
+  /* additive (the reference has no bicubic; north_star names it): GStreamer's `videoscale method=catrom`, bit-exact, for
+   * numerics = gst-exact, RGB outputs, no borders, and lines at least as long as the filter (ceil(4 * max(1, in/out)) taps,
+   * at most 64); anything else -> VFHIP_ERR_UNSUPPORTED at configure */
+  VFHIP_SCALE_BICUBIC = 2
 } VfHipScaleMethod;
 
 typedef struct VfHipConvertScale VfHipConvertScale;

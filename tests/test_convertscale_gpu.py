@@ -217,3 +217,54 @@ def test_yuv_outputs_1080p_vs_oracle(vfhip, oracle, ifmt, ofmt):
         got, _ = run(vfhip, ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", ofmt, ow, oh)
         want = oracle.convertscale(ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", ofmt, ow, oh)
         assert np.array_equal(meaningful(ofmt, ow, oh, got), meaningful(ofmt, ow, oh, want))
+
+
+# ---- method=bicubic (videoscale method=catrom) ---------------------------------------------------------------------
+from test_oracle_golden import MANIFEST_B, ZB, cubic_in_domain  # noqa: E402
+
+
+@pytest.mark.parametrize("case", [c for c in MANIFEST_B if cubic_in_domain(c)], ids=[c["name"] for c in MANIFEST_B if cubic_in_domain(c)])
+def test_golden_gstreamer_vectors_bicubic(vfhip, case):
+    raw, want = ZB[case["name"] + "_in"], ZB[case["name"] + "_out"]
+    col, site = case["colorimetry"], case["chroma_site"]
+    if col is None:
+        col, site = oracle_lib.default_colorimetry(case["h"])
+    got, kname = run(vfhip, case["in_format"], case["w"], case["h"], raw, col, site, "bicubic", case["out_format"], case["ow"], case["oh"])
+    assert kname == "k_cs_ntap"
+    assert np.array_equal(got.reshape(-1), want), f"{(got.reshape(-1) != want).sum()} bytes differ"
+
+
+def test_bicubic_outside_the_pinned_domain_is_refused(vfhip):
+    cs = vfhip.ConvertScale(0)
+    for (w, h, ow, oh, ofmt, kw) in [(3, 3, 7, 5, "BGRA", {}), (16, 16, 1, 1, "BGRA", {}), (64, 36, 32, 18, "NV12", {}), (64, 36, 32, 18, "BGRA", dict(numerics="metal")),
+                                     (64, 36, 32, 18, "BGRA", dict(add_borders=True))]:
+        with pytest.raises(vfhip.VfHipError) as e:
+            cs.configure("NV12", w, h, ofmt, ow, oh, method="bicubic", **kw)
+        assert e.value.code == -2                       # VFHIP_ERR_UNSUPPORTED
+    cs.close()
+
+
+def test_bicubic_1080p_to_540p_vs_oracle_and_batch(vfhip, oracle):
+    """the headline shape at half size (vertical pass first, 8 taps each way) against the oracle, plus a 3-frame batch"""
+    import torch
+    w, h, ow, oh = 1920, 1080, 960, 540
+    rng = np.random.default_rng(5)
+    size = vfhip.plane_layout("NV12", w, h)[1]
+    frames = [rng.integers(0, 256, size, dtype=np.uint8) for _ in range(3)]
+    cs = vfhip.ConvertScale(0)
+    cs.configure("NV12", w, h, "BGRA", ow, oh, method="bicubic", colorimetry="bt709", chroma_site="mpeg2")
+    want = [oracle.convertscale("NV12", w, h, f, "bt709", "mpeg2", "bicubic", "BGRA", ow, oh) for f in frames]
+    assert np.array_equal(cs.process(frames[0]).reshape(oh, ow, 4), want[0])
+    pitch = (size + 255) // 256 * 256
+    ring = np.zeros((3, pitch), np.uint8)
+    for k, f in enumerate(frames):
+        ring[k, :size] = f
+    din, dout = torch.from_numpy(ring).cuda(), torch.zeros((3, ow * oh * 4), dtype=torch.uint8, device="cuda")
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    cs.process_device(din.data_ptr(), dout.data_ptr(), stream=s.cuda_stream, n_frames=3, in_pitch=pitch, out_pitch=ow * oh * 4)
+    s.synchronize()
+    out = dout.cpu().numpy().reshape(3, oh, ow, 4)
+    for k in range(3):
+        assert np.array_equal(out[k], want[k]), f"frame {k}"
+    cs.close()

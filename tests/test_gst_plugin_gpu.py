@@ -253,3 +253,16 @@ def test_recurring_upstream_memory_is_page_locked_in_place(tmp_path):
     assert r.returncode == 0, r.stderr
     x, y = np.fromfile(a, np.uint8), np.fromfile(b, np.uint8)
     assert x.size == y.size == 12 * 640 * 360 * 4 and np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("iw,ih,ow,oh,fmt", [(1920, 1080, 640, 480, "NV12"), (1280, 720, 1920, 1080, "I420"), (720, 576, 360, 288, "NV12"), (640, 480, 320, 240, "BGRA")])
+def test_pixel_parity_bicubic_with_cpu_videoscale_catrom(tmp_path, iw, ih, ow, oh, fmt):
+    """method=bicubic is byte-identical to videoconvert ! videoscale method=catrom on the same frames"""
+    a, b = tmp_path / "cpu.raw", tmp_path / "hip.raw"
+    r = gst_env.launch(f"videotestsrc num-buffers=2 ! {caps(fmt, iw, ih)} ! tee name=t "
+                       f"t. ! queue ! videoconvert ! videoscale method=catrom ! {caps('BGRA', ow, oh)} ! filesink location={a} "
+                       f"t. ! queue ! vfhipconvertscale method=bicubic ! {caps('BGRA', ow, oh)} ! filesink location={b}", timeout=300)
+    assert r.returncode == 0, r.stderr
+    x, y = np.fromfile(a, np.uint8), np.fromfile(b, np.uint8)
+    assert x.size == y.size == 2 * ow * oh * 4
+    assert np.array_equal(x, y), f"max diff {np.abs(x.astype(int) - y.astype(int)).max()}, {(x != y).sum()} bytes differ"
