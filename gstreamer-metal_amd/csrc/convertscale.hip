@@ -108,7 +108,7 @@ static int cubic_table (int in, int out, std::vector<int2> &tab)
   const double fx = 2.0 * 2.0 / n;
   tab.assign ((size_t) n * out, make_int2 (0, 0));
   for (int j = 0; j < out; j++) {
-    double x = (j + 0.5) * in / out - 0.5;
+    double x = ((j + 0.5) / out) * in - 0.5;        // this order: the quotient first (it decides which way exact .5 ties fall)
     x = x < 0.0 ? 0.0 : (x > in - 1.0 ? in - 1.0 : x);
     const int xi = (int) std::floor (x) - (n - 1) / 2;
     double w[64], sum = 0.0, m[64];

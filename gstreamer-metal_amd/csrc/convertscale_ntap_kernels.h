@@ -21,11 +21,28 @@ struct NtapParams {
   const int2 *tab;          // [out samples][n] of {source index, 6-bit weight}
 };
 
-__device__ __forceinline__ uint32_t ntap_finish (int a0, int a1, int a2, int a3)
+// The sums are accumulated in f32: every term is an 8-bit sample times a 6-bit signed weight and |sum| < 2^15, far inside
+// the 24-bit range in which f32 integer arithmetic is exact; v_cvt_f32_ubyteN extracts and converts a byte in one
+// instruction and v_fma_f32 issues at full rate.
+struct Acc4 { float a0, a1, a2, a3; };
+__device__ __forceinline__ void ntap_acc (Acc4 &a, uint32_t v, int tap)
 {
-  a0 = min (max ((a0 + 32) >> 6, 0), 255); a1 = min (max ((a1 + 32) >> 6, 0), 255);
-  a2 = min (max ((a2 + 32) >> 6, 0), 255); a3 = min (max ((a3 + 32) >> 6, 0), 255);
-  return (uint32_t) a0 | ((uint32_t) a1 << 8) | ((uint32_t) a2 << 16) | ((uint32_t) a3 << 24);
+  const float t = (float) tap;
+  a.a0 = fmaf ((float) (v & 0xff), t, a.a0); a.a1 = fmaf ((float) ((v >> 8) & 0xff), t, a.a1);
+  a.a2 = fmaf ((float) ((v >> 16) & 0xff), t, a.a2); a.a3 = fmaf ((float) (v >> 24), t, a.a3);
+}
+
+// clamp ((sum + 32) >> 6, 0, 255) per channel, packed.  Done in f32 as well — floor (sum / 64 + .5) is exact, and
+// v_cvt_pk_u8_f32 saturates and inserts the byte.  NOT written as integer shift + min/max: hipcc (ROCm 7.2) fuses that
+// pattern into gfx950's v_ashr_pk_u8_i32 and then ORs the other two channels into the result's upper half, which the
+// instruction does not clear (it kept the bits of its first source: every pixel whose first channel summed negative came
+// out with 255 in the third) — found by the golden-vector tests.
+__device__ __forceinline__ uint32_t ntap_finish (const Acc4 &a)
+{
+  uint32_t q = __builtin_amdgcn_cvt_pk_u8_f32 (floorf (fmaf (a.a0, 0.015625f, 0.5f)), 0u, 0u);
+  q = __builtin_amdgcn_cvt_pk_u8_f32 (floorf (fmaf (a.a1, 0.015625f, 0.5f)), 1u, q);
+  q = __builtin_amdgcn_cvt_pk_u8_f32 (floorf (fmaf (a.a2, 0.015625f, 0.5f)), 2u, q);
+  return __builtin_amdgcn_cvt_pk_u8_f32 (floorf (fmaf (a.a3, 0.015625f, 0.5f)), 3u, q);
 }
 
 __global__ __launch_bounds__ (256) void k_ntap_v (const NtapParams p)
@@ -34,13 +51,12 @@ __global__ __launch_bounds__ (256) void k_ntap_v (const NtapParams p)
   const int y = __builtin_amdgcn_readfirstlane ((int) (blockIdx.y * 4 + threadIdx.y));      // one row per wave
   if (y >= p.h || x >= p.w) return;
   const int2 *t = p.tab + (size_t) y * p.n;
-  int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  Acc4 a = { 0.0f, 0.0f, 0.0f, 0.0f };
   for (int l = 0; l < p.n; l++) {
     const int2 e = t[l];
-    const uint32_t v = *reinterpret_cast<const uint32_t *> (p.in + (size_t) e.x * p.is + 4 * x);
-    a0 += (int) (v & 0xff) * e.y; a1 += (int) ((v >> 8) & 0xff) * e.y; a2 += (int) ((v >> 16) & 0xff) * e.y; a3 += (int) (v >> 24) * e.y;
+    ntap_acc (a, *reinterpret_cast<const uint32_t *> (p.in + (size_t) e.x * p.is + 4 * x), e.y);
   }
-  *reinterpret_cast<uint32_t *> (p.out + (size_t) y * p.os + 4 * x) = ntap_finish (a0, a1, a2, a3);
+  *reinterpret_cast<uint32_t *> (p.out + (size_t) y * p.os + 4 * x) = ntap_finish (a);
 }
 
 __global__ __launch_bounds__ (256) void k_ntap_h (const NtapParams p)
@@ -49,13 +65,12 @@ __global__ __launch_bounds__ (256) void k_ntap_h (const NtapParams p)
   if (y >= p.h || x >= p.w) return;
   const int2 *t = p.tab + (size_t) x * p.n;
   const uint8_t *row = p.in + (size_t) y * p.is;
-  int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  Acc4 a = { 0.0f, 0.0f, 0.0f, 0.0f };
   for (int l = 0; l < p.n; l++) {
     const int2 e = t[l];
-    const uint32_t v = *reinterpret_cast<const uint32_t *> (row + 4 * e.x);
-    a0 += (int) (v & 0xff) * e.y; a1 += (int) ((v >> 8) & 0xff) * e.y; a2 += (int) ((v >> 16) & 0xff) * e.y; a3 += (int) (v >> 24) * e.y;
+    ntap_acc (a, *reinterpret_cast<const uint32_t *> (row + 4 * e.x), e.y);
   }
-  *reinterpret_cast<uint32_t *> (p.out + (size_t) y * p.os + 4 * x) = ntap_finish (a0, a1, a2, a3);
+  *reinterpret_cast<uint32_t *> (p.out + (size_t) y * p.os + 4 * x) = ntap_finish (a);
 }
 
 }  // namespace vfhip

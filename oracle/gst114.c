@@ -172,7 +172,7 @@ static void hscale (const uint8_t *in, int is, int w, int h, uint8_t *out, int o
  * real element (impulse responses give every 6-bit tap exactly; random frames confirm arithmetic and pass order;
  * tests/golden/convertscale_gst114_bicubic.npz):
  *   scale = in / out; fx = min (1, 1 / scale); n_taps = ceil (4 / fx); fx = 4 / n_taps        (envelope 2)
- *   x = clamp ((j + .5) * in / out - .5, 0, in - 1); first tap at floor (x) - (n_taps - 1) / 2
+ *   x = clamp (((j + .5) / out) * in - .5, 0, in - 1) in exactly this order; first tap at floor (x) - (n_taps - 1) / 2
  *   w_l = k ((x - x_l) * fx), Mitchell-Netravali form with b = 0, c = .5, normalised by their sum; taps that fall outside
  *   the line are ADDED to the edge tap in double precision; then t_l = floor (offset + 64 w_l) with the offset found by
  *   bisection from .5 so that the taps sum to 64 (<= 64 steps);
@@ -202,7 +202,7 @@ int gst114_cubic_taps (int in, int out, int *idx, int *taps, int max_entries)
   if (n > 64 || n > in || (long) n * out > max_entries) return -1;
   const double fx = 2.0 * 2.0 / n;
   for (int j = 0; j < out; j++) {
-    double x = (j + 0.5) * in / out - 0.5;
+    double x = ((j + 0.5) / out) * in - 0.5;        /* this order: the quotient first (it decides which way exact .5 ties fall) */
     x = x < 0.0 ? 0.0 : (x > in - 1.0 ? in - 1.0 : x);
     const int xi = (int) __builtin_floor (x) - (n - 1) / 2;
     double w[64], sum = 0.0, m[64];

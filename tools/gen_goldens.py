@@ -129,7 +129,8 @@ def gen_bicubic():
         rng = np.random.default_rng(20261005)
         cols, sites = ["bt601", "bt709", "bt2020"], ["jpeg", "mpeg2"]
         sizes = [(64, 36, 32, 18), (64, 36, 128, 72), (48, 40, 20, 37), (48, 40, 96, 38), (33, 17, 16, 8), (200, 8, 100, 4), (8, 200, 4, 100),
-                 (64, 16, 32, 8), (64, 18, 32, 9), (17, 13, 11, 29), (96, 54, 96, 20), (96, 54, 31, 54), (3, 3, 7, 5), (40, 30, 9, 7), (16, 16, 1, 1)]
+                 (64, 16, 32, 8), (64, 18, 32, 9), (17, 13, 11, 29), (96, 54, 96, 20), (96, 54, 31, 54), (3, 3, 7, 5), (40, 30, 9, 7), (16, 16, 1, 1),
+                 (300, 12, 100, 12), (195, 9, 65, 21)]    # 3:1 with a non-power-of-two output: exposes the order of (j + .5) / out * in
         sizes += [tuple(int(v) for v in rng.integers(2, 97, 4)) for _ in range(10)]
         t = 0
         for fmt in ["NV12", "I420", "BGRA", "RGBA"]:
