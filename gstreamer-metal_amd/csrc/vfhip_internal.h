@@ -70,6 +70,8 @@ int download_finish (Staging &st, size_t slot, VfHipFrame *host, const bool stag
 }  // namespace vfhip
 
 namespace vfhip {
+// PNG -> straight RGBA8 (image_png.hip; host code, zlib)
+int decode_png (const char *path, std::vector<uint8_t> &rgba, int *width, int *height);
 // shared argument checks of the element entry points
 int check_frame (const VfHipFrame *f, const VfHipVideoInfo *want, const char *what);
 }  // namespace vfhip

@@ -117,6 +117,35 @@ def test_deinterlace_device_path_history(vfhip, metalref):
     d.close()
 
 
+@pytest.mark.parametrize("n,per_row", [(8, 8), (16, 4), (4, 2)])
+def test_videofilter_png_lut_file(vfhip, metalref, tmp_path, n, per_row):
+    """PNG LUT layout of the reference (parse_png_lut, metalvideofilterrenderer.m:166-305): N x N slices, width / N per row"""
+    import png_util
+    rng = np.random.default_rng(n)
+    lut8 = rng.integers(0, 256, (n, n, n, 3), dtype=np.uint8)              # [b][g][r]
+    rows = (n + per_row - 1) // per_row
+    img = np.zeros((rows * n, per_row * n, 3), np.uint8)
+    for b in range(n):
+        img[(b // per_row) * n:(b // per_row + 1) * n, (b % per_row) * n:(b % per_row + 1) * n] = lut8[b]
+    path = tmp_path / "lut.png"
+    png_util.write_png(path, img, 2, 8, filters=[1, 4])
+    w, h = 48, 24
+    raw = smooth("BGRA", w, h, 9)
+    vf = vfhip.VideoFilter(0)
+    vf.configure("BGRA", w, h)
+    vf.load_lut(str(path))
+    assert vf.lut_size == n
+    lut = np.ones((n, n, n, 4), np.float32)
+    lut[..., :3] = lut8.astype(np.float32) / np.float32(255.0)
+    prm = vfhip.filter_params(contrast=1.1)
+    close(vf.process(raw, prm), metalref.videofilter("BGRA", w, h, raw, "BGRA", ol.mr_filter_params(prm), lut=lut), "png lut", max_off_by_one=0.05)
+    png_util.write_png(tmp_path / "odd.png", np.zeros((5, 7, 3), np.uint8), 2)          # 35 pixels: no cube
+    with pytest.raises(vfhip.VfHipError):
+        vf.load_lut(str(tmp_path / "odd.png"))
+    assert vf.lut_size == n
+    vf.close()
+
+
 SINGLE = [dict(brightness=0.3), dict(brightness=-0.4), dict(contrast=1.7), dict(contrast=0.3), dict(saturation=0.0), dict(saturation=1.8),
           dict(hue=1.0), dict(hue=-2.5), dict(gamma=2.2), dict(gamma=0.45), dict(sepia=0.8), dict(invert=True), dict(vignette=0.9),
           dict(chroma_key=(0.0, 1.0, 0.0), tolerance=0.3, smoothness=0.1), dict(chroma_key=(0.5, 0.5, 0.5), tolerance=0.2, smoothness=0.0),
@@ -205,8 +234,10 @@ def test_videofilter_cube_lut_file(vfhip, metalref, tmp_path):
         vf.load_lut(str(tmp_path / "missing.cube"))
     assert e.value.code == -7
     with pytest.raises(vfhip.VfHipError) as e:
-        vf.load_lut(str(tmp_path / "lut.png"))
+        vf.load_lut(str(tmp_path / "lut.txt"))
     assert e.value.code == -2
+    with pytest.raises(vfhip.VfHipError):
+        vf.load_lut(str(tmp_path / "missing.png"))
     (tmp_path / "bad.cube").write_text("LUT_3D_SIZE 3\n0 0 0\n")
     with pytest.raises(vfhip.VfHipError):
         vf.load_lut(str(tmp_path / "bad.cube"))
