@@ -51,7 +51,7 @@ def _load():
     lib = C.CDLL(LIB_PATH)
     lib.vfhip_last_error_string.restype = C.c_char_p
     for n in ("vfhip_pinned_alloc", "vfhip_device_malloc", "vfhip_convertscale_new", "vfhip_deinterlace_new",
-              "vfhip_videofilter_new", "vfhip_compositor_new", "vfhip_transform_new"):
+              "vfhip_videofilter_new", "vfhip_compositor_new", "vfhip_transform_new", "vfhip_overlay_new"):
         getattr(lib, n).restype = C.c_void_p
     lib.vfhip_convertscale_kernel_name.restype = C.c_char_p
     lib.vfhip_pinned_alloc.argtypes = [C.c_int, C.c_size_t]
@@ -91,6 +91,14 @@ def _load():
     lib.vfhip_transform_process_device_batch.argtypes = batch + [C.POINTER(TransformParams), C.c_void_p]
     lib.vfhip_compositor_composite_device_batch.argtypes = [C.c_void_p, C.POINTER(PadInput), C.POINTER(C.c_size_t), C.c_int, C.c_int,
                                                             C.POINTER(Frame), C.c_size_t, C.c_int, C.c_void_p]
+    lib.vfhip_overlay_configure.argtypes = [C.c_void_p, C.POINTER(VideoInfo), C.POINTER(VideoInfo)]
+    lib.vfhip_overlay_load_image.argtypes = [C.c_void_p, C.c_char_p]
+    lib.vfhip_overlay_set_image.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.vfhip_overlay_image_size.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.vfhip_overlay_process.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(Frame), C.POINTER(OverlayParams)]
+    lib.vfhip_overlay_process_device_batch.argtypes = batch + [C.POINTER(OverlayParams), C.c_void_p]
+    for n in ("vfhip_overlay_clear_image", "vfhip_overlay_cleanup", "vfhip_overlay_free"):
+        getattr(lib, n).argtypes = [C.c_void_p]
     lib.vfhip_transform_cleanup.argtypes = [C.c_void_p]
     lib.vfhip_transform_free.argtypes = [C.c_void_p]
     for n in ("vfhip_deinterlace_reset", "vfhip_deinterlace_cleanup", "vfhip_deinterlace_free", "vfhip_videofilter_clear_lut",
@@ -115,6 +123,10 @@ class VideoFilterParams(C.Structure):
 class TransformParams(C.Structure):
     _fields_ = [("method", C.c_int32), ("crop_top", C.c_int32), ("crop_bottom", C.c_int32), ("crop_left", C.c_int32),
                 ("crop_right", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class OverlayParams(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("width", C.c_float), ("height", C.c_float), ("alpha", C.c_float)]
 
 
 class PadInput(C.Structure):
@@ -434,3 +446,51 @@ class Transform(_Element):
         fo = frame_from_base(self.out_info, self.out_fmt, self.w, self.hh, out_ptr)
         prm = TransformParams(TRANSFORM_METHODS[method], *crop)
         check(lib.vfhip_transform_process_device_batch(self.h, C.byref(fi), C.byref(fo), in_pitch, out_pitch, n_frames, C.byref(prm), stream))
+
+
+class Overlay(_Element):
+    """MetalOverlayRenderer equivalent (reference overlay/metaloverlayrenderer.h)."""
+    _free = "vfhip_overlay_free"
+
+    def __init__(self, device=-1):
+        self.h = lib.vfhip_overlay_new(device)
+        if not self.h:
+            raise VfHipError(-6, lib.vfhip_last_error_string().decode(errors="replace"))
+
+    def configure(self, in_fmt, w, h, out_fmt=None, colorimetry="bt601"):
+        self.in_fmt, self.out_fmt, self.w, self.hh = in_fmt, out_fmt or in_fmt, w, h
+        self.in_info = make_info(in_fmt, w, h, colorimetry)
+        self.out_info = make_info(self.out_fmt, w, h, colorimetry)
+        check(lib.vfhip_overlay_configure(self.h, C.byref(self.in_info), C.byref(self.out_info)))
+        return self
+
+    def load_image(self, path):
+        check(lib.vfhip_overlay_load_image(self.h, (path or "").encode()))
+
+    def set_image(self, rgba):
+        """rgba: (h, w, 4) uint8, the bytes the shader sees (the reference's texture is premultiplied)"""
+        rgba = np.ascontiguousarray(rgba, np.uint8)
+        check(lib.vfhip_overlay_set_image(self.h, rgba.ctypes.data, rgba.shape[1], rgba.shape[0]))
+
+    def clear_image(self):
+        lib.vfhip_overlay_clear_image(self.h)
+
+    @property
+    def image_size(self):
+        w, h = C.c_int(), C.c_int()
+        return (w.value, h.value) if lib.vfhip_overlay_image_size(self.h, C.byref(w), C.byref(h)) else None
+
+    def process(self, raw_in, x=0.0, y=0.0, width=0.0, height=0.0, alpha=1.0):
+        raw_in = np.ascontiguousarray(raw_in, dtype=np.uint8)
+        out = np.zeros(plane_layout(self.out_fmt, self.w, self.hh)[1], np.uint8)
+        fi = frame_from_base(self.in_info, self.in_fmt, self.w, self.hh, raw_in.ctypes.data)
+        fo = frame_from_base(self.out_info, self.out_fmt, self.w, self.hh, out.ctypes.data)
+        prm = OverlayParams(x, y, width, height, alpha)
+        check(lib.vfhip_overlay_process(self.h, C.byref(fi), C.byref(fo), C.byref(prm)))
+        return out
+
+    def process_device(self, in_ptr, out_ptr, x=0.0, y=0.0, width=0.0, height=0.0, alpha=1.0, stream=None, n_frames=1, in_pitch=0, out_pitch=0):
+        fi = frame_from_base(self.in_info, self.in_fmt, self.w, self.hh, in_ptr)
+        fo = frame_from_base(self.out_info, self.out_fmt, self.w, self.hh, out_ptr)
+        prm = OverlayParams(x, y, width, height, alpha)
+        check(lib.vfhip_overlay_process_device_batch(self.h, C.byref(fi), C.byref(fo), in_pitch, out_pitch, n_frames, C.byref(prm), stream))

@@ -279,6 +279,29 @@ int vfhip_transform_process_device_batch (VfHipTransform *h, const VfHipFrame *i
 void vfhip_transform_cleanup (VfHipTransform *h);
 void vfhip_transform_free (VfHipTransform *h);
 
+/* ---- overlay: a still image blended over the video (reference: MetalOverlayRenderer, overlay/metaloverlayrenderer.{h,m}) --
+ * SURVEY.md §8f "next" item 4.  Output size == input size.  Without an image the frame only passes through the 8-bit
+ * render target (the element is in passthrough then, gstvfmetaloverlay.m:94-99). */
+typedef struct {
+  float x, y;                 /* top-left corner of the image in frame pixels (OverlayParams, metaloverlayrenderer.h:30-36) */
+  float width, height;        /* drawn size in pixels; <= 0: the image's own size */
+  float alpha;                /* opacity 0..1, multiplies the image's alpha */
+} VfHipOverlayParams;
+
+typedef struct VfHipOverlay VfHipOverlay;
+VfHipOverlay *vfhip_overlay_new (int device);
+int vfhip_overlay_configure (VfHipOverlay *h, const VfHipVideoInfo *in, const VfHipVideoInfo *out);
+int vfhip_overlay_load_image (VfHipOverlay *h, const char *path);     /* -loadImageFromFile: (PNG; NULL / "" clears) */
+int vfhip_overlay_set_image (VfHipOverlay *h, const uint8_t *rgba, int width, int height);   /* bytes as the shader sees them */
+void vfhip_overlay_clear_image (VfHipOverlay *h);
+int vfhip_overlay_image_size (VfHipOverlay *h, int *width, int *height);                     /* returns 1 when an image is loaded */
+int vfhip_overlay_process (VfHipOverlay *h, const VfHipFrame *in, VfHipFrame *out, const VfHipOverlayParams *params);
+int vfhip_overlay_process_device (VfHipOverlay *h, const VfHipFrame *in, VfHipFrame *out, const VfHipOverlayParams *params, void *stream);
+int vfhip_overlay_process_device_batch (VfHipOverlay *h, const VfHipFrame *in0, VfHipFrame *out0, size_t in_frame_pitch,
+    size_t out_frame_pitch, int n_frames, const VfHipOverlayParams *params, void *stream);
+void vfhip_overlay_cleanup (VfHipOverlay *h);
+void vfhip_overlay_free (VfHipOverlay *h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -540,3 +540,31 @@ int metalref_transform (const MrImg *in, const MrImg *out, int method, int crop_
   free (q);
   return 0;
 }
+
+
+/* ---- overlay: video sampled 1:1, the image bilinear inside its rectangle, rgb = mix (video, image, image.a * alpha)
+ * (overlayFragmentRGBA / NV12 / I420, overlay/metaloverlay_shaders.h:60-151).  Quirk kept: the reference's decoder hands
+ * the shader PREMULTIPLIED colours which it then mixes as if they were straight (metaloverlayrenderer.m:214-219). ---- */
+int metalref_overlay (const MrImg *in, const MrImg *out, const MrImg *ov, float ox, float oy, float ow, float oh, float alpha)
+{
+  const int w = out->w, h = out->h;
+  uint32_t *q = malloc ((size_t) w * h * 4);
+  if (!q) return -2;
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      F4 v = fetch_1to1 (in, x, y, 1);
+      if (ov) {
+        const float tu = ((float) x + 0.5f) / (float) w, tv = ((float) y + 0.5f) / (float) h;
+        const float px = tu * (float) w, py = tv * (float) h;
+        if (px >= ox && px < ox + ow && py >= oy && py < oy + oh) {
+          const F4 o = sample_rgba (ov, (px - ox) / ow, (py - oy) / oh, 1);
+          const float a = o.a * alpha;
+          v.r = v.r + (o.r - v.r) * a; v.g = v.g + (o.g - v.g) * a; v.b = v.b + (o.b - v.b) * a;
+        }
+      }
+      q[(size_t) y * w + x] = quant_rgba8 (v);
+    }
+  store_image (out, q);
+  free (q);
+  return 0;
+}

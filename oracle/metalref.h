@@ -45,6 +45,10 @@ int metalref_compositor (const MrPad *pads, int n, int background, const MrImg *
 /* transform (transform/metaltransform_shaders.h:40-120, metaltransformrenderer.m:44-104,265-293) */
 int metalref_transform (const MrImg *in, const MrImg *out, int method, int crop_top, int crop_bottom, int crop_left, int crop_right);
 
+/* overlay (overlay/metaloverlay_shaders.h:60-151, metaloverlayrenderer.m:247-300): `ov` = RGBA8 image as the reference's
+ * texture holds it (already premultiplied by its decoder); ov == NULL -> plain copy through the 8-bit target */
+int metalref_overlay (const MrImg *in, const MrImg *out, const MrImg *ov, float x, float y, float width, float height, float alpha);
+
 #ifdef __cplusplus
 }
 #endif

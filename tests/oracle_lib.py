@@ -254,10 +254,30 @@ def _mr_transform(self, in_fmt, w, h, raw, out_fmt, method, crop=(0, 0, 0, 0), m
 MetalRef.transform = _mr_transform
 
 
+def _mr_overlay(self, in_fmt, w, h, raw, out_fmt, image, x=0.0, y=0.0, width=0.0, height=0.0, alpha=1.0, m709=False):
+    """image: (ih, iw, 4) uint8 as the shader sees it, or None"""
+    raw = np.ascontiguousarray(raw, np.uint8)
+    out = np.zeros(raw_layout(out_fmt, w, h)[1], np.uint8)
+    i, o = mr_img(in_fmt, w, h, raw, m709), mr_img(out_fmt, w, h, out, m709)
+    ov = None
+    if image is not None:
+        image = np.ascontiguousarray(image, np.uint8)
+        ih, iw = image.shape[:2]
+        ovi = mr_img("RGBA", iw, ih, image.reshape(-1))
+        ov = C.byref(ovi)
+        width, height = (width if width > 0 else iw), (height if height > 0 else ih)
+    f = C.c_float
+    assert self.lib.metalref_overlay(C.byref(i), C.byref(o), ov, f(x), f(y), f(width), f(height), f(alpha)) == 0
+    return out
+
+
+MetalRef.overlay = _mr_overlay
+
+
 def load_metalref():
     build()
     lib = C.CDLL(LIB)
-    for n in ("metalref_convertscale", "metalref_deinterlace", "metalref_videofilter", "metalref_compositor", "metalref_transform"):
+    for n in ("metalref_convertscale", "metalref_deinterlace", "metalref_videofilter", "metalref_compositor", "metalref_transform", "metalref_overlay"):
         getattr(lib, n).restype = C.c_int
     return MetalRef(lib)
 

@@ -487,3 +487,64 @@ def test_transform_batch(vfhip, metalref):
     for k in range(n):
         close(out[k, :size], metalref.transform("I420", w, h, frames[k], "I420", 2, crop=(2, 4, 6, 0)), f"batch transform frame {k}")
     t.close()
+
+
+# ---- overlay ---------------------------------------------------------------------------------------------------------
+def _logo(w, h, seed=0):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.zeros((h, w, 4), np.uint8)
+    img[..., 0] = (xx * 255 // max(w - 1, 1)); img[..., 1] = (yy * 255 // max(h - 1, 1)); img[..., 2] = rng.integers(0, 256, (h, w))
+    img[..., 3] = np.clip(255 - 6 * np.hypot(xx - w / 2, yy - h / 2), 0, 255)          # soft round alpha
+    return img
+
+
+@pytest.mark.parametrize("ifmt,ofmt", [("BGRA", "BGRA"), ("RGBA", "NV12"), ("NV12", "NV12"), ("I420", "BGRA"), ("NV12", "I420")])
+def test_overlay_formats_and_placement(vfhip, metalref, ifmt, ofmt):
+    w, h = 96, 54
+    raw = smooth(ifmt, w, h, 11)
+    img = _logo(24, 16)
+    ov = vfhip.Overlay(0)
+    ov.configure(ifmt, w, h, ofmt, colorimetry="bt709")
+    ov.set_image(img)
+    assert ov.image_size == (24, 16)
+    for kw in (dict(x=10, y=7, alpha=0.8), dict(x=-5, y=40, width=50, height=30, alpha=1.0), dict(x=80, y=0, width=0, height=9, alpha=0.35),
+               dict(x=30.5, y=12.25, width=33.3, height=20.7, alpha=0.6), dict(x=200, y=200, alpha=1.0)):
+        got = ov.process(raw, **kw)
+        want = metalref.overlay(ifmt, w, h, raw, ofmt, img, m709=True, **kw)
+        close(got, want, f"overlay {ifmt}->{ofmt} {kw}", max_off_by_one=0.03)
+    ov.clear_image()
+    assert ov.image_size is None
+    close(ov.process(raw), metalref.overlay(ifmt, w, h, raw, ofmt, None, m709=True), "overlay without image")
+    ov.close()
+
+
+def test_overlay_png_file_and_batch(vfhip, metalref, tmp_path):
+    import png_util
+    import torch
+    w, h, n = 80, 48, 3
+    img = _logo(20, 20, 3)
+    path = tmp_path / "logo.png"
+    png_util.write_png(path, img, 6, 8, filters=[4, 2])
+    ov = vfhip.Overlay(0)
+    ov.configure("BGRA", w, h)
+    ov.load_image(str(path))
+    pre = img.copy()
+    pre[..., :3] = (img[..., :3].astype(np.uint32) * img[..., 3:4] + 127) // 255            # what the loader premultiplies to
+    frames = [smooth("BGRA", w, h, 20 + k) for k in range(n)]
+    close(ov.process(frames[0], x=30, y=10, alpha=0.9), metalref.overlay("BGRA", w, h, frames[0], "BGRA", pre, x=30, y=10, alpha=0.9), "png overlay")
+    pitch = (4 * w * h + 255) // 256 * 256
+    din, dout = _ring(frames, pitch), torch.zeros((n, pitch), dtype=torch.uint8, device="cuda")
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    ov.process_device(din.data_ptr(), dout.data_ptr(), x=5, y=5, width=40, height=30, alpha=0.5, stream=s.cuda_stream, n_frames=n, in_pitch=pitch, out_pitch=pitch)
+    s.synchronize()
+    out = dout.cpu().numpy()
+    for k in range(n):
+        close(out[k, :4 * w * h], metalref.overlay("BGRA", w, h, frames[k], "BGRA", pre, x=5, y=5, width=40, height=30, alpha=0.5), f"batch overlay {k}")
+    with pytest.raises(vfhip.VfHipError) as e:
+        ov.load_image(str(tmp_path / "logo.jpg"))
+    assert e.value.code == -2 and ov.image_size == (20, 20)
+    ov.load_image("")                                       # empty path clears, like the reference
+    assert ov.image_size is None
+    ov.close()
