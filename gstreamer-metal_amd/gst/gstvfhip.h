@@ -21,6 +21,7 @@ gboolean gst_vfhip_videofilter_register (GstPlugin * plugin);
 gboolean gst_vfhip_deinterlace_register (GstPlugin * plugin);
 gboolean gst_vfhip_compositor_register (GstPlugin * plugin);
 gboolean gst_vfhip_transform_register (GstPlugin * plugin);
+gboolean gst_vfhip_overlay_register (GstPlugin * plugin);
 
 /* pinned host memory for GstBuffers (gstvfhipallocator.c) */
 GstAllocator *gst_vfhip_pinned_allocator_get (void);

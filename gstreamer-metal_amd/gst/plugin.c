@@ -22,6 +22,7 @@ plugin_init (GstPlugin * plugin)
   ok &= gst_vfhip_deinterlace_register (plugin);
   ok &= gst_vfhip_compositor_register (plugin);
   ok &= gst_vfhip_transform_register (plugin);
+  ok &= gst_vfhip_overlay_register (plugin);
   return ok;
 }
 

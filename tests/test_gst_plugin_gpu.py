@@ -266,3 +266,45 @@ def test_pixel_parity_bicubic_with_cpu_videoscale_catrom(tmp_path, iw, ih, ow, o
     x, y = np.fromfile(a, np.uint8), np.fromfile(b, np.uint8)
     assert x.size == y.size == 2 * ow * oh * 4
     assert np.array_equal(x, y), f"max diff {np.abs(x.astype(int) - y.astype(int)).max()}, {(x != y).sum()} bytes differ"
+
+
+# ---- overlay (reference tests/test-overlay.sh shapes + pixel parity with the oracle) -----------------------------------
+def _write_logo(path, w=48, h=32):
+    import png_util
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.zeros((h, w, 4), np.uint8)
+    img[..., 0], img[..., 1], img[..., 2] = xx * 255 // (w - 1), yy * 255 // (h - 1), 200
+    img[..., 3] = np.clip(255 - 8 * np.hypot(xx - w / 2, yy - h / 2), 0, 255)
+    png_util.write_png(path, img, 6, 8, filters=[4])
+    pre = img.copy()
+    pre[..., :3] = (img[..., :3].astype(np.uint32) * img[..., 3:4] + 127) // 255
+    return pre
+
+
+@pytest.mark.parametrize("fmt", ["BGRA", "RGBA", "NV12", "I420"])
+def test_overlay_pipelines(tmp_path, fmt):
+    logo = tmp_path / "logo.png"
+    _write_logo(logo)
+    ok(f"{SRC} ! {caps(fmt, 320, 240)} ! vfhipoverlay location={logo} x=20 y=10 ! fakesink")
+    ok(f"{SRC} ! {caps(fmt, 320, 240)} ! vfhipoverlay location={logo} relative-x=0.8 relative-y=0.05 width=60 height=40 alpha=0.5 ! fakesink")
+    ok(f"{SRC} ! {caps(fmt, 320, 240)} ! vfhipoverlay ! fakesink")                                   # no image: passthrough
+    ok(f"{SRC} ! {caps(fmt, 320, 240)} ! vfhipoverlay location={tmp_path / 'missing.png'} ! fakesink")   # warning, passthrough
+
+
+def test_overlay_pixels_match_oracle(tmp_path):
+    import oracle_lib
+    mr = oracle_lib.load_metalref()
+    logo = tmp_path / "logo.png"
+    pre = _write_logo(logo)
+    a, o = tmp_path / "in.raw", tmp_path / "out.raw"
+    r = gst_env.launch(f"videotestsrc num-buffers=2 pattern=ball ! {caps('NV12', 320, 240)} ! tee name=t t. ! queue ! filesink location={a} "
+                       f"t. ! queue ! vfhipoverlay location={logo} relative-x=0.5 y=30 width=96 alpha=0.75 ! {caps('NV12', 320, 240)} ! filesink location={o}")
+    assert r.returncode == 0, r.stderr
+    n = 320 * 240 * 3 // 2
+    fa, fo = np.fromfile(a, np.uint8), np.fromfile(o, np.uint8)
+    assert fa.size == fo.size == 2 * n
+    for k in range(2):
+        want = mr.overlay("NV12", 320, 240, fa[k * n:(k + 1) * n], "NV12", pre, x=160.0, y=30.0, width=96.0, height=0.0, alpha=0.75)
+        got = fo[k * n:(k + 1) * n]
+        d = np.abs(want.astype(int) - got.astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 0.02, f"frame {k}: max {d.max()}, {(d > 0).sum()} bytes differ"

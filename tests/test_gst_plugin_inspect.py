@@ -23,7 +23,7 @@ def squeeze(text):
 def test_plugin_registers_elements():
     r = gst_env.inspect("vfhip")
     assert r.returncode == 0, r.stdout + r.stderr
-    for e in ("vfhipconvertscale", "vfhipvideofilter", "vfhipdeinterlace", "vfhiptransform", "vfhipcompositor"):
+    for e in ("vfhipconvertscale", "vfhipvideofilter", "vfhipdeinterlace", "vfhiptransform", "vfhipcompositor", "vfhipoverlay"):
         assert e in r.stdout
 
 
@@ -76,3 +76,13 @@ def test_compositor_api():
     src = open(gst_env.PLUGIN_DIR + "/gstvfhipcompositor.c").read()
     for prop in ("xpos", "ypos", "width", "height", "alpha", "operator", "sizing-policy", "zorder"):
         assert f'("{prop}"' in src
+
+
+def test_overlay_api():
+    """reference overlay/gstvfmetaloverlay.m:375-420: names, ranges, defaults"""
+    t = gst_env.inspect("vfhipoverlay").stdout
+    assert {"location", "x", "y", "width", "height", "alpha", "relative-x", "relative-y", "device-id"} <= props(t)
+    assert "GstVideoFilter" in t
+    sq = squeeze(t)
+    assert "Range: -1 - 1 Default: -1" in sq and "Range: 0 - 1 Default: 1" in sq and "Range: 0 - 2147483647 Default: 0" in sq
+    assert t.count("(string)BGRA, (string)RGBA, (string)NV12, (string)I420 }") == 4
