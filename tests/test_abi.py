@@ -53,3 +53,42 @@ def test_plane_geometry_helpers():
     assert lib.vfhip_plane_width_bytes(I420, 2, 63) == 32
     assert lib.vfhip_plane_width_bytes(UYVY, 0, 63) == 128
     assert lib.vfhip_format_n_planes(99) < 0
+
+
+def test_header_is_plain_c_and_a_c_client_links(tmp_path):
+    """include/vfhip.h compiles as C99 (pedantic), and a C program written the way a reference maintainer would call
+    the boundary links against libvfhip.so and runs its GPU-free part"""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "client.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "vfhip.h"
+int main (void)
+{
+  VfHipVideoInfo in, out;
+  VfHipFrame f;
+  VfHipVideoFilterParams vp;
+  VfHipOverlayParams op;
+  memset (&in, 0, sizeof in); memset (&out, 0, sizeof out); memset (&f, 0, sizeof f); memset (&vp, 0, sizeof vp); memset (&op, 0, sizeof op);
+  in.format = VFHIP_FORMAT_NV12; in.width = 3840; in.height = 2160; in.color_matrix = VFHIP_MATRIX_BT2020; in.chroma_site = VFHIP_CHROMA_SITE_H_COSITED;
+  out.format = VFHIP_FORMAT_BGRA; out.width = 1920; out.height = 1080;
+  if (vfhip_abi_version () != VFHIP_ABI_VERSION) return 2;
+  if (vfhip_plane_width_bytes (in.format, 1, in.width) != 3840 || vfhip_plane_height (in.format, 1, in.height) != 1080) return 3;
+  if (vfhip_convertscale_configure (NULL, &in, &out, VFHIP_SCALE_BILINEAR, 0, 0xFF000000u, VFHIP_NUMERICS_GST_EXACT) != VFHIP_ERR_INVALID) return 4;
+  if (!strstr (vfhip_last_error_string (), "null")) return 5;
+  printf ("devices: %d\n", vfhip_device_count ());     /* negative status without a GPU: no CPU fallback */
+  return 0;
+}
+''')
+    exe = tmp_path / "client"
+    libdir = os.path.dirname(LIB)
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                        "-L", libdir, "-lvfhip", f"-Wl,-rpath,{libdir}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "devices:" in r.stdout
