@@ -6,9 +6,9 @@
 //   -cleanup                            -> vfhip_convertscale_cleanup     (:514-528)
 #include "vfhip_internal.h"
 #include "convertscale_kernels.h"
+#include "convertscale_ntap_kernels.h"
 #include "convertscale_metal_kernels.h"
 #include "convertscale_planar_kernels.h"
-#include "convertscale_ntap_kernels.h"
 #include <cmath>
 #include <cstdlib>
 
@@ -56,6 +56,7 @@ struct VfHipConvertScale {
   VfHipConvertScale *conv = nullptr;
   int2 *d_nt_h = nullptr, *d_nt_v = nullptr; int nt_h = 0, nt_v = 0;
   void *nt_mid0 = nullptr, *nt_mid1 = nullptr;
+  bool nt_tile = false;             // every tile's source region fits k_cs_cubic_tile's LDS arrays
   // pipelined host path (submit / wait): up to two frames in flight, flight k uses staging slots 2k (in) and 2k+1 (out)
   struct Flight { VfHipFrame out; bool staged[VFHIP_MAX_PLANES]; } flight[2];
   int fl_head = 0, fl_count = 0;
@@ -304,21 +305,37 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
       return set_error (VFHIP_ERR_UNSUPPORTED, "method=bicubic needs numerics=gst-exact, an NV12 / I420 / BGRA / RGBA input, a BGRA / RGBA output and no borders");
     if (!cubic_in_domain (iw, ow) || !cubic_in_domain (ih, oh))
       return set_error (VFHIP_ERR_UNSUPPORTED, "method=bicubic: %dx%d -> %dx%d has a line shorter than its filter (or more than 64 taps)", iw, ih, ow, oh);
-    if (in->format != out->format) {                  // videoconvert at the input size: the existing gst-exact kernels
-      h->conv = vfhip_convertscale_new (h->dev->ordinal);
-      if (!h->conv) return VFHIP_ERR_HIP;
-      VfHipVideoInfo mid = *out;
-      mid.width = iw; mid.height = ih;
-      int rc = vfhip_convertscale_configure (h->conv, in, &mid, VFHIP_SCALE_BILINEAR, 0, 0, VFHIP_NUMERICS_GST_EXACT);
-      if (rc) return rc;
-      VFHIP_CHECK_HIP (hipMalloc (&h->nt_mid0, (size_t) iw * ih * 4 + 256));
-    }
-    std::vector<int2> t;
-    if (ow != iw) { h->nt_h = cubic_table (iw, ow, t); int rc = upload_int2 (t, &h->d_nt_h); if (rc) return rc; }
-    if (oh != ih) { h->nt_v = cubic_table (ih, oh, t); int rc = upload_int2 (t, &h->d_nt_v); if (rc) return rc; }
+    std::vector<int2> th_, tv_;
+    if (ow != iw) { h->nt_h = cubic_table (iw, ow, th_); int rc = upload_int2 (th_, &h->d_nt_h); if (rc) return rc; }
+    if (oh != ih) { h->nt_v = cubic_table (ih, oh, tv_); int rc = upload_int2 (tv_, &h->d_nt_v); if (rc) return rc; }
     h->vfirst = ih > oh + h->nt_v ? 1 : 0;           // GstVideoScaler pass order for n taps (oracle/gst114.c)
-    if (h->nt_h && h->nt_v) VFHIP_CHECK_HIP (hipMalloc (&h->nt_mid1, (h->vfirst ? (size_t) iw * oh : (size_t) ow * ih) * 4 + 256));
-    h->kernel = VfHipConvertScale::K_NTAP; h->kernel_name = "k_cs_ntap";
+    // fused tile kernel when every 64 x 16 output tile's source region fits its LDS arrays
+    auto span = [] (const std::vector<int2> &tb, int n, int out, int tile, int in) {
+      if (!n) return tile < in ? tile : in;
+      int m = 0;
+      for (int o0 = 0; o0 < out; o0 += tile) {
+        const int o1 = (o0 + tile < out ? o0 + tile : out) - 1;
+        const int sp = tb[(size_t) o1 * n + n - 1].x - tb[(size_t) o0 * n].x + 1;
+        if (sp > m) m = sp;
+      }
+      return m;
+    };
+    const int rw = span (th_, h->nt_h, ow, CT_TW, iw), rh = span (tv_, h->nt_v, oh, CT_TH, ih);
+    h->nt_tile = rw <= CT_RW && rh <= CT_RH && (h->vfirst ? CT_TH * rw : rh * CT_TW) <= CT_RH * CT_TW;
+    if (const char *e = getenv ("VFHIP_CUBIC_TILE")) h->nt_tile = h->nt_tile && atoi (e) != 0;        // tuning / test knob
+    if (!h->nt_tile) {                                // three-pass fallback: conversion at the input size by a child handle, then the passes
+      if (in->format != out->format) {
+        h->conv = vfhip_convertscale_new (h->dev->ordinal);
+        if (!h->conv) return VFHIP_ERR_HIP;
+        VfHipVideoInfo mid = *out;
+        mid.width = iw; mid.height = ih;
+        int rc = vfhip_convertscale_configure (h->conv, in, &mid, VFHIP_SCALE_BILINEAR, 0, 0, VFHIP_NUMERICS_GST_EXACT);
+        if (rc) return rc;
+        VFHIP_CHECK_HIP (hipMalloc (&h->nt_mid0, (size_t) iw * ih * 4 + 256));
+      }
+      if (h->nt_h && h->nt_v) VFHIP_CHECK_HIP (hipMalloc (&h->nt_mid1, (h->vfirst ? (size_t) iw * oh : (size_t) ow * ih) * 4 + 256));
+    }
+    h->kernel = VfHipConvertScale::K_NTAP; h->kernel_name = h->nt_tile ? "k_cs_cubic_tile" : "k_cs_ntap";
     h->configured = true;
     return VFHIP_OK;
   }
@@ -512,6 +529,21 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
 {
   if (n_frames <= 0) return VFHIP_OK;
   if (n_frames > 65535) return set_error (VFHIP_ERR_INVALID, "batch of %d frames exceeds 65535", n_frames);
+  if (h->kernel == VfHipConvertScale::K_NTAP && h->nt_tile) {
+    CubicTileParams t {};
+    for (int k = 0; k < 3; k++) { t.cs.in[k] = (const uint8_t *) in->data[k]; t.cs.is[k] = in->stride[k]; }
+    t.cs.in_pitch = in_pitch; t.cs.out_pitch = out_pitch;
+    t.cs.in_w = h->in.width; t.cs.in_h = h->in.height; t.cs.in_fmt = h->in.format; t.cs.out_rgba = h->out.format == VFHIP_FORMAT_RGBA;
+    for (int k = 0; k < 5; k++) t.cs.c[k] = kOrcCoef[h->in.color_matrix][k];
+    t.cs.cosited = h->in.chroma_site == VFHIP_CHROMA_SITE_H_COSITED;
+    t.out = (uint8_t *) out->data[0]; t.os = out->stride[0];
+    t.ow = h->out.width; t.oh = h->out.height; t.nh = h->nt_h; t.nv = h->nt_v; t.vfirst = h->vfirst;
+    t.tab_h = h->d_nt_h; t.tab_v = h->d_nt_v;
+    dim3 grid ((unsigned) ((t.ow + CT_TW - 1) / CT_TW), (unsigned) ((t.oh + CT_TH - 1) / CT_TH), (unsigned) n_frames);
+    hipLaunchKernelGGL (k_cs_cubic_tile, grid, dim3 (256), 0, s, t);
+    VFHIP_CHECK_HIP (hipGetLastError ());
+    return VFHIP_OK;
+  }
   if (h->kernel == VfHipConvertScale::K_NTAP) {
     for (int k = 0; k < n_frames; k++) {
       VfHipFrame fi = *in, fo = *out;

@@ -73,4 +73,88 @@ __global__ __launch_bounds__ (256) void k_ntap_h (const NtapParams p)
   *reinterpret_cast<uint32_t *> (p.out + (size_t) y * p.os + 4 * x) = ntap_finish (a);
 }
 
+// ---- k_cs_cubic_tile: conversion + both n-tap passes fused per output tile ----------------------------------------------
+// One workgroup = a 64 x 16 tile of output pixels.  The source region the tile's taps reach (for 2:1: 135 x 39 pixels) is
+// converted ONCE into LDS as 8-bit RGBA (cs_tap: the gst-exact per-pixel conversion of k_cs_generic — GStreamer converts at
+// the input size first), the first pass runs LDS -> LDS, the second LDS -> HBM, in GstVideoScaler's order; the 8-bit
+// rounding between the passes is kept, so the result is the three-pass path's bit for bit while every input byte is read
+// about 1.3 times and nothing intermediate touches HBM.  The host falls back to the three-pass path when a tile's source
+// region does not fit the LDS arrays (down-scales beyond ~2.1:1 horizontally or ~2.5:1 vertically).
+constexpr int CT_TW = 64, CT_TH = 16, CT_RW = 144, CT_RH = 48;
+
+struct CubicTileParams {
+  CsParams cs;                       // input planes / strides / matrix / formats for cs_tap; in_pitch, out_pitch for batches
+  uint8_t *out; int os;
+  int ow, oh, nh, nv, vfirst;
+  const int2 *tab_h, *tab_v;         // [ow][nh], [oh][nv] of {source index, 6-bit weight}; nh / nv == 0: no scaling on that axis
+};
+
+__global__ __launch_bounds__ (256) void k_cs_cubic_tile (const CubicTileParams p)
+{
+  __shared__ uint32_t reg[CT_RH][CT_RW];                              // converted source region
+  __shared__ uint32_t tmp[CT_RH * CT_TW];                             // first-pass result: [CT_TH][rw] (V first) or [rh][CT_TW] (H first)
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * CT_TW, y0 = blockIdx.y * CT_TH;
+  const int tw = min (CT_TW, p.ow - x0), th = min (CT_TH, p.oh - y0);
+  const uint8_t *in[3] = { p.cs.in[0] + (size_t) blockIdx.z * p.cs.in_pitch,
+                           p.cs.in[1] ? p.cs.in[1] + (size_t) blockIdx.z * p.cs.in_pitch : nullptr,
+                           p.cs.in[2] ? p.cs.in[2] + (size_t) blockIdx.z * p.cs.in_pitch : nullptr };
+  uint8_t *out = p.out + (size_t) blockIdx.z * p.cs.out_pitch;
+  // source region of this tile (tables hold absolute, edge-clamped, non-decreasing indices)
+  const int cx0 = p.nh ? p.tab_h[(size_t) x0 * p.nh].x : x0, cx1 = p.nh ? p.tab_h[(size_t) (x0 + tw - 1) * p.nh + p.nh - 1].x : x0 + tw - 1;
+  const int ry0 = p.nv ? p.tab_v[(size_t) y0 * p.nv].x : y0, ry1 = p.nv ? p.tab_v[(size_t) (y0 + th - 1) * p.nv + p.nv - 1].x : y0 + th - 1;
+  const int rw = cx1 - cx0 + 1, rh = ry1 - ry0 + 1;
+  for (int i = tid; i < rw * rh; i += 256) {
+    const int ry = i / rw, rx = i - ry * rw;
+    int px[4];
+    cs_tap (p.cs, in, cx0 + rx, ry0 + ry, px);
+    reg[ry][rx] = (uint32_t) px[0] | ((uint32_t) px[1] << 8) | ((uint32_t) px[2] << 16) | ((uint32_t) px[3] << 24);
+  }
+  __syncthreads ();
+  if (p.nh && p.nv) {
+    if (p.vfirst) {                                                    // tmp[ty][rx] = vertical taps over the region's columns
+      for (int i = tid; i < th * rw; i += 256) {
+        const int ty = i / rw, rx = i - ty * rw;
+        const int2 *t = p.tab_v + (size_t) (y0 + ty) * p.nv;
+        Acc4 a = { 0.0f, 0.0f, 0.0f, 0.0f };
+        for (int l = 0; l < p.nv; l++) ntap_acc (a, reg[t[l].x - ry0][rx], t[l].y);
+        tmp[ty * rw + rx] = ntap_finish (a);
+      }
+    } else {                                                           // tmp[ry][tx] = horizontal taps over the region's rows
+      for (int i = tid; i < rh * tw; i += 256) {
+        const int ry = i / tw, tx = i - ry * tw;
+        const int2 *t = p.tab_h + (size_t) (x0 + tx) * p.nh;
+        Acc4 a = { 0.0f, 0.0f, 0.0f, 0.0f };
+        for (int l = 0; l < p.nh; l++) ntap_acc (a, reg[ry][t[l].x - cx0], t[l].y);
+        tmp[ry * CT_TW + tx] = ntap_finish (a);
+      }
+    }
+    __syncthreads ();
+  }
+  for (int i = tid; i < th * tw; i += 256) {
+    const int ty = i / tw, tx = i - ty * tw;
+    Acc4 a = { 0.0f, 0.0f, 0.0f, 0.0f };
+    uint32_t q;
+    if (p.nh && p.nv) {
+      if (p.vfirst) {
+        const int2 *t = p.tab_h + (size_t) (x0 + tx) * p.nh;
+        for (int l = 0; l < p.nh; l++) ntap_acc (a, tmp[ty * rw + (t[l].x - cx0)], t[l].y);
+      } else {
+        const int2 *t = p.tab_v + (size_t) (y0 + ty) * p.nv;
+        for (int l = 0; l < p.nv; l++) ntap_acc (a, tmp[(t[l].x - ry0) * CT_TW + tx], t[l].y);
+      }
+      q = ntap_finish (a);
+    } else if (p.nh) {
+      const int2 *t = p.tab_h + (size_t) (x0 + tx) * p.nh;
+      for (int l = 0; l < p.nh; l++) ntap_acc (a, reg[ty][t[l].x - cx0], t[l].y);
+      q = ntap_finish (a);
+    } else if (p.nv) {
+      const int2 *t = p.tab_v + (size_t) (y0 + ty) * p.nv;
+      for (int l = 0; l < p.nv; l++) ntap_acc (a, reg[t[l].x - ry0][tx], t[l].y);
+      q = ntap_finish (a);
+    } else q = reg[ty][tx];
+    *reinterpret_cast<uint32_t *> (out + (size_t) (y0 + ty) * p.os + 4 * (x0 + tx)) = q;
+  }
+}
+
 }  // namespace vfhip

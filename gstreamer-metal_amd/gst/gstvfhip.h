@@ -41,6 +41,8 @@ void gst_vfhip_pin_foreign_memory (GstBuffer * buf, GstVfHipPinStats * stats);
 /* template caps: both memories, device memory first */
 #define GST_VFHIP_CAPS(formats) GST_VIDEO_CAPS_MAKE_WITH_FEATURES (GST_CAPS_FEATURE_MEMORY_HIP, formats) "; " GST_VIDEO_CAPS_MAKE (formats)
 GstAllocator *gst_vfhip_device_allocator_get (gint device);
+gint gst_vfhip_element_device (gpointer element);
+GstMapFlags gst_vfhip_map_flag (GstBuffer * buf, gint device);
 gboolean gst_vfhip_is_device_memory (GstMemory * mem);
 gboolean gst_vfhip_caps_has_hip_feature (GstCaps * caps);
 GstCaps *gst_vfhip_caps_both_memories (GstCaps * caps);

@@ -121,7 +121,7 @@ gst_vfhip_propose_allocation (GstBaseTransform * trans, GstQuery * decide_query,
     GstAllocationParams params;
     gst_query_parse_allocation (query, &caps, NULL);
     /* memory:HIPMemory negotiated on our sink pad: upstream should hand us device buffers */
-    a = gst_vfhip_caps_has_hip_feature (caps) ? gst_vfhip_device_allocator_get (-1) : gst_vfhip_pinned_allocator_get ();
+    a = gst_vfhip_caps_has_hip_feature (caps) ? gst_vfhip_device_allocator_get (gst_vfhip_element_device (trans)) : gst_vfhip_pinned_allocator_get ();
     gst_allocation_params_init (&params);
     params.align = 63;
     gst_query_add_allocation_param (query, a, &params);
@@ -141,7 +141,7 @@ gst_vfhip_decide_allocation (GstBaseTransform * trans, GstQuery * query, gboolea
   GstAllocationParams params;
   gst_query_parse_allocation (query, &caps, NULL);
   if (gst_vfhip_caps_has_hip_feature (caps)) {
-    a = gst_vfhip_device_allocator_get (-1);
+    a = gst_vfhip_device_allocator_get (gst_vfhip_element_device (trans));
     while (gst_query_get_n_allocation_pools (query) > 0)
       gst_query_remove_nth_allocation_pool (query, 0);
   } else

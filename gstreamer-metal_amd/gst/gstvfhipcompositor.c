@@ -898,7 +898,7 @@ comp_aggregate (GstAggregator * agg, gboolean timeout)
     bufs[i] = gst_aggregator_pad_pop_buffer (GST_AGGREGATOR_PAD (cpad));
     if (!bufs[i] || !cpad->have_info || cpad->alpha == 0.0)
       continue;
-    if (!gst_video_frame_map (&frames[i], &cpad->info, bufs[i], (GstMapFlags) (GST_MAP_READ | GST_MAP_VFHIP)))
+    if (!gst_video_frame_map (&frames[i], &cpad->info, bufs[i], (GstMapFlags) (GST_MAP_READ | gst_vfhip_map_flag (bufs[i], gst_vfhip_element_device (self)))))
       continue;
     comp_pad_rect (self, cpad, GST_VIDEO_INFO_PAR_N (&self->out_info), GST_VIDEO_INFO_PAR_D (&self->out_info), &w, &h, &xo, &yo);
     gst_vfhip_frame (&frames[i], &pads[used].frame);

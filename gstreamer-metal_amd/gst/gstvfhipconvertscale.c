@@ -234,6 +234,7 @@ cs_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
   GstVideoFrame in, out;
   VfHipFrame vin, vout;
   int rc;
+  gint dev;
   if (!self->negotiated)
     return GST_FLOW_NOT_NEGOTIATED;
   if (!self->renderer) {
@@ -241,9 +242,10 @@ cs_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
     return GST_FLOW_ERROR;
   }
   gst_vfhip_pin_foreign_memory (inbuf, &self->pin);         /* recurring pageable upstream memory: page-lock it in place */
-  if (!gst_video_frame_map (&in, &self->in_info, inbuf, (GstMapFlags) (GST_MAP_READ | GST_MAP_VFHIP)))
+  dev = gst_vfhip_element_device (self);
+  if (!gst_video_frame_map (&in, &self->in_info, inbuf, (GstMapFlags) (GST_MAP_READ | gst_vfhip_map_flag (inbuf, dev))))
     return GST_FLOW_ERROR;
-  if (!gst_video_frame_map (&out, &self->out_info, outbuf, (GstMapFlags) (GST_MAP_WRITE | GST_MAP_VFHIP))) {
+  if (!gst_video_frame_map (&out, &self->out_info, outbuf, (GstMapFlags) (GST_MAP_WRITE | gst_vfhip_map_flag (outbuf, dev)))) {
     gst_video_frame_unmap (&in);
     return GST_FLOW_ERROR;
   }
@@ -311,6 +313,7 @@ cs_generate_output (GstBaseTransform * trans, GstBuffer ** outbuf)
   GstFlowReturn ret;
   VfHipFrame vin, vout;
   guint k;
+  gint dev;
   gboolean reconf;
   if (self->async_depth < 1 || self->passthrough) {
     if (self->n_pending && (ret = cs_drain (self, TRUE)) != GST_FLOW_OK)
@@ -345,11 +348,12 @@ cs_generate_output (GstBaseTransform * trans, GstBuffer ** outbuf)
   }
   k = (self->pending_head + self->n_pending) & 1;
   gst_vfhip_pin_foreign_memory (inbuf, &self->pin);
-  if (!gst_video_frame_map (&self->pending[k].in, &self->in_info, inbuf, (GstMapFlags) (GST_MAP_READ | GST_MAP_VFHIP))) {
+  dev = gst_vfhip_element_device (self);
+  if (!gst_video_frame_map (&self->pending[k].in, &self->in_info, inbuf, (GstMapFlags) (GST_MAP_READ | gst_vfhip_map_flag (inbuf, dev)))) {
     gst_buffer_unref (inbuf); gst_buffer_unref (out);
     return GST_FLOW_ERROR;
   }
-  if (!gst_video_frame_map (&self->pending[k].out, &self->out_info, out, (GstMapFlags) (GST_MAP_WRITE | GST_MAP_VFHIP))) {
+  if (!gst_video_frame_map (&self->pending[k].out, &self->out_info, out, (GstMapFlags) (GST_MAP_WRITE | gst_vfhip_map_flag (out, dev)))) {
     gst_video_frame_unmap (&self->pending[k].in);
     gst_buffer_unref (inbuf); gst_buffer_unref (out);
     return GST_FLOW_ERROR;

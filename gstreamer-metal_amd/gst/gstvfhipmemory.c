@@ -125,23 +125,48 @@ gst_vfhip_device_allocator_init (GstVfHipDeviceAllocator * self)
   GST_OBJECT_FLAG_SET (self, GST_ALLOCATOR_FLAG_CUSTOM_ALLOC);
 }
 
-/* one allocator per GPU ordinal (-1: libvfhip's default device) */
+/* the GPU ordinal an element runs on: its device-id property resolved like libvfhip does (-1: $VFHIP_DEVICE, else 0);
+ * negative when there is no usable device */
+gint
+gst_vfhip_element_device (gpointer element)
+{
+  gint id = -1;
+  if (element && g_object_class_find_property (G_OBJECT_GET_CLASS (element), "device-id"))
+    g_object_get (element, "device-id", &id, NULL);
+  return vfhip_device_init (id);
+}
+
+/* one allocator per GPU ordinal: streams sharded across the GPUs of a node by device-id keep their frames on their GPU */
 GstAllocator *
 gst_vfhip_device_allocator_get (gint device)
 {
   static GMutex lock;
-  static GstAllocator *alloc[65];
+  static GstAllocator *alloc[64];
   GstAllocator *a;
-  const gint slot = (device < 0 || device > 63) ? 64 : device;
+  const gint slot = (device < 0 || device > 63) ? 0 : device;
   g_mutex_lock (&lock);
   if (!alloc[slot]) {
     alloc[slot] = g_object_new (gst_vfhip_device_allocator_get_type (), NULL);
     gst_object_ref_sink (alloc[slot]);
-    ((GstVfHipDeviceAllocator *) alloc[slot])->device = slot == 64 ? -1 : device;
+    ((GstVfHipDeviceAllocator *) alloc[slot])->device = slot;
   }
   a = gst_object_ref (alloc[slot]);
   g_mutex_unlock (&lock);
   return a;
+}
+
+/* GST_MAP_VFHIP when `buf` is one device memory on GPU `device` (its planes can be used in place); 0 otherwise — a device
+ * memory that lives on ANOTHER GPU is then mapped through its host shadow like by any CPU element */
+GstMapFlags
+gst_vfhip_map_flag (GstBuffer * buf, gint device)
+{
+  GstMemory *mem;
+  if (device < 0 || gst_buffer_n_memory (buf) != 1)
+    return (GstMapFlags) 0;
+  mem = gst_buffer_peek_memory (buf, 0);
+  if (!gst_vfhip_is_device_memory (mem) || ((VfHipDeviceMemory *) mem)->device != device)
+    return (GstMapFlags) 0;
+  return GST_MAP_VFHIP;
 }
 
 gboolean
@@ -206,6 +231,7 @@ gst_vfhip_filter_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuff
   GstVideoFrame in, out;
   GstFlowReturn res;
   GstVfHipPinStats *pin;
+  gint dev;
   if (G_UNLIKELY (!filter->negotiated))
     return GST_FLOW_NOT_NEGOTIATED;
   if (!(pin = g_object_get_data (G_OBJECT (trans), "vfhip-pin-stats"))) {
@@ -213,9 +239,10 @@ gst_vfhip_filter_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuff
     g_object_set_data_full (G_OBJECT (trans), "vfhip-pin-stats", pin, g_free);
   }
   gst_vfhip_pin_foreign_memory (inbuf, pin);                 /* recurring pageable upstream memory: page-lock it in place */
-  if (!gst_video_frame_map (&in, &filter->in_info, inbuf, (GstMapFlags) (GST_MAP_READ | GST_MAP_VFHIP | GST_VIDEO_FRAME_MAP_FLAG_NO_REF)))
+  dev = gst_vfhip_element_device (trans);
+  if (!gst_video_frame_map (&in, &filter->in_info, inbuf, (GstMapFlags) (GST_MAP_READ | gst_vfhip_map_flag (inbuf, dev) | GST_VIDEO_FRAME_MAP_FLAG_NO_REF)))
     return GST_FLOW_ERROR;
-  if (!gst_video_frame_map (&out, &filter->out_info, outbuf, (GstMapFlags) (GST_MAP_WRITE | GST_MAP_VFHIP | GST_VIDEO_FRAME_MAP_FLAG_NO_REF))) {
+  if (!gst_video_frame_map (&out, &filter->out_info, outbuf, (GstMapFlags) (GST_MAP_WRITE | gst_vfhip_map_flag (outbuf, dev) | GST_VIDEO_FRAME_MAP_FLAG_NO_REF))) {
     gst_video_frame_unmap (&in);
     return GST_FLOW_ERROR;
   }

@@ -223,15 +223,18 @@ def test_yuv_outputs_1080p_vs_oracle(vfhip, oracle, ifmt, ofmt):
 from test_oracle_golden import MANIFEST_B, ZB, cubic_in_domain  # noqa: E402
 
 
+@pytest.mark.parametrize("tile", [1, 0], ids=["fused-tile", "three-pass"])
 @pytest.mark.parametrize("case", [c for c in MANIFEST_B if cubic_in_domain(c)], ids=[c["name"] for c in MANIFEST_B if cubic_in_domain(c)])
-def test_golden_gstreamer_vectors_bicubic(vfhip, case):
+def test_golden_gstreamer_vectors_bicubic(vfhip, case, tile, monkeypatch):
+    """both device paths: the fused tile kernel (when a tile's source region fits LDS) and the three-pass fallback"""
+    monkeypatch.setenv("VFHIP_CUBIC_TILE", str(tile))
     raw, want = ZB[case["name"] + "_in"], ZB[case["name"] + "_out"]
     col, site = case["colorimetry"], case["chroma_site"]
     if col is None:
         col, site = oracle_lib.default_colorimetry(case["h"])
     got, kname = run(vfhip, case["in_format"], case["w"], case["h"], raw, col, site, "bicubic", case["out_format"], case["ow"], case["oh"])
-    assert kname == "k_cs_ntap"
-    assert np.array_equal(got.reshape(-1), want), f"{(got.reshape(-1) != want).sum()} bytes differ"
+    assert kname in ("k_cs_cubic_tile", "k_cs_ntap") and (tile or kname == "k_cs_ntap")
+    assert np.array_equal(got.reshape(-1), want), f"{kname}: {(got.reshape(-1) != want).sum()} bytes differ"
 
 
 def test_bicubic_outside_the_pinned_domain_is_refused(vfhip):
@@ -253,6 +256,7 @@ def test_bicubic_1080p_to_540p_vs_oracle_and_batch(vfhip, oracle):
     frames = [rng.integers(0, 256, size, dtype=np.uint8) for _ in range(3)]
     cs = vfhip.ConvertScale(0)
     cs.configure("NV12", w, h, "BGRA", ow, oh, method="bicubic", colorimetry="bt709", chroma_site="mpeg2")
+    assert cs.kernel_name == "k_cs_cubic_tile"              # 2:1 fits the tile kernel's LDS region
     want = [oracle.convertscale("NV12", w, h, f, "bt709", "mpeg2", "bicubic", "BGRA", ow, oh) for f in frames]
     assert np.array_equal(cs.process(frames[0]).reshape(oh, ow, 4), want[0])
     pitch = (size + 255) // 256 * 256

@@ -121,6 +121,20 @@ def main():
     report("C1 convertscale NV12 1080p -> BGRA 640x480 (generic gst-exact)", cs.kernel_name, timed(c1, s, 5), 64, w * h * 3 // 2 + 4 * ow * oh)
     cs.close()
 
+    # C2 with method=bicubic (videoscale method=catrom, bit-exact)
+    w, h, ow, oh = 3840, 2160, 1920, 1080
+    size = vfhip.plane_layout("NV12", w, h)[1]
+    pitch = (size + 255) // 256 * 256
+    NB = 16
+    bin_, bout = ring(NB, size, 40), ring(NB, 4 * ow * oh, 41)
+    cs = vfhip.ConvertScale(0)
+    cs.configure("NV12", w, h, "BGRA", ow, oh, method="bicubic", colorimetry="bt2020", chroma_site="mpeg2")
+
+    def c2b():
+        cs.process_device(bin_.data_ptr(), bout.data_ptr(), stream=s.cuda_stream, n_frames=NB, in_pitch=pitch, out_pitch=bout.shape[1])
+    report("C2 convertscale NV12 2160p -> BGRA 1080p method=bicubic (gst-exact catrom)", cs.kernel_name, timed(c2b, s, 3), NB, w * h * 3 // 2 + 4 * ow * oh)
+    cs.close()
+
 
 def e2e():
     """element-level (PCIe-inclusive) rate of vfhip_convertscale_process on C2: pageable vs pinned host buffers"""
