@@ -176,3 +176,63 @@ def test_convertscale_submit_wait_pipeline(vfhip, oracle):
             for a in ins + outs:
                 lib.vfhip_pinned_free(a.ctypes.data)
     cs.close()
+
+
+def test_many_handles_from_many_threads(vfhip, oracle, metalref):
+    """SURVEY.md §8b threading: handles are single-caller, the device singleton is shared; eight threads, each with its own
+    handles of a different element type / configuration, hammer the same GPU concurrently and every result is still exact
+    (reference: tests/test-multi-element.sh, one command queue per renderer)"""
+    import threading
+    errors = []
+
+    def worker(k):
+        try:
+            rng = np.random.default_rng(100 + k)
+            if k % 4 == 0:
+                w, h, ow, oh = 256, 128, 128, 64
+                cs = vfhip.ConvertScale(0)
+                cs.configure("NV12", w, h, "BGRA", ow, oh, colorimetry="bt709", chroma_site="mpeg2")
+                for _ in range(12):
+                    raw = rng.integers(0, 256, ol.raw_layout("NV12", w, h)[1], dtype=np.uint8)
+                    want = oracle.convertscale("NV12", w, h, raw, "bt709", "mpeg2", "bilinear", "BGRA", ow, oh)
+                    assert np.array_equal(cs.process(raw).reshape(oh, ow, 4), want)
+                cs.close()
+            elif k % 4 == 1:
+                w, h = 96, 64
+                vf = vfhip.VideoFilter(0)
+                vf.configure("BGRA", w, h)
+                prm = vfhip.filter_params(brightness=0.1, sharpness=0.5, gamma=1.4)
+                for i in range(8):
+                    raw = smooth("BGRA", w, h, 200 + 10 * k + i)
+                    want = metalref.videofilter("BGRA", w, h, raw, "BGRA", ol.mr_filter_params(prm))
+                    assert np.abs(vf.process(raw, prm).astype(int) - want.astype(int)).max() <= 1
+                vf.close()
+            elif k % 4 == 2:
+                w, h = 128, 72
+                d = vfhip.Deinterlace(0)
+                d.configure("NV12", w, h)
+                prev = None
+                for i in range(8):
+                    raw = smooth("NV12", w, h, 300 + 10 * k + i)
+                    want = metalref.deinterlace("NV12", w, h, raw, prev, 3, tff=True, threshold=0.05)
+                    assert np.abs(d.process(raw, method="greedyh", tff=True, threshold=0.05).astype(int) - want.astype(int)).max() <= 1
+                    prev = raw
+                d.close()
+            else:
+                w, h, ow, oh = 160, 90, 240, 135
+                cs = vfhip.ConvertScale(0)
+                cs.configure("I420", w, h, "RGBA", ow, oh, method="bicubic", colorimetry="bt601", chroma_site="jpeg")
+                for _ in range(8):
+                    raw = rng.integers(0, 256, ol.raw_layout("I420", w, h)[1], dtype=np.uint8)
+                    want = oracle.convertscale("I420", w, h, raw, "bt601", "jpeg", "bicubic", "RGBA", ow, oh)
+                    assert np.array_equal(cs.process(raw).reshape(oh, ow, 4), want)
+                cs.close()
+        except Exception as e:                        # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
