@@ -291,6 +291,7 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
 
   const bool in_420_or_rgb = in->format == VFHIP_FORMAT_NV12 || in->format == VFHIP_FORMAT_I420 ||
                              in->format == VFHIP_FORMAT_BGRA || in->format == VFHIP_FORMAT_RGBA;
+  const bool in_packed = in->format == VFHIP_FORMAT_UYVY || in->format == VFHIP_FORMAT_YUY2;   // pinned for RGB outputs only
   const bool out_rgb = out->format == VFHIP_FORMAT_BGRA || out->format == VFHIP_FORMAT_RGBA;
   // gst-exact covers the cells whose GStreamer arithmetic is pinned; every other cell of
   // the 6x6 matrix runs the reference-shader (metal) arithmetic.
@@ -301,8 +302,8 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
                       !h->add_borders && (!in_yuv || (in->color_matrix == out->color_matrix && in->chroma_site == out->chroma_site));
   if (method == VFHIP_SCALE_BICUBIC) {
     const int iw = in->width, ih = in->height, ow = out->width, oh = out->height;
-    if (numerics != VFHIP_NUMERICS_GST_EXACT || !in_420_or_rgb || !out_rgb || h->add_borders)
-      return set_error (VFHIP_ERR_UNSUPPORTED, "method=bicubic needs numerics=gst-exact, an NV12 / I420 / BGRA / RGBA input, a BGRA / RGBA output and no borders");
+    if (numerics != VFHIP_NUMERICS_GST_EXACT || !(in_420_or_rgb || in_packed) || !out_rgb || h->add_borders)
+      return set_error (VFHIP_ERR_UNSUPPORTED, "method=bicubic needs numerics=gst-exact, a BGRA / RGBA output and no borders");
     if (!cubic_in_domain (iw, ow) || !cubic_in_domain (ih, oh))
       return set_error (VFHIP_ERR_UNSUPPORTED, "method=bicubic: %dx%d -> %dx%d has a line shorter than its filter (or more than 64 taps)", iw, ih, ow, oh);
     std::vector<int2> th_, tv_;
@@ -359,7 +360,7 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
     h->configured = true;
     return VFHIP_OK;
   }
-  const bool exact = numerics == VFHIP_NUMERICS_GST_EXACT && in_420_or_rgb && out_rgb;
+  const bool exact = numerics == VFHIP_NUMERICS_GST_EXACT && (in_420_or_rgb || in_packed) && out_rgb;
   if (!exact) {
     h->kernel = VfHipConvertScale::K_METAL; h->kernel_name = "k_cs_metal";
     h->configured = true;

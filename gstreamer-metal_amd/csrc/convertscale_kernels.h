@@ -360,13 +360,25 @@ __device__ __forceinline__ void cs_tap (const CsParams &p, const uint8_t *const 
     return;
   }
   const int cw = (p.in_w + 1) >> 1, chh = (p.in_h + 1) >> 1;
-  const int Y = in[0][(size_t) cy * p.is[0] + cx];
   const int j = cy >> 1, k = cx >> 1;
-  int U, V;
-  if (p.in_fmt == VFHIP_FORMAT_I420) {      // GStreamer's I420 fast path: nearest-replicated chroma
+  int Y, U, V;
+  if (p.in_fmt == VFHIP_FORMAT_UYVY || p.in_fmt == VFHIP_FORMAT_YUY2) {
+    // packed 4:2:2 (UYVY: U Y0 V Y1, YUY2: Y0 U Y1 V): NV12's horizontal chroma rule, no vertical step (oracle/gst114.c
+    // gst114_packed422_to_rgb)
+    const int yuy2 = p.in_fmt == VFHIP_FORMAT_YUY2;
+    const uint8_t *row = in[0] + (size_t) cy * p.is[0];
+    const int kn = (cx & 1) ? min (k + 1, cw - 1) : max (k - 1, 0);
+    const int u0 = row[4 * k + (yuy2 ? 1 : 0)], v0 = row[4 * k + (yuy2 ? 3 : 2)];
+    const int un = row[4 * kn + (yuy2 ? 1 : 0)], vn = row[4 * kn + (yuy2 ? 3 : 2)];
+    Y = row[2 * cx + (yuy2 ? 0 : 1)];
+    if (p.cosited) { U = (cx & 1) ? (u0 + un + 1) >> 1 : u0; V = (cx & 1) ? (v0 + vn + 1) >> 1 : v0; }
+    else { U = (3 * u0 + un + 2) >> 2; V = (3 * v0 + vn + 2) >> 2; }
+  } else if (p.in_fmt == VFHIP_FORMAT_I420) {      // GStreamer's I420 fast path: nearest-replicated chroma
+    Y = in[0][(size_t) cy * p.is[0] + cx];
     U = in[1][(size_t) j * p.is[1] + k];
     V = in[2][(size_t) j * p.is[2] + k];
   } else {
+    Y = in[0][(size_t) cy * p.is[0] + cx];
     const int jn = (cy & 1) ? min (j + 1, chh - 1) : max (j - 1, 0);
     const uint8_t *r0 = in[1] + (size_t) j * p.is[1], *r1 = in[1] + (size_t) jn * p.is[1];
     const int kn = (cx & 1) ? min (k + 1, cw - 1) : max (k - 1, 0);

@@ -117,6 +117,41 @@ int gst114_yuv420_to_rgb (const uint8_t *yp, int ys, const uint8_t *up, int us, 
   return 0;
 }
 
+/* packed 4:2:2 (UYVY: U Y0 V Y1, YUY2: Y0 U Y1 V) -> packed 8-bit RGB: the chroma row is up-sampled horizontally with the
+ * same rule as NV12's (co-sited / 3:1), there is no vertical step, then the ORC matrix.  Pinned by probing videoconvert
+ * (chroma ramps under chroma-site none / jpeg / mpeg2) and by tests/golden/convertscale_gst114_packed.npz. */
+int gst114_packed422_to_rgb (const uint8_t *in, int is, int yuy2, int w, int h, int matrix, int cosited, int out_format, uint8_t *out, int os)
+{
+  if (w <= 0 || h <= 0 || matrix < 0 || matrix > 2) return -1;
+  const int cw = (w + 1) / 2, yo = yuy2 ? 0 : 1, uo = yuy2 ? 1 : 0, vo = yuy2 ? 3 : 2;
+  const int ro = out_format == GST114_RGBA ? 0 : 2, bo = 2 - ro;
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < h; y++) {
+    const uint8_t *row = in + (size_t) y * is;
+    uint8_t *hu = malloc ((size_t) w), *hv = malloc ((size_t) w);
+    upsample_h (row + uo, 4, cw, w, cosited, hu);
+    upsample_h (row + vo, 4, cw, w, cosited, hv);
+    uint8_t *o = out + (size_t) y * os;
+    for (int x = 0; x < w; x++) {
+      int r, g, b;
+      gst114_yuv_to_rgb (matrix, row[2 * x + yo], hu[x], hv[x], &r, &g, &b);
+      o[4 * x + ro] = (uint8_t) r; o[4 * x + 1] = (uint8_t) g; o[4 * x + bo] = (uint8_t) b; o[4 * x + 3] = 255;
+    }
+    free (hu); free (hv);
+  }
+  return 0;
+}
+
+int gst114_convertscale_packed422 (const uint8_t *in, int is, int yuy2, int w, int h, int matrix, int cosited, int out_format, int method,
+    uint8_t *out, int os, int ow, int oh)
+{
+  uint8_t *full = malloc ((size_t) w * h * 4); if (!full) return -2;
+  int rc = gst114_packed422_to_rgb (in, is, yuy2, w, h, matrix, cosited, out_format, full, w * 4);
+  if (rc == 0) rc = gst114_scale_4u8 (full, w * 4, w, h, out, os, ow, oh, method);
+  free (full);
+  return rc;
+}
+
 /* ---- videoscale, 4 x u8 ---------------------------------------------------------------- */
 
 void gst114_vtaps (int in_h, int out_h, int y, int *i0, int *i1, int *w)
@@ -133,6 +168,8 @@ uint32_t gst114_hinc (int in_w, int out_w)
   if (out_w <= 1) return 0;
   return (uint32_t) ((((uint64_t) (in_w - 1)) << 16) / (uint64_t) (out_w - 1)) - 1;
 }
+
+int gst114_scale_4u8 (const uint8_t *in, int is, int w, int h, uint8_t *out, int os, int ow, int oh, int method);
 
 int gst114_nearest_index (int in, int out, int j)
 {

@@ -22,6 +22,9 @@ int gst114_scale_4u8 (const uint8_t *in, int is, int w, int h, uint8_t *out, int
 int gst114_rgb_to_yuv420 (const uint8_t *in, int is, int in_format, int w, int h, int matrix, int cosited,
     int planar, uint8_t *yp, int ys, uint8_t *up, int us, uint8_t *vp, int vs);
 int gst114_scale_plane (const uint8_t *in, int is, int w, int h, int n, uint8_t *out, int os, int ow, int oh);
+int gst114_packed422_to_rgb (const uint8_t *in, int is, int yuy2, int w, int h, int matrix, int cosited, int out_format, uint8_t *out, int os);
+int gst114_convertscale_packed422 (const uint8_t *in, int is, int yuy2, int w, int h, int matrix, int cosited, int out_format, int method,
+    uint8_t *out, int os, int ow, int oh);
 int gst114_default_matrix (int height);
 int gst114_default_cosited (int height);
 int gst114_convertscale_yuv420 (const uint8_t *yp, int ys, const uint8_t *up, int us, const uint8_t *vp, int vs,

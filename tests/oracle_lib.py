@@ -44,6 +44,8 @@ def planes(fmt, w, h, raw):
         return [(raw[: ys * h], ys), (raw[uo: uo + cs * (hp // 2)], cs), (raw[vo: vo + cs * (hp // 2)], cs)]
     if fmt in ("BGRA", "RGBA"):
         return [(raw[: 4 * w * h], 4 * w)]
+    if fmt in ("UYVY", "YUY2"):
+        return [(raw[: r4(2 * w) * h], r4(2 * w))]
     raise ValueError(fmt)
 
 
@@ -79,6 +81,9 @@ class Oracle:
                 (y, ys), (u, us), (v, vs) = pl
                 rc = L.gst114_convertscale_yuv420(self._p(y), ys, self._p(u), us, self._p(v), vs, 1, w, h, mat, cos, ofmt, meth,
                                                   self._p(out), ow * 4, ow, oh)
+            elif fmt in ("UYVY", "YUY2"):
+                stride = r4(2 * w)
+                rc = L.gst114_convertscale_packed422(self._p(raw), stride, int(fmt == "YUY2"), w, h, mat, cos, ofmt, meth, self._p(out), ow * 4, ow, oh)
             else:
                 src = pl[0][0].reshape(h, w, 4)
                 if fmt != out_format:

@@ -272,3 +272,24 @@ def test_bicubic_1080p_to_540p_vs_oracle_and_batch(vfhip, oracle):
     for k in range(3):
         assert np.array_equal(out[k], want[k]), f"frame {k}"
     cs.close()
+
+
+# ---- packed 4:2:2 inputs (UYVY / YUY2) -> RGB outputs, gst-exact -----------------------------------------------------------
+from test_oracle_golden import MANIFEST_P, ZP  # noqa: E402
+
+
+@pytest.mark.parametrize("case", MANIFEST_P, ids=[c["name"] for c in MANIFEST_P])
+def test_golden_gstreamer_vectors_packed_inputs(vfhip, case):
+    raw, want = ZP[case["name"] + "_in"], ZP[case["name"] + "_out"]
+    got, kname = run(vfhip, case["in_format"], case["w"], case["h"], raw, case["colorimetry"], case["chroma_site"], case["method"],
+                     case["out_format"], case["ow"], case["oh"])
+    assert kname in ("k_cs_generic", "k_cs_cubic_tile", "k_cs_ntap")            # never the metal arithmetic
+    assert np.array_equal(got.reshape(-1), want), f"{kname}: {(got.reshape(-1) != want).sum()} bytes differ"
+
+
+@pytest.mark.parametrize("fmt", ["UYVY", "YUY2"])
+def test_packed_inputs_1080p_vs_oracle(vfhip, oracle, fmt):
+    w, h, ow, oh = 1920, 1080, 1280, 720
+    raw = np.random.default_rng(9).integers(0, 256, vfhip.plane_layout(fmt, w, h)[1], dtype=np.uint8)
+    got, _ = run(vfhip, fmt, w, h, raw, "bt709", "mpeg2", "bilinear", "BGRA", ow, oh)
+    assert np.array_equal(got, oracle.convertscale(fmt, w, h, raw, "bt709", "mpeg2", "bilinear", "BGRA", ow, oh))

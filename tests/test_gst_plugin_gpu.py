@@ -308,3 +308,14 @@ def test_overlay_pixels_match_oracle(tmp_path):
         got = fo[k * n:(k + 1) * n]
         d = np.abs(want.astype(int) - got.astype(int))
         assert d.max() <= 1 and (d > 0).mean() < 0.02, f"frame {k}: max {d.max()}, {(d > 0).sum()} bytes differ"
+
+
+@pytest.mark.parametrize("fmt", ["UYVY", "YUY2"])
+def test_pixel_parity_packed_inputs_with_cpu_elements(tmp_path, fmt):
+    a, b = tmp_path / "cpu.raw", tmp_path / "hip.raw"
+    r = gst_env.launch(f"videotestsrc num-buffers=2 ! {caps(fmt, 1280, 720)} ! tee name=t "
+                       f"t. ! queue ! videoconvert ! videoscale ! {caps('BGRA', 640, 480)} ! filesink location={a} "
+                       f"t. ! queue ! vfhipconvertscale ! {caps('BGRA', 640, 480)} ! filesink location={b}", timeout=300)
+    assert r.returncode == 0, r.stderr
+    x, y = np.fromfile(a, np.uint8), np.fromfile(b, np.uint8)
+    assert x.size == y.size == 2 * 640 * 480 * 4 and np.array_equal(x, y)

@@ -117,3 +117,16 @@ def test_cubic_taps_known_answers(oracle):
     n, t, ix = taps(16, 12)
     assert n == 6 and t[4] == [-2, 0, 34, 34, 0, -2]
     assert all(sum(r) == 64 for r in t)
+
+
+# ---- packed 4:2:2 inputs (UYVY / YUY2) -> RGB outputs: 34 vectors from the real elements --------------------------------
+MANIFEST_P, ZP = oracle_lib.load_golden("convertscale_gst114_packed.npz")
+
+
+@pytest.mark.parametrize("case", MANIFEST_P, ids=[c["name"] for c in MANIFEST_P])
+def test_oracle_matches_gstreamer_packed_inputs(oracle, case):
+    raw, want = ZP[case["name"] + "_in"], ZP[case["name"] + "_out"]
+    assert hashlib.sha256(raw.tobytes()).hexdigest() == case["in_sha256"]
+    got = oracle.convertscale(case["in_format"], case["w"], case["h"], raw, case["colorimetry"], case["chroma_site"], case["method"],
+                              case["out_format"], case["ow"], case["oh"])
+    assert np.array_equal(got.reshape(-1), want), f"{(got.reshape(-1) != want).sum()} bytes differ"

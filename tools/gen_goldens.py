@@ -196,6 +196,43 @@ def gen_yuv_outputs():
     print("wrote", len(cases), "yuv-output cases")
 
 
+def gen_packed():
+    """UYVY / YUY2 inputs -> RGB outputs through `videoconvert ! videoscale` -> tests/golden/convertscale_gst114_packed.npz"""
+    cases, arrays = [], {}
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = build_helper(tmp)
+        rng = np.random.default_rng(20261006)
+        cols, sites = ["bt601", "bt709", "bt2020"], ["jpeg", "mpeg2"]
+        sizes = [(64, 36, 64, 36), (64, 36, 32, 18), (64, 36, 100, 50), (48, 40, 20, 37), (33, 17, 33, 17), (33, 17, 16, 8), (17, 9, 40, 21), (2, 2, 2, 2),
+                 (200, 8, 100, 4), (31, 30, 31, 12), (50, 20, 125, 20)]
+        sizes += [tuple(int(v) for v in rng.integers(2, 97, 4)) for _ in range(6)]
+        t = 0
+        for fmt in ["UYVY", "YUY2"]:
+            for (w, h, ow, oh) in sizes:
+                col, site = cols[t % 3], sites[(t // 3) % 2]
+                method = ["bilinear", "nearest", "bicubic"][t % 3] if t % 4 else "bilinear"
+                if method == "bicubic" and not all(i == o or (int(np.ceil(4 * max(1.0, i / o))) <= min(i, 64)) for i, o in ((w, ow), (h, oh))):
+                    method = "bilinear"
+                ofmt = "RGBA" if t % 5 == 1 else "BGRA"
+                stride = (2 * w + 3) // 4 * 4
+                raw = rng.integers(0, 256, stride * h, dtype=np.uint8).tobytes()
+                caps = f"video/x-raw,format={fmt},width={w},height={h},framerate=1/1,colorimetry={col},chroma-site={site}"
+                m = {"bilinear": "bilinear", "nearest": "nearest-neighbour", "bicubic": "catrom"}[method]
+                out = gst_run(exe, tmp, raw, len(raw), caps, f"videoconvert ! videoscale method={m}", f"video/x-raw,format={ofmt},width={ow},height={oh}")
+                assert len(out) == ow * oh * 4
+                name = f"pk_{fmt.lower()}_{t:03d}_{w}x{h}_to_{ow}x{oh}_{method}"
+                arrays[name + "_in"], arrays[name + "_out"] = np.frombuffer(raw, np.uint8), np.frombuffer(out, np.uint8)
+                cases.append(dict(name=name, in_format=fmt, w=w, h=h, colorimetry=col, chroma_site=site, method=method, out_format=ofmt, ow=ow, oh=oh,
+                                  in_sha256=hashlib.sha256(raw).hexdigest(), out_sha256=hashlib.sha256(out).hexdigest()))
+                t += 1
+    arrays["manifest"] = np.frombuffer(json.dumps(cases).encode(), np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "convertscale_gst114_packed.npz"), **arrays)
+    print("wrote", len(cases), "packed-input cases")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "packed":
+    gen_packed()
+    sys.exit(0)
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "bicubic":
     gen_bicubic()
     sys.exit(0)
