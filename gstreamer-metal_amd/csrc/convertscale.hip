@@ -322,7 +322,8 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
       return m;
     };
     const int rw = span (th_, h->nt_h, ow, CT_TW, iw), rh = span (tv_, h->nt_v, oh, CT_TH, ih);
-    h->nt_tile = rw <= CT_RW && rh <= CT_RH && (h->vfirst ? CT_TH * rw : rh * CT_TW) <= CT_RH * CT_TW;
+    const int rwa = rw + 14;                          // 8-column alignment slack of the NV12 fast conversion on both sides
+    h->nt_tile = h->nt_h <= CT_MAXN && h->nt_v <= CT_MAXN && rwa <= CT_RW && rh <= CT_RH && (h->vfirst ? CT_TH * rwa : rh * CT_TW) <= CT_RH * CT_TW;
     if (const char *e = getenv ("VFHIP_CUBIC_TILE")) h->nt_tile = h->nt_tile && atoi (e) != 0;        // tuning / test knob
     if (!h->nt_tile) {                                // three-pass fallback: conversion at the input size by a child handle, then the passes
       if (in->format != out->format) {
@@ -540,6 +541,10 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
     t.out = (uint8_t *) out->data[0]; t.os = out->stride[0];
     t.ow = h->out.width; t.oh = h->out.height; t.nh = h->nt_h; t.nv = h->nt_v; t.vfirst = h->vfirst;
     t.tab_h = h->d_nt_h; t.tab_v = h->d_nt_v;
+    {
+      const uintptr_t a = (uintptr_t) t.cs.in[0] | (uintptr_t) t.cs.in[1] | (uintptr_t) t.cs.is[0] | (uintptr_t) t.cs.is[1] | (uintptr_t) in_pitch;
+      t.fast_nv12 = h->in.format == VFHIP_FORMAT_NV12 && !(a & 7) && h->in.width >= 16 && getenv ("VFHIP_CUBIC_SCALAR") == nullptr;
+    }
     dim3 grid ((unsigned) ((t.ow + CT_TW - 1) / CT_TW), (unsigned) ((t.oh + CT_TH - 1) / CT_TH), (unsigned) n_frames);
     hipLaunchKernelGGL (k_cs_cubic_tile, grid, dim3 (256), 0, s, t);
     VFHIP_CHECK_HIP (hipGetLastError ());

@@ -80,19 +80,53 @@ __global__ __launch_bounds__ (256) void k_ntap_h (const NtapParams p)
 // rounding between the passes is kept, so the result is the three-pass path's bit for bit while every input byte is read
 // about 1.3 times and nothing intermediate touches HBM.  The host falls back to the three-pass path when a tile's source
 // region does not fit the LDS arrays (down-scales beyond ~2.1:1 horizontally or ~2.5:1 vertically).
-constexpr int CT_TW = 64, CT_TH = 16, CT_RW = 144, CT_RH = 48;
+constexpr int CT_TW = 64, CT_TH = 16, CT_RW = 152, CT_RH = 48, CT_MAXN = 12;       // CT_RW: a multiple of 8 (aligned 8-column groups) with room for the alignment slack
+
+// Eight adjacent source pixels (columns gx .. gx+7, gx % 8 == 0) of NV12 row cy, converted with the packed ORC pipeline of
+// the 2-tap kernels (load_craw / hfilter / orc_pair: one 8-byte luma load, two chroma rows with their neighbour pairs)
+// instead of eight scalar cs_tap calls.  Same arithmetic (horizontal then vertical chroma filter, mulhs matrix).
+// Requires 8-byte aligned planes / strides and gx + 8 <= in_w.
+template <bool COSITED>
+__device__ __forceinline__ void cs_convert8_nv12 (const CsParams &p, const uint8_t *const in[3], int gx, int cy, uint32_t out[8])
+{
+  const int cw = (p.in_w + 1) >> 1, chh = (p.in_h + 1) >> 1;
+  const int j = cy >> 1, jn = (cy & 1) ? min (j + 1, chh - 1) : max (j - 1, 0);
+  // neighbour pairs, edge-replicated: the right one of the last chroma group / the left one of the first are their own
+  const uint32_t roff = (gx / 2 + 4 < cw) ? 8u : 6u, loff = gx > 0 ? 2u : 0u;
+  const CRow a = hfilter<COSITED> (load_craw<COSITED> (in[1], (uint32_t) j * (uint32_t) p.is[1] + (uint32_t) gx, roff, loff));
+  const CRow b = hfilter<COSITED> (load_craw<COSITED> (in[1], (uint32_t) jn * (uint32_t) p.is[1] + (uint32_t) gx, roff, loff));
+  const uint32_t X = 0x80808080u;
+  const uint32_t e01 = filt31_u8 (a.e01, b.e01) ^ X, e23 = filt31_u8 (a.e23, b.e23) ^ X, o01 = filt31_u8 (a.o01, b.o01) ^ X, o23 = filt31_u8 (a.o23, b.o23) ^ X;
+  const uint2 yv = *reinterpret_cast<const uint2 *> (in[0] + (size_t) cy * p.is[0] + gx);
+  const uint32_t y0 = yv.x ^ X, y1 = yv.y ^ X;
+  const int bias = 128 << 16;
+#pragma unroll
+  for (int n = 0; n < 4; n++) {
+    const uint32_t sel = (n & 1) ? 0x03030202u : 0x01010000u;
+    const uint32_t yn = n < 2 ? y0 : y1, en = n < 2 ? e01 : e23, on = n < 2 ? o01 : o23;
+    uint32_t bb, gg, rr;
+    orc_pair (perm_b32 (0u, yn, sel), perm_b32 (0u, en, sel), perm_b32 (0u, on, sel), p.c, bias, bb, gg, rr);
+    const uint32_t x = p.out_rgba ? rr : bb, z = p.out_rgba ? bb : rr;        // byte 0 / byte 2 channel
+    const uint32_t xg = perm_b32 (gg, x, 0x05010400u);                          // [x_e, g_e, x_o, g_o]
+    const uint32_t za = perm_b32 (0xffffffffu, z, 0x07010700u);                 // [z_e, ff, z_o, ff]
+    out[2 * n] = perm_b32 (za, xg, 0x05040100u);                                // [x_e, g_e, z_e, ff]
+    out[2 * n + 1] = perm_b32 (za, xg, 0x07060302u);                            // [x_o, g_o, z_o, ff]
+  }
+}
 
 struct CubicTileParams {
   CsParams cs;                       // input planes / strides / matrix / formats for cs_tap; in_pitch, out_pitch for batches
   uint8_t *out; int os;
   int ow, oh, nh, nv, vfirst;
+  int fast_nv12;                     // NV12 input with 8-byte aligned planes / strides: convert in 8-column groups (cs_convert8_nv12)
   const int2 *tab_h, *tab_v;         // [ow][nh], [oh][nv] of {source index, 6-bit weight}; nh / nv == 0: no scaling on that axis
 };
 
 __global__ __launch_bounds__ (256) void k_cs_cubic_tile (const CubicTileParams p)
 {
-  __shared__ uint32_t reg[CT_RH][CT_RW];                              // converted source region
+  __shared__ __attribute__ ((aligned (16))) uint32_t reg[CT_RH][CT_RW];   // converted source region
   __shared__ uint32_t tmp[CT_RH * CT_TW];                             // first-pass result: [CT_TH][rw] (V first) or [rh][CT_TW] (H first)
+  __shared__ int2 lth[CT_TW * CT_MAXN], ltv[CT_TH * CT_MAXN];         // this tile's tap tables (LDS reads instead of per-lane global loads)
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * CT_TW, y0 = blockIdx.y * CT_TH;
   const int tw = min (CT_TW, p.ow - x0), th = min (CT_TH, p.oh - y0);
@@ -101,21 +135,48 @@ __global__ __launch_bounds__ (256) void k_cs_cubic_tile (const CubicTileParams p
                            p.cs.in[2] ? p.cs.in[2] + (size_t) blockIdx.z * p.cs.in_pitch : nullptr };
   uint8_t *out = p.out + (size_t) blockIdx.z * p.cs.out_pitch;
   // source region of this tile (tables hold absolute, edge-clamped, non-decreasing indices)
-  const int cx0 = p.nh ? p.tab_h[(size_t) x0 * p.nh].x : x0, cx1 = p.nh ? p.tab_h[(size_t) (x0 + tw - 1) * p.nh + p.nh - 1].x : x0 + tw - 1;
+  int cx0 = p.nh ? p.tab_h[(size_t) x0 * p.nh].x : x0;
+  const int cx1 = p.nh ? p.tab_h[(size_t) (x0 + tw - 1) * p.nh + p.nh - 1].x : x0 + tw - 1;
   const int ry0 = p.nv ? p.tab_v[(size_t) y0 * p.nv].x : y0, ry1 = p.nv ? p.tab_v[(size_t) (y0 + th - 1) * p.nv + p.nv - 1].x : y0 + th - 1;
-  const int rw = cx1 - cx0 + 1, rh = ry1 - ry0 + 1;
-  for (int i = tid; i < rw * rh; i += 256) {
-    const int ry = i / rw, rx = i - ry * rw;
-    int px[4];
-    cs_tap (p.cs, in, cx0 + rx, ry0 + ry, px);
-    reg[ry][rx] = (uint32_t) px[0] | ((uint32_t) px[1] << 8) | ((uint32_t) px[2] << 16) | ((uint32_t) px[3] << 24);
+  const int rh = ry1 - ry0 + 1;
+  int rw = cx1 - cx0 + 1;
+  for (int i = tid; i < tw * p.nh; i += 256) lth[i] = p.tab_h[(size_t) x0 * p.nh + i];
+  for (int i = tid; i < th * p.nv; i += 256) ltv[i] = p.tab_v[(size_t) y0 * p.nv + i];
+  if (p.fast_nv12) {
+    // region widened to whole 8-column groups; groups that would cross the right image edge fall back to cs_tap
+    const int ga = cx0 & ~7, groups = ((cx1 + 1 - ga) + 7) >> 3;
+    for (int i = tid; i < groups * rh; i += 256) {
+      const int ry = i / groups, g = i - ry * groups, gx = ga + 8 * g;
+      uint32_t px8[8];
+      if (gx + 8 <= p.cs.in_w) {
+        if (p.cs.cosited) cs_convert8_nv12<true> (p.cs, in, gx, ry0 + ry, px8);
+        else cs_convert8_nv12<false> (p.cs, in, gx, ry0 + ry, px8);
+      } else {
+#pragma unroll 1
+        for (int k = 0; k < 8; k++) {
+          int px[4];
+          cs_tap (p.cs, in, min (gx + k, p.cs.in_w - 1), ry0 + ry, px);
+          px8[k] = (uint32_t) px[0] | ((uint32_t) px[1] << 8) | ((uint32_t) px[2] << 16) | ((uint32_t) px[3] << 24);
+        }
+      }
+      uint4 *d = reinterpret_cast<uint4 *> (&reg[ry][8 * g]);
+      d[0] = make_uint4 (px8[0], px8[1], px8[2], px8[3]); d[1] = make_uint4 (px8[4], px8[5], px8[6], px8[7]);
+    }
+    cx0 = ga; rw = 8 * groups;
+  } else {
+    for (int i = tid; i < rw * rh; i += 256) {
+      const int ry = i / rw, rx = i - ry * rw;
+      int px[4];
+      cs_tap (p.cs, in, cx0 + rx, ry0 + ry, px);
+      reg[ry][rx] = (uint32_t) px[0] | ((uint32_t) px[1] << 8) | ((uint32_t) px[2] << 16) | ((uint32_t) px[3] << 24);
+    }
   }
   __syncthreads ();
   if (p.nh && p.nv) {
     if (p.vfirst) {                                                    // tmp[ty][rx] = vertical taps over the region's columns
       for (int i = tid; i < th * rw; i += 256) {
         const int ty = i / rw, rx = i - ty * rw;
-        const int2 *t = p.tab_v + (size_t) (y0 + ty) * p.nv;
+        const int2 *t = ltv + ty * p.nv;
         Acc4 a = { 0.0f, 0.0f, 0.0f, 0.0f };
         for (int l = 0; l < p.nv; l++) ntap_acc (a, reg[t[l].x - ry0][rx], t[l].y);
         tmp[ty * rw + rx] = ntap_finish (a);
@@ -123,7 +184,7 @@ __global__ __launch_bounds__ (256) void k_cs_cubic_tile (const CubicTileParams p
     } else {                                                           // tmp[ry][tx] = horizontal taps over the region's rows
       for (int i = tid; i < rh * tw; i += 256) {
         const int ry = i / tw, tx = i - ry * tw;
-        const int2 *t = p.tab_h + (size_t) (x0 + tx) * p.nh;
+        const int2 *t = lth + tx * p.nh;
         Acc4 a = { 0.0f, 0.0f, 0.0f, 0.0f };
         for (int l = 0; l < p.nh; l++) ntap_acc (a, reg[ry][t[l].x - cx0], t[l].y);
         tmp[ry * CT_TW + tx] = ntap_finish (a);
@@ -137,19 +198,19 @@ __global__ __launch_bounds__ (256) void k_cs_cubic_tile (const CubicTileParams p
     uint32_t q;
     if (p.nh && p.nv) {
       if (p.vfirst) {
-        const int2 *t = p.tab_h + (size_t) (x0 + tx) * p.nh;
+        const int2 *t = lth + tx * p.nh;
         for (int l = 0; l < p.nh; l++) ntap_acc (a, tmp[ty * rw + (t[l].x - cx0)], t[l].y);
       } else {
-        const int2 *t = p.tab_v + (size_t) (y0 + ty) * p.nv;
+        const int2 *t = ltv + ty * p.nv;
         for (int l = 0; l < p.nv; l++) ntap_acc (a, tmp[(t[l].x - ry0) * CT_TW + tx], t[l].y);
       }
       q = ntap_finish (a);
     } else if (p.nh) {
-      const int2 *t = p.tab_h + (size_t) (x0 + tx) * p.nh;
+      const int2 *t = lth + tx * p.nh;
       for (int l = 0; l < p.nh; l++) ntap_acc (a, reg[ty][t[l].x - cx0], t[l].y);
       q = ntap_finish (a);
     } else if (p.nv) {
-      const int2 *t = p.tab_v + (size_t) (y0 + ty) * p.nv;
+      const int2 *t = ltv + ty * p.nv;
       for (int l = 0; l < p.nv; l++) ntap_acc (a, reg[t[l].x - ry0][tx], t[l].y);
       q = ntap_finish (a);
     } else q = reg[ty][tx];
