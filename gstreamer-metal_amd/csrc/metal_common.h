@@ -205,13 +205,15 @@ __device__ __forceinline__ void store_block (const OutImg &o, int bx, int by, co
       for (int dy = 0; dy < 2; dy++) {
         if (y0 + dy >= o.h) break;
         uint32_t *row = reinterpret_cast<uint32_t *> (o.p[0] + (size_t) (y0 + dy) * o.s[0]);
-#pragma unroll
-        for (int dx = 0; dx < 2; dx++) {
-          if (x0 + dx >= o.w) break;
-          uint32_t v = q[dy][dx];
-          if (o.fmt == VFHIP_FORMAT_BGRA) v = (v & 0xff00ff00u) | ((v & 0xff) << 16) | ((v >> 16) & 0xff);
-          row[x0 + dx] = v;
+        uint32_t v0 = q[dy][0], v1 = q[dy][1];
+        if (o.fmt == VFHIP_FORMAT_BGRA) {
+          v0 = __builtin_amdgcn_perm (0u, v0, 0x03000102u);           // swap bytes 0 and 2
+          v1 = __builtin_amdgcn_perm (0u, v1, 0x03000102u);
         }
+        // the pair goes out as ONE 8-byte store when the address allows: a dword store per pixel leaves every store
+        // instruction half-coalesced (lane stride 8 bytes)
+        if (x0 + 1 < o.w && ((reinterpret_cast<uintptr_t> (row) & 7) == 0)) *reinterpret_cast<uint2 *> (row + x0) = make_uint2 (v0, v1);
+        else { row[x0] = v0; if (x0 + 1 < o.w) row[x0 + 1] = v1; }
       }
       return;
     }
