@@ -245,6 +245,11 @@ static void launch_half (CsParams &p, int n_frames, int n_cu, hipStream_t s)
   if (r == 4 || r == 8 || r == 16) rows = r;
   p.half_rows = rows;
   dim3 grid ((unsigned) (bpf (rows) * n_frames));
+  if (p.in_fmt == VFHIP_FORMAT_I420) {
+    if (p.out_rgba) hipLaunchKernelGGL ((k_cs_i420_half<true>), grid, dim3 (256), 0, s, p);
+    else hipLaunchKernelGGL ((k_cs_i420_half<false>), grid, dim3 (256), 0, s, p);
+    return;
+  }
   if (p.cosited) {
     if (p.out_rgba) hipLaunchKernelGGL ((k_cs_nv12_half<true, true>), grid, dim3 (256), 0, s, p);
     else hipLaunchKernelGGL ((k_cs_nv12_half<true, false>), grid, dim3 (256), 0, s, p);
@@ -397,10 +402,10 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
     VFHIP_CHECK_HIP (hipMemcpy (h->d_htab, ht.data (), ht.size () * sizeof (int), hipMemcpyHostToDevice));
   }
 
-  const bool half = in->format == VFHIP_FORMAT_NV12 && method == VFHIP_SCALE_BILINEAR && !h->add_borders &&
+  const bool half = in_yuv && method == VFHIP_SCALE_BILINEAR && !h->add_borders &&
                     in->width == 2 * out->width && in->height == 2 * out->height && (out->width % 4) == 0 && out->height >= 3;
   const bool taps = in_yuv && method == VFHIP_SCALE_BILINEAR && in->width >= 8;
-  if (half) { h->kernel = VfHipConvertScale::K_HALF; h->kernel_name = "k_cs_nv12_half"; }
+  if (half) { h->kernel = VfHipConvertScale::K_HALF; h->kernel_name = in->format == VFHIP_FORMAT_I420 ? "k_cs_i420_half" : "k_cs_nv12_half"; }
   else if (taps) { h->kernel = VfHipConvertScale::K_TAPS; h->kernel_name = "k_cs_taps"; }
   else { h->kernel = VfHipConvertScale::K_GENERIC; h->kernel_name = "k_cs_generic"; }
   h->configured = true;
@@ -595,6 +600,12 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
     const uintptr_t a = (uintptr_t) p.in[0] | (uintptr_t) p.in[1] | (uintptr_t) p.is[0] | (uintptr_t) p.is[1] | (uintptr_t) in_pitch;
     const uintptr_t b = (uintptr_t) p.out | (uintptr_t) p.os | (uintptr_t) out_pitch;
     if ((a & 7) || (b & 15)) half = false;
+    // I420: 8-byte luma loads as above, 4-byte loads from the U and V planes
+    if (p.in_fmt == VFHIP_FORMAT_I420 && (((uintptr_t) p.in[1] | (uintptr_t) p.in[2] | (uintptr_t) p.is[1] | (uintptr_t) p.is[2]) & 3)) half = false;
+    if (p.in_fmt == VFHIP_FORMAT_I420 && (((uintptr_t) p.in[1] | (uintptr_t) p.is[1]) & 7)) { /* the NV12 test above was stricter than I420 needs: only & 3 matters */
+      const uintptr_t a2 = (uintptr_t) p.in[0] | (uintptr_t) p.is[0] | (uintptr_t) in_pitch;
+      half = !(a2 & 7) && !(b & 15) && !(((uintptr_t) p.in[1] | (uintptr_t) p.in[2] | (uintptr_t) p.is[1] | (uintptr_t) p.is[2] | (uintptr_t) in_pitch) & 3);
+    }
   }
   if (half) {
     launch_half (p, n_frames, h->dev->n_cu, s);

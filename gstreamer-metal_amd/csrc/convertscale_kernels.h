@@ -245,6 +245,81 @@ __global__ __launch_bounds__ (256, 8) void k_cs_nv12_half (const CsParams p)
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_cs_i420_half<RGBA>: I420 -> BGRA / RGBA at exactly 2:1 in both axes, bilinear
+// ------------------------------------------------------------------------------------------------
+// GStreamer converts I420 with NEAREST-replicated chroma (its I420 fast path: oracle/gst114.c), so the four source pixels
+// behind one output pixel share one (U, V): the three chroma terms of the ORC matrix are evaluated once per OUTPUT pixel,
+// masked to their high halves, and added to each source pixel's luma term with full-rate v_add (the mulhs sums stay exact
+// because every addend has a zero low half).  No chroma filter state crosses rows, so a lane simply walks its strip with
+// the next row's loads in flight.  Same mapping, taps and packing as k_cs_nv12_half; ~25 % fewer VALU cycles per pixel.
+template <bool RGBA>
+__global__ __launch_bounds__ (256, 8) void k_cs_i420_half (const CsParams p)
+{
+  const int cgpr = p.out_w >> 2;
+  const int b = blockIdx.x, rows = p.half_rows;
+  const int strips = (p.out_h + rows - 1) / rows;
+  const int bpf = (cgpr * strips + 255) >> 8;
+  const int frame = b / bpf;
+  const int t = (b % bpf) * 256 + threadIdx.x;
+  if (t >= cgpr * strips) return;
+  const int strip = t / cgpr, cg = t - strip * cgpr;
+  const int y0 = strip * rows, yend = min (y0 + rows, p.out_h);
+  const uint8_t *yp = p.in[0] + (size_t) frame * p.in_pitch, *up = p.in[1] + (size_t) frame * p.in_pitch, *vp = p.in[2] + (size_t) frame * p.in_pitch;
+  uint8_t *op = p.out + (size_t) frame * p.out_pitch;
+  const uint32_t ys = (uint32_t) p.is[0], us = (uint32_t) p.is[1], vs = (uint32_t) p.is[2], os = (uint32_t) p.os;
+  const uint32_t cx = 8u * (uint32_t) cg, ccx = 4u * (uint32_t) cg;
+  uint32_t wgt[4];
+#pragma unroll
+  for (int n = 0; n < 4; n++) {
+    const uint32_t tt = (uint32_t) (cg * 4 + n) * p.hinc;
+    const uint32_t f = (tt >> 8) & 0xffu;
+    wgt[n] = (255u - f) | (f << 8);
+  }
+  const uint32_t X = 0x80808080u;
+  const int M = (int) 0xffff0000, bias = 128 << 16;
+  auto load_row = [&] (int y, uint2 &yt, uint2 &yb, uint32_t &u4, uint32_t &v4) {
+    const uint32_t yo = __umul24 ((uint32_t) (2 * y), ys) + cx;
+    yt = *reinterpret_cast<const uint2 *> (yp + yo);
+    yb = *reinterpret_cast<const uint2 *> (yp + (yo + ys));
+    u4 = *reinterpret_cast<const uint32_t *> (up + (__umul24 ((uint32_t) y, us) + ccx));
+    v4 = *reinterpret_cast<const uint32_t *> (vp + (__umul24 ((uint32_t) y, vs) + ccx));
+  };
+  uint2 yt, yb; uint32_t u4, v4;
+  load_row (y0, yt, yb, u4, v4);
+  for (int y = y0; y < yend; y++) {
+    uint2 nyt, nyb; uint32_t nu4, nv4;
+    load_row (min (y + 1, yend - 1), nyt, nyb, nu4, nv4);             // the last row re-reads itself (never out of bounds)
+    const uint32_t ux = u4 ^ X, vx = v4 ^ X;
+    const uint32_t yt0 = yt.x ^ X, yt1 = yt.y ^ X, yb0 = yb.x ^ X, yb1 = yb.y ^ X;
+    uint32_t out[4];
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+      // chroma terms of output pixel n: [U U V V] of chroma sample n, once for its 2x2 source pixels
+      const uint32_t uv = perm_b32 (vx, ux, (uint32_t) n * 0x01010101u + 0x04040000u);
+      const int cr = mad_i32_i16<1> (uv, p.c[1], 0) & M;                                   // mulhs (V, p2) << 16
+      const int cb = mad_i32_i16<0> (uv, p.c[2], 0) & M;                                   // mulhs (U, p3) << 16
+      const int cgn = mad_i32_i16<1> (uv, p.c[4], mad_i32_i16<0> (uv, p.c[3], 0) & M) & M; // (mulhs (U, p4) + mulhs (V, p5)) << 16
+      const uint32_t sy = (n & 1) ? 0x03030202u : 0x01010000u;
+      const uint32_t yst = perm_b32 (0u, n < 2 ? yt0 : yt1, sy), ysb = perm_b32 (0u, n < 2 ? yb0 : yb1, sy);
+      // luma terms (+128 bias) of the four source pixels, low halves cleared
+      const int wte = mad_i32_i16<0> (yst, p.c[0], bias) & M, wto = mad_i32_i16<1> (yst, p.c[0], bias) & M;
+      const int wbe = mad_i32_i16<0> (ysb, p.c[0], bias) & M, wbo = mad_i32_i16<1> (ysb, p.c[0], bias) & M;
+      // channel = luma + chroma (plain adds: exact, every addend has a zero low half), saturate the [even | odd] pair
+#define VF_PAIR(we, wo, c) sat_pk_u8_i16 (perm_b32 ((uint32_t) ((wo) + (c)), (uint32_t) ((we) + (c)), 0x07060302u))
+      const uint32_t bt = VF_PAIR (wte, wto, cb), gt = VF_PAIR (wte, wto, cgn), rt = VF_PAIR (wte, wto, cr);
+      const uint32_t bbm = VF_PAIR (wbe, wbo, cb), gbm = VF_PAIR (wbe, wbo, cgn), rbm = VF_PAIR (wbe, wbo, cr);
+#undef VF_PAIR
+      const uint32_t vb = avg_rnd_u8 (bt, bbm), vg = avg_rnd_u8 (gt, gbm), vr = avg_rnd_u8 (rt, rbm);
+      const uint32_t hb = dot4_u8 (vb, wgt[n], vb & 0xffu), hg = dot4_u8 (vg, wgt[n], vg & 0xffu), hr = dot4_u8 (vr, wgt[n], vr & 0xffu);
+      const uint32_t lo = RGBA ? perm_b32 (hg, hr, 0x0c0c0501u) : perm_b32 (hg, hb, 0x0c0c0501u);
+      out[n] = perm_b32 (RGBA ? hb : hr, lo, 0x0d050100u);
+    }
+    *reinterpret_cast<uint4 *> (op + (__umul24 ((uint32_t) y, os) + 2u * cx)) = make_uint4 (out[0], out[1], out[2], out[3]);
+    yt = nyt; yb = nyb; u4 = nu4; v4 = nv4;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_cs_taps<I420>: NV12 / I420 -> BGRA / RGBA, 2-tap bilinear at ANY ratio (BASELINE configs[0], 1080p -> 720p, up-scales ...)
 // ------------------------------------------------------------------------------------------------
 // One output pixel per lane.  Its 2x2 taps are two ADJACENT source columns (xa, xa+1) on two source rows, so per

@@ -293,3 +293,49 @@ def test_packed_inputs_1080p_vs_oracle(vfhip, oracle, fmt):
     raw = np.random.default_rng(9).integers(0, 256, vfhip.plane_layout(fmt, w, h)[1], dtype=np.uint8)
     got, _ = run(vfhip, fmt, w, h, raw, "bt709", "mpeg2", "bilinear", "BGRA", ow, oh)
     assert np.array_equal(got, oracle.convertscale(fmt, w, h, raw, "bt709", "mpeg2", "bilinear", "BGRA", ow, oh))
+
+
+# ---- I420 at exactly 2:1: k_cs_i420_half -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h", HALF_CASES)
+@pytest.mark.parametrize("col", ["bt601", "bt709", "bt2020"])
+@pytest.mark.parametrize("ofmt", ["BGRA", "RGBA"])
+def test_i420_half_kernel_vs_oracle(vfhip, oracle, w, h, col, ofmt):
+    rng = np.random.default_rng(w * 1000 + h + 7)
+    raw = rng.integers(0, 256, vfhip.plane_layout("I420", w, h)[1], dtype=np.uint8)
+    got, kname = run(vfhip, "I420", w, h, raw, col, "jpeg", "bilinear", ofmt, w // 2, h // 2)
+    assert kname == "k_cs_i420_half"
+    want = oracle.convertscale("I420", w, h, raw, col, "jpeg", "bilinear", ofmt, w // 2, h // 2)
+    assert np.array_equal(got, want), f"max diff {np.abs(got.astype(int) - want.astype(int)).max()}"
+
+
+def test_i420_half_extremes_and_full_size_batch(vfhip, oracle):
+    import torch
+    w, h = 64, 16
+    size = vfhip.plane_layout("I420", w, h)[1]
+    for fill in (0, 255, None):
+        raw = np.full(size, fill, np.uint8) if fill is not None else np.tile(np.array([0, 255, 255, 0, 16, 235, 240, 1], np.uint8), size // 8 + 1)[:size]
+        for col in ("bt601", "bt709", "bt2020"):
+            got, _ = run(vfhip, "I420", w, h, raw, col, "mpeg2", "bilinear", "BGRA", w // 2, h // 2)
+            assert np.array_equal(got, oracle.convertscale("I420", w, h, raw, col, "mpeg2", "bilinear", "BGRA", w // 2, h // 2))
+    # 2160p -> 1080p, a 3-frame device batch: frame 2 == alone; top slice == oracle on the slice (rows are independent here)
+    w, h, ow, oh, n = 3840, 2160, 1920, 1080, 3
+    lay, size = vfhip.plane_layout("I420", w, h)
+    pitch = (size + 255) // 256 * 256
+    g = torch.Generator(device="cpu").manual_seed(9)
+    host = torch.randint(0, 256, (n, pitch), dtype=torch.uint8, generator=g)
+    dev_in, dev_out = host.cuda(), torch.zeros((n, ow * oh * 4), dtype=torch.uint8, device="cuda")
+    cs = vfhip.ConvertScale(0)
+    cs.configure("I420", w, h, "BGRA", ow, oh, colorimetry="bt2020", chroma_site="mpeg2")
+    assert cs.kernel_name == "k_cs_i420_half"
+    s = torch.cuda.Stream()
+    cs.process_device(dev_in.data_ptr(), dev_out.data_ptr(), stream=s.cuda_stream, n_frames=n, in_pitch=pitch, out_pitch=ow * oh * 4)
+    s.synchronize()
+    out = dev_out.cpu().numpy().reshape(n, oh, ow, 4)
+    assert np.array_equal(cs.process(host[2, :size].numpy()).reshape(oh, ow, 4), out[2])
+    hs = 128
+    f0 = host[0].numpy()
+    ys, cs_ = lay[0][1], lay[1][1]
+    top = np.concatenate([f0[:ys * hs], f0[lay[1][0]: lay[1][0] + cs_ * (hs // 2)], f0[lay[2][0]: lay[2][0] + cs_ * (hs // 2)]])
+    want = oracle.convertscale("I420", w, hs, top, "bt2020", "mpeg2", "bilinear", "BGRA", ow, hs // 2)
+    assert np.array_equal(out[0, :hs // 2], want)
+    cs.close()

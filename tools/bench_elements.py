@@ -121,6 +121,21 @@ def main():
     report("C1 convertscale NV12 1080p -> BGRA 640x480 (generic gst-exact)", cs.kernel_name, timed(c1, s, 5), 64, w * h * 3 // 2 + 4 * ow * oh)
     cs.close()
 
+    # C2's shape with an I420 input: k_cs_i420_half (GStreamer's I420 path replicates chroma: less arithmetic per pixel)
+    w, h, ow, oh = 3840, 2160, 1920, 1080
+    size = vfhip.plane_layout("I420", w, h)[1]
+    pitch = (size + 255) // 256 * 256
+    NI = 64
+    iin, iout = ring(NI, size, 50), ring(NI, 4 * ow * oh, 51)
+    cs = vfhip.ConvertScale(0)
+    cs.configure("I420", w, h, "BGRA", ow, oh, colorimetry="bt2020", chroma_site="mpeg2")
+
+    def c2i():
+        cs.process_device(iin.data_ptr(), iout.data_ptr(), stream=s.cuda_stream, n_frames=NI, in_pitch=pitch, out_pitch=iout.shape[1])
+    report("C2 shape, I420 2160p -> BGRA 1080p bilinear (gst-exact)", cs.kernel_name, timed(c2i, s, 20, warm=10), NI, w * h * 3 // 2 + 4 * ow * oh)
+    cs.close()
+    del iin, iout
+
     # C2 with method=bicubic (videoscale method=catrom, bit-exact)
     w, h, ow, oh = 3840, 2160, 1920, 1080
     size = vfhip.plane_layout("NV12", w, h)[1]
