@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-launch duration of the headline kernel over a few seconds of back-to-back launches (power / clock dynamics).
-usage: clock_series.py [seconds] [frames]"""
+usage: clock_series.py [seconds] [frames] [const]   (const: a constant-byte input ring instead of random bytes — data toggling costs power)"""
 import os
 import sys
 
@@ -15,7 +15,10 @@ W, H, OW, OH = 3840, 2160, 1920, 1080
 _, in_size = vfhip.plane_layout("NV12", W, H)
 in_pitch = (in_size + 255) // 256 * 256
 out_pitch = OW * OH * 4
-ring_in = torch.randint(0, 256, (F, in_pitch), dtype=torch.uint8, device="cuda")
+if len(sys.argv) > 3 and sys.argv[3] == "const":
+    ring_in = torch.full((F, in_pitch), 0x5a, dtype=torch.uint8, device="cuda")
+else:
+    ring_in = torch.randint(0, 256, (F, in_pitch), dtype=torch.uint8, device="cuda")
 ring_out = torch.empty((F, out_pitch), dtype=torch.uint8, device="cuda")
 cs = vfhip.ConvertScale(0)
 cs.configure("NV12", W, H, "BGRA", OW, OH, colorimetry="bt2020", chroma_site="mpeg2")
