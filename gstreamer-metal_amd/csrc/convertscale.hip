@@ -597,15 +597,13 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
   bool half = h->kernel == VfHipConvertScale::K_HALF;
   if (half) {
     // vector-access preconditions of the fast path; otherwise the generic kernel computes the same bytes
-    const uintptr_t a = (uintptr_t) p.in[0] | (uintptr_t) p.in[1] | (uintptr_t) p.is[0] | (uintptr_t) p.is[1] | (uintptr_t) in_pitch;
+    // 8-byte luma loads (both formats), 8-byte chroma loads from the NV12 UV plane, 4-byte ones from the I420 U / V planes,
+    // 16-byte stores
+    const bool i420 = p.in_fmt == VFHIP_FORMAT_I420;
+    const uintptr_t luma = (uintptr_t) p.in[0] | (uintptr_t) p.is[0] | (uintptr_t) in_pitch;
+    const uintptr_t chroma = (uintptr_t) p.in[1] | (uintptr_t) p.is[1] | (i420 ? (uintptr_t) p.in[2] | (uintptr_t) p.is[2] : 0);
     const uintptr_t b = (uintptr_t) p.out | (uintptr_t) p.os | (uintptr_t) out_pitch;
-    if ((a & 7) || (b & 15)) half = false;
-    // I420: 8-byte luma loads as above, 4-byte loads from the U and V planes
-    if (p.in_fmt == VFHIP_FORMAT_I420 && (((uintptr_t) p.in[1] | (uintptr_t) p.in[2] | (uintptr_t) p.is[1] | (uintptr_t) p.is[2]) & 3)) half = false;
-    if (p.in_fmt == VFHIP_FORMAT_I420 && (((uintptr_t) p.in[1] | (uintptr_t) p.is[1]) & 7)) { /* the NV12 test above was stricter than I420 needs: only & 3 matters */
-      const uintptr_t a2 = (uintptr_t) p.in[0] | (uintptr_t) p.is[0] | (uintptr_t) in_pitch;
-      half = !(a2 & 7) && !(b & 15) && !(((uintptr_t) p.in[1] | (uintptr_t) p.in[2] | (uintptr_t) p.is[1] | (uintptr_t) p.is[2] | (uintptr_t) in_pitch) & 3);
-    }
+    if ((luma & 7) || (chroma & (i420 ? 3 : 7)) || (b & 15)) half = false;
   }
   if (half) {
     launch_half (p, n_frames, h->dev->n_cu, s);
