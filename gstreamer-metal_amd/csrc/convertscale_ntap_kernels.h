@@ -122,7 +122,8 @@ struct CubicTileParams {
   const int2 *tab_h, *tab_v;         // [ow][nh], [oh][nv] of {source index, 6-bit weight}; nh / nv == 0: no scaling on that axis
 };
 
-__global__ __launch_bounds__ (256) void k_cs_cubic_tile (const CubicTileParams p)
+template <int THREADS>
+__global__ __launch_bounds__ (THREADS) void k_cs_cubic_tile (const CubicTileParams p)
 {
   __shared__ __attribute__ ((aligned (16))) uint32_t reg[CT_RH][CT_RW];   // converted source region
   __shared__ uint32_t tmp[CT_RH * CT_TW];                             // first-pass result: [CT_TH][rw] (V first) or [rh][CT_TW] (H first)
@@ -140,12 +141,12 @@ __global__ __launch_bounds__ (256) void k_cs_cubic_tile (const CubicTileParams p
   const int ry0 = p.nv ? p.tab_v[(size_t) y0 * p.nv].x : y0, ry1 = p.nv ? p.tab_v[(size_t) (y0 + th - 1) * p.nv + p.nv - 1].x : y0 + th - 1;
   const int rh = ry1 - ry0 + 1;
   int rw = cx1 - cx0 + 1;
-  for (int i = tid; i < tw * p.nh; i += 256) lth[i] = p.tab_h[(size_t) x0 * p.nh + i];
-  for (int i = tid; i < th * p.nv; i += 256) ltv[i] = p.tab_v[(size_t) y0 * p.nv + i];
+  for (int i = tid; i < tw * p.nh; i += THREADS) lth[i] = p.tab_h[(size_t) x0 * p.nh + i];
+  for (int i = tid; i < th * p.nv; i += THREADS) ltv[i] = p.tab_v[(size_t) y0 * p.nv + i];
   if (p.fast_nv12) {
     // region widened to whole 8-column groups; groups that would cross the right image edge fall back to cs_tap
     const int ga = cx0 & ~7, groups = ((cx1 + 1 - ga) + 7) >> 3;
-    for (int i = tid; i < groups * rh; i += 256) {
+    for (int i = tid; i < groups * rh; i += THREADS) {
       const int ry = i / groups, g = i - ry * groups, gx = ga + 8 * g;
       uint32_t px8[8];
       if (gx + 8 <= p.cs.in_w) {
@@ -164,7 +165,7 @@ __global__ __launch_bounds__ (256) void k_cs_cubic_tile (const CubicTileParams p
     }
     cx0 = ga; rw = 8 * groups;
   } else {
-    for (int i = tid; i < rw * rh; i += 256) {
+    for (int i = tid; i < rw * rh; i += THREADS) {
       const int ry = i / rw, rx = i - ry * rw;
       int px[4];
       cs_tap (p.cs, in, cx0 + rx, ry0 + ry, px);
@@ -174,7 +175,7 @@ __global__ __launch_bounds__ (256) void k_cs_cubic_tile (const CubicTileParams p
   __syncthreads ();
   if (p.nh && p.nv) {
     if (p.vfirst) {                                                    // tmp[ty][rx] = vertical taps over the region's columns
-      for (int i = tid; i < th * rw; i += 256) {
+      for (int i = tid; i < th * rw; i += THREADS) {
         const int ty = i / rw, rx = i - ty * rw;
         const int2 *t = ltv + ty * p.nv;
         Acc4 a = { 0.0f, 0.0f, 0.0f, 0.0f };
@@ -182,7 +183,7 @@ __global__ __launch_bounds__ (256) void k_cs_cubic_tile (const CubicTileParams p
         tmp[ty * rw + rx] = ntap_finish (a);
       }
     } else {                                                           // tmp[ry][tx] = horizontal taps over the region's rows
-      for (int i = tid; i < rh * tw; i += 256) {
+      for (int i = tid; i < rh * tw; i += THREADS) {
         const int ry = i / tw, tx = i - ry * tw;
         const int2 *t = lth + tx * p.nh;
         Acc4 a = { 0.0f, 0.0f, 0.0f, 0.0f };
@@ -192,7 +193,7 @@ __global__ __launch_bounds__ (256) void k_cs_cubic_tile (const CubicTileParams p
     }
     __syncthreads ();
   }
-  for (int i = tid; i < th * tw; i += 256) {
+  for (int i = tid; i < th * tw; i += THREADS) {
     const int ty = i / tw, tx = i - ty * tw;
     Acc4 a = { 0.0f, 0.0f, 0.0f, 0.0f };
     uint32_t q;
