@@ -319,3 +319,20 @@ def test_pixel_parity_packed_inputs_with_cpu_elements(tmp_path, fmt):
     assert r.returncode == 0, r.stderr
     x, y = np.fromfile(a, np.uint8), np.fromfile(b, np.uint8)
     assert x.size == y.size == 2 * 640 * 480 * 4 and np.array_equal(x, y)
+
+
+def test_no_per_frame_leak_in_the_element_shells():
+    """peak RSS of a 4-element pipeline (async convertscale, device buffers in between, overlay-less) does not grow with the
+    number of frames: maps, buffer refs, pending frames and registrations are all released per frame"""
+    import resource
+
+    def peak_kb(n):
+        """peak RSS over all children waited for so far (a running maximum: the short run goes first)"""
+        cmd = (f"videotestsrc num-buffers={n} ! {caps('NV12', 640, 360)} ! identity drop-allocation=true ! vfhipdeinterlace method=greedyh ! "
+               f"vfhipconvertscale async-depth=1 ! {caps('BGRA', 320, 180)} ! vfhipvideofilter brightness=0.1 ! vfhiptransform method=vertical-flip ! fakesink")
+        r = gst_env.launch(cmd, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        return resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
+
+    a, b = peak_kb(150), peak_kb(1500)
+    assert b < a * 1.08 + 20000, f"peak RSS grew from {a} kB (150 frames) to {b} kB (1500 frames)"
