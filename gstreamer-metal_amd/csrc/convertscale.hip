@@ -57,9 +57,7 @@ struct VfHipConvertScale {
   int2 *d_nt_h = nullptr, *d_nt_v = nullptr; int nt_h = 0, nt_v = 0;
   void *nt_mid0 = nullptr, *nt_mid1 = nullptr;
   bool nt_tile = false;             // every tile's source region fits k_cs_cubic_tile's LDS arrays
-  // pipelined host path (submit / wait): up to two frames in flight, flight k uses staging slots 2k (in) and 2k+1 (out)
-  struct Flight { VfHipFrame out; bool staged[VFHIP_MAX_PLANES]; } flight[2];
-  int fl_head = 0, fl_count = 0;
+  Flights fl;                       // pipelined host path (submit / wait)
 };
 
 static void free_tables (VfHipConvertScale *h)
@@ -277,7 +275,7 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
 {
   if (!h || !in || !out) return set_error (VFHIP_ERR_INVALID, "null argument");
   std::lock_guard<std::mutex> lk (h->mu);
-  if (h->fl_count) return set_error (VFHIP_ERR_INVALID, "configure with %d submitted frame(s) still in flight: wait for them first", h->fl_count);
+  if (h->fl.count) return set_error (VFHIP_ERR_INVALID, "configure with %d submitted frame(s) still in flight: wait for them first", h->fl.count);
   if (in->width <= 0 || in->height <= 0 || out->width <= 0 || out->height <= 0 || in->width > 32768 || in->height > 32768 ||
       out->width > 32768 || out->height > 32768)
     return set_error (VFHIP_ERR_INVALID, "bad frame size %dx%d -> %dx%d", in->width, in->height, out->width, out->height);
@@ -641,39 +639,24 @@ int vfhip_convertscale_submit (VfHipConvertScale *h, const VfHipFrame *in, VfHip
   int rc = validate_frames (h, in, out);
   if (rc) return rc;
   std::lock_guard<std::mutex> lk (h->mu);
-  if (h->fl_count >= 2) return set_error (VFHIP_ERR_INVALID, "two frames are already in flight: call vfhip_convertscale_wait first");
   VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
-  const int k = (h->fl_head + h->fl_count) & 1;
-  VfHipFrame din, dout;
-  // pageable planes are copied into the pinned staging slot here (CPU work that overlaps the previous frame's GPU work);
-  // pinned planes are DMA'd in place and must stay valid until the frame's wait() returns
-  if ((rc = upload_frame (h->st, (size_t) 2 * k, in, &din))) return rc;
-  if ((rc = output_frame (h->st, (size_t) 2 * k + 1, &h->out, out, &dout))) return rc;
-  VFHIP_CHECK_HIP (hipStreamWaitEvent (h->st.s_compute, h->st.ev_h2d, 0));
-  if ((rc = launch_device (h, &din, &dout, 0, 0, 1, h->st.s_compute))) return rc;
-  VFHIP_CHECK_HIP (hipEventRecord (h->st.ev_compute, h->st.s_compute));
-  h->flight[k].out = *out;
-  if ((rc = download_begin (h->st, (size_t) 2 * k + 1, &h->flight[k].out, h->flight[k].staged, h->st.ev_done[k]))) return rc;
-  h->fl_count++;
-  return VFHIP_OK;
+  return flights_submit (h->st, h->fl, &h->out, in, out,
+      [h] (const VfHipFrame *di, VfHipFrame *dout, hipStream_t s) { return launch_device (h, di, dout, 0, 0, 1, s); });
 }
 
 int vfhip_convertscale_wait (VfHipConvertScale *h)
 {
   if (!h) return set_error (VFHIP_ERR_INVALID, "null handle");
   std::lock_guard<std::mutex> lk (h->mu);
-  if (h->fl_count == 0) return set_error (VFHIP_ERR_INVALID, "no frame in flight");
   VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
-  const int k = h->fl_head;
-  h->fl_head ^= 1; h->fl_count--;
-  return download_finish (h->st, (size_t) 2 * k + 1, &h->flight[k].out, h->flight[k].staged, h->st.ev_done[k]);
+  return flights_wait (h->st, h->fl);
 }
 
 int vfhip_convertscale_in_flight (VfHipConvertScale *h)
 {
   if (!h) return 0;
   std::lock_guard<std::mutex> lk (h->mu);
-  return h->fl_count;
+  return h->fl.count;
 }
 
 int vfhip_convertscale_process (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame *out)
@@ -681,7 +664,7 @@ int vfhip_convertscale_process (VfHipConvertScale *h, const VfHipFrame *in, VfHi
   int rc = validate_frames (h, in, out);
   if (rc) return rc;
   std::lock_guard<std::mutex> lk (h->mu);
-  if (h->fl_count) return set_error (VFHIP_ERR_INVALID, "frames submitted with vfhip_convertscale_submit are still in flight");
+  if (h->fl.count) return set_error (VFHIP_ERR_INVALID, "frames submitted with vfhip_convertscale_submit are still in flight");
   VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
   VfHipFrame din, dout;
   if ((rc = upload_frame (h->st, 0, in, &din))) return rc;                 // pinned staging + async H2D on the h2d stream
@@ -697,10 +680,7 @@ void vfhip_convertscale_cleanup (VfHipConvertScale *h)
   if (!h) return;
   std::lock_guard<std::mutex> lk (h->mu);
   (void) hipSetDevice (h->dev->ordinal);
-  if (h->fl_count) {                       // abandoned frames: let the GPU finish with the staging buffers before they go
-    (void) hipStreamSynchronize (h->st.s_h2d); (void) hipStreamSynchronize (h->st.s_compute); (void) hipStreamSynchronize (h->st.s_d2h);
-    h->fl_count = 0; h->fl_head = 0;
-  }
+  flights_abandon (h->st, h->fl);
   free_tables (h);
   for (auto &b : h->st.slots) {
     if (b.host) (void) hipHostFree (b.host);

@@ -55,6 +55,7 @@ struct VfHipOverlay {
   Staging st;
   bool configured = false;
   VfHipVideoInfo in {}, out {};
+  Flights fl;                       // pipelined host path (submit / wait)
   uint8_t *d_img = nullptr;        // RGBA8, tight rows
   int img_w = 0, img_h = 0;
 };
@@ -112,6 +113,7 @@ int vfhip_overlay_configure (VfHipOverlay *h, const VfHipVideoInfo *in, const Vf
 {
   if (!h || !in || !out) return set_error (VFHIP_ERR_INVALID, "null argument");
   std::lock_guard<std::mutex> lk (h->mu);
+  if (h->fl.count) return set_error (VFHIP_ERR_INVALID, "configure with %d submitted frame(s) still in flight: wait for them first", h->fl.count);
   if (in->width <= 0 || in->height <= 0 || in->width > 32768 || in->height > 32768 || in->width != out->width || in->height != out->height)
     return set_error (VFHIP_ERR_INVALID, "overlay: bad or differing frame sizes");
   if (in->format < VFHIP_FORMAT_BGRA || in->format > VFHIP_FORMAT_I420 || out->format < VFHIP_FORMAT_BGRA || out->format > VFHIP_FORMAT_I420)
@@ -174,6 +176,7 @@ int vfhip_overlay_process (VfHipOverlay *h, const VfHipFrame *in, VfHipFrame *ou
   int rc = ov_check (h, in, out, prm);
   if (rc) return rc;
   std::lock_guard<std::mutex> lk (h->mu);
+  if (h->fl.count) return set_error (VFHIP_ERR_INVALID, "frames submitted with vfhip_overlay_submit are still in flight");
   VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
   VfHipFrame din, dout;
   if ((rc = upload_frame (h->st, 0, in, &din))) return rc;
@@ -182,6 +185,32 @@ int vfhip_overlay_process (VfHipOverlay *h, const VfHipFrame *in, VfHipFrame *ou
   if ((rc = ov_launch (h, &din, &dout, prm, h->st.s_compute))) return rc;
   VFHIP_CHECK_HIP (hipEventRecord (h->st.ev_compute, h->st.s_compute));
   return download_frame (h->st, 1, &dout, out);
+}
+
+int vfhip_overlay_submit (VfHipOverlay *h, const VfHipFrame *in, VfHipFrame *out, const VfHipOverlayParams *prm)
+{
+  int rc = ov_check (h, in, out, prm);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk (h->mu);
+  VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
+  const VfHipOverlayParams p = *prm;
+  return flights_submit (h->st, h->fl, &h->out, in, out,
+      [h, &p] (const VfHipFrame *di, VfHipFrame *dout, hipStream_t s) { return ov_launch (h, di, dout, &p, s); });
+}
+
+int vfhip_overlay_wait (VfHipOverlay *h)
+{
+  if (!h) return set_error (VFHIP_ERR_INVALID, "null handle");
+  std::lock_guard<std::mutex> lk (h->mu);
+  VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
+  return flights_wait (h->st, h->fl);
+}
+
+int vfhip_overlay_in_flight (VfHipOverlay *h)
+{
+  if (!h) return 0;
+  std::lock_guard<std::mutex> lk (h->mu);
+  return h->fl.count;
 }
 
 int vfhip_overlay_process_device_batch (VfHipOverlay *h, const VfHipFrame *in0, VfHipFrame *out0, size_t in_frame_pitch, size_t out_frame_pitch,
@@ -205,6 +234,7 @@ void vfhip_overlay_cleanup (VfHipOverlay *h)
   if (!h) return;
   std::lock_guard<std::mutex> lk (h->mu);
   (void) hipSetDevice (h->dev->ordinal);
+  flights_abandon (h->st, h->fl);
   for (auto &b : h->st.slots) { if (b.host) (void) hipHostFree (b.host); if (b.devp) (void) hipFree (b.devp); }
   h->st.slots.clear ();
   h->configured = false;               // the image survives, like the reference's texture (cleanup drops frame resources only)

@@ -47,6 +47,7 @@ struct VfHipTransform {
   Staging st;
   bool configured = false;
   VfHipVideoInfo in {}, out {};
+  Flights fl;                       // pipelined host path (submit / wait)
 };
 
 // UV matrix of the eight methods, column-major [m00 m10 m01 m11]
@@ -103,6 +104,7 @@ int vfhip_transform_configure (VfHipTransform *h, const VfHipVideoInfo *in, cons
 {
   if (!h || !in || !out) return set_error (VFHIP_ERR_INVALID, "null argument");
   std::lock_guard<std::mutex> lk (h->mu);
+  if (h->fl.count) return set_error (VFHIP_ERR_INVALID, "configure with %d submitted frame(s) still in flight: wait for them first", h->fl.count);
   if (in->width <= 0 || in->height <= 0 || in->width > 32768 || in->height > 32768 || out->width <= 0 || out->height <= 0 ||
       out->width > 32768 || out->height > 32768)
     return set_error (VFHIP_ERR_INVALID, "bad frame size");
@@ -117,6 +119,7 @@ int vfhip_transform_process (VfHipTransform *h, const VfHipFrame *in, VfHipFrame
   int rc = tr_check (h, in, out, prm);
   if (rc) return rc;
   std::lock_guard<std::mutex> lk (h->mu);
+  if (h->fl.count) return set_error (VFHIP_ERR_INVALID, "frames submitted with vfhip_transform_submit are still in flight");
   VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
   VfHipFrame din, dout;
   if ((rc = upload_frame (h->st, 0, in, &din))) return rc;
@@ -136,6 +139,32 @@ int vfhip_transform_process_device (VfHipTransform *h, const VfHipFrame *in, VfH
   return tr_launch (h, in, out, prm, stream ? (hipStream_t) stream : h->st.s_compute);
 }
 
+int vfhip_transform_submit (VfHipTransform *h, const VfHipFrame *in, VfHipFrame *out, const VfHipTransformParams *prm)
+{
+  int rc = tr_check (h, in, out, prm);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk (h->mu);
+  VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
+  const VfHipTransformParams p = *prm;
+  return flights_submit (h->st, h->fl, &h->out, in, out,
+      [h, &p] (const VfHipFrame *di, VfHipFrame *dout, hipStream_t s) { return tr_launch (h, di, dout, &p, s); });
+}
+
+int vfhip_transform_wait (VfHipTransform *h)
+{
+  if (!h) return set_error (VFHIP_ERR_INVALID, "null handle");
+  std::lock_guard<std::mutex> lk (h->mu);
+  VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
+  return flights_wait (h->st, h->fl);
+}
+
+int vfhip_transform_in_flight (VfHipTransform *h)
+{
+  if (!h) return 0;
+  std::lock_guard<std::mutex> lk (h->mu);
+  return h->fl.count;
+}
+
 int vfhip_transform_process_device_batch (VfHipTransform *h, const VfHipFrame *in0, VfHipFrame *out0,
     size_t in_frame_pitch, size_t out_frame_pitch, int n_frames, const VfHipTransformParams *prm, void *stream)
 {
@@ -152,6 +181,7 @@ void vfhip_transform_cleanup (VfHipTransform *h)
   if (!h) return;
   std::lock_guard<std::mutex> lk (h->mu);
   (void) hipSetDevice (h->dev->ordinal);
+  flights_abandon (h->st, h->fl);
   for (auto &b : h->st.slots) { if (b.host) (void) hipHostFree (b.host); if (b.devp) (void) hipFree (b.devp); }
   h->st.slots.clear ();
   h->configured = false;

@@ -67,6 +67,51 @@ int download_frame (Staging &st, size_t slot, const VfHipFrame *dev_frame, VfHip
 int download_begin (Staging &st, size_t slot, VfHipFrame *host, bool staged[VFHIP_MAX_PLANES], hipEvent_t done);
 int download_finish (Staging &st, size_t slot, VfHipFrame *host, const bool staged[VFHIP_MAX_PLANES], hipEvent_t done);
 
+// ---- pipelined host path shared by the renderers' _submit / _wait entry points -----------------------------------------
+// Up to two frames in flight per handle; flight k uses staging slots 2k (input image) and 2k + 1 (output image).  submit
+// enqueues upload -> kernel(s) -> download on the handle's three streams and returns; wait blocks until the OLDEST frame's
+// output is complete (and moves staged planes of a pageable destination into the caller's frame).
+struct Flights {
+  struct F { VfHipFrame out; bool staged[VFHIP_MAX_PLANES]; } f[2];
+  int head = 0, count = 0;
+};
+
+template <class Launch>                     // Launch: int (const VfHipFrame *dev_in, VfHipFrame *dev_out, hipStream_t)
+static inline int flights_submit (Staging &st, Flights &fl, const VfHipVideoInfo *out_info, const VfHipFrame *in, VfHipFrame *out, Launch launch)
+{
+  if (fl.count >= 2) return set_error (VFHIP_ERR_INVALID, "two frames are already in flight: call the handle's _wait first");
+  const int k = (fl.head + fl.count) & 1;
+  VfHipFrame din, dout;
+  int rc;
+  // pageable planes are copied into the pinned staging slot here (CPU work that overlaps the previous frame's GPU work);
+  // pinned planes are DMA'd in place and must stay valid until the frame's wait returns
+  if ((rc = upload_frame (st, (size_t) 2 * k, in, &din))) return rc;
+  if ((rc = output_frame (st, (size_t) 2 * k + 1, out_info, out, &dout))) return rc;
+  VFHIP_CHECK_HIP (hipStreamWaitEvent (st.s_compute, st.ev_h2d, 0));
+  if ((rc = launch (&din, &dout, st.s_compute))) return rc;
+  VFHIP_CHECK_HIP (hipEventRecord (st.ev_compute, st.s_compute));
+  fl.f[k].out = *out;
+  if ((rc = download_begin (st, (size_t) 2 * k + 1, &fl.f[k].out, fl.f[k].staged, st.ev_done[k]))) return rc;
+  fl.count++;
+  return VFHIP_OK;
+}
+
+static inline int flights_wait (Staging &st, Flights &fl)
+{
+  if (fl.count == 0) return set_error (VFHIP_ERR_INVALID, "no frame in flight");
+  const int k = fl.head;
+  fl.head ^= 1; fl.count--;
+  return download_finish (st, (size_t) 2 * k + 1, &fl.f[k].out, fl.f[k].staged, st.ev_done[k]);
+}
+
+// abandoned frames (cleanup with a non-empty pipeline): let the GPU finish with the staging buffers before they go
+static inline void flights_abandon (Staging &st, Flights &fl)
+{
+  if (!fl.count) return;
+  (void) hipStreamSynchronize (st.s_h2d); (void) hipStreamSynchronize (st.s_compute); (void) hipStreamSynchronize (st.s_d2h);
+  fl.count = 0; fl.head = 0;
+}
+
 }  // namespace vfhip
 
 namespace vfhip {

@@ -285,6 +285,7 @@ struct VfHipVideoFilter {
   VfHipVideoInfo in {}, out {};
   float4 *d_lut = nullptr;
   int lut_size = 0;
+  Flights fl;                       // pipelined host path (submit / wait)
 };
 
 static int vf_launch (VfHipVideoFilter *h, const VfHipFrame *in, VfHipFrame *out, const VfHipVideoFilterParams *prm, hipStream_t s,
@@ -352,6 +353,7 @@ int vfhip_videofilter_configure (VfHipVideoFilter *h, const VfHipVideoInfo *in, 
 {
   if (!h || !in || !out) return set_error (VFHIP_ERR_INVALID, "null argument");
   std::lock_guard<std::mutex> lk (h->mu);
+  if (h->fl.count) return set_error (VFHIP_ERR_INVALID, "configure with %d submitted frame(s) still in flight: wait for them first", h->fl.count);
   if (in->width <= 0 || in->height <= 0 || in->width > 32768 || in->height > 32768)
     return set_error (VFHIP_ERR_INVALID, "bad frame size %dx%d", in->width, in->height);
   if (in->width != out->width || in->height != out->height)
@@ -368,6 +370,7 @@ int vfhip_videofilter_process (VfHipVideoFilter *h, const VfHipFrame *in, VfHipF
   int rc = vf_check (h, in, out, prm);
   if (rc) return rc;
   std::lock_guard<std::mutex> lk (h->mu);
+  if (h->fl.count) return set_error (VFHIP_ERR_INVALID, "frames submitted with vfhip_videofilter_submit are still in flight");
   VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
   VfHipFrame din, dout;
   if ((rc = upload_frame (h->st, 0, in, &din))) return rc;
@@ -376,6 +379,32 @@ int vfhip_videofilter_process (VfHipVideoFilter *h, const VfHipFrame *in, VfHipF
   if ((rc = vf_launch (h, &din, &dout, prm, h->st.s_compute))) return rc;
   VFHIP_CHECK_HIP (hipEventRecord (h->st.ev_compute, h->st.s_compute));
   return download_frame (h->st, 1, &dout, out);
+}
+
+int vfhip_videofilter_submit (VfHipVideoFilter *h, const VfHipFrame *in, VfHipFrame *out, const VfHipVideoFilterParams *prm)
+{
+  int rc = vf_check (h, in, out, prm);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk (h->mu);
+  VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
+  const VfHipVideoFilterParams p = *prm;              // the launch takes the parameters by value: nothing of `prm` is kept
+  return flights_submit (h->st, h->fl, &h->out, in, out,
+      [h, &p] (const VfHipFrame *di, VfHipFrame *dout, hipStream_t s) { return vf_launch (h, di, dout, &p, s); });
+}
+
+int vfhip_videofilter_wait (VfHipVideoFilter *h)
+{
+  if (!h) return set_error (VFHIP_ERR_INVALID, "null handle");
+  std::lock_guard<std::mutex> lk (h->mu);
+  VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
+  return flights_wait (h->st, h->fl);
+}
+
+int vfhip_videofilter_in_flight (VfHipVideoFilter *h)
+{
+  if (!h) return 0;
+  std::lock_guard<std::mutex> lk (h->mu);
+  return h->fl.count;
 }
 
 int vfhip_videofilter_process_device (VfHipVideoFilter *h, const VfHipFrame *in, VfHipFrame *out,
@@ -493,6 +522,7 @@ void vfhip_videofilter_cleanup (VfHipVideoFilter *h)
   if (!h) return;
   std::lock_guard<std::mutex> lk (h->mu);
   (void) hipSetDevice (h->dev->ordinal);
+  flights_abandon (h->st, h->fl);
   for (auto &b : h->st.slots) { if (b.host) (void) hipHostFree (b.host); if (b.devp) (void) hipFree (b.devp); }
   h->st.slots.clear ();
   h->configured = false;              // the LUT survives cleanup like the reference's _lutTexture (a property, not a caps resource)

@@ -35,6 +35,24 @@ gboolean gst_vfhip_decide_allocation (struct _GstBaseTransform * trans, GstQuery
 typedef struct { guint registered, reused; gboolean disabled; } GstVfHipPinStats;
 void gst_vfhip_pin_foreign_memory (GstBuffer * buf, GstVfHipPinStats * stats);
 
+/* async-depth=1: one frame in flight across buffers (gstvfhipasync.c) */
+typedef struct
+{
+  gint depth;                                   /* the async-depth property */
+  int (*submit) (struct _GstBaseTransform * trans, const VfHipFrame * in, VfHipFrame * out);   /* libvfhip _submit with the element's parameters */
+  int (*wait) (struct _GstBaseTransform * trans);                                              /* libvfhip _wait */
+  struct { GstBuffer *inbuf, *outbuf; GstVideoFrame in, out; } pending[2];
+  guint n, head;
+  GstVfHipPinStats pin;
+} GstVfHipAsync;
+GstFlowReturn gst_vfhip_async_drain (struct _GstBaseTransform * trans, GstVfHipAsync * a, gboolean push);
+GstFlowReturn gst_vfhip_async_generate_output (struct _GstBaseTransform * trans, GstBuffer ** outbuf, GstVfHipAsync * a, const GstVideoInfo * in_info,
+    const GstVideoInfo * out_info, gboolean ready, GstFlowReturn (*parent) (struct _GstBaseTransform *, GstBuffer **));
+gboolean gst_vfhip_async_sink_event (struct _GstBaseTransform * trans, GstEvent * event, GstVfHipAsync * a, gboolean (*parent) (struct _GstBaseTransform *, GstEvent *));
+gboolean gst_vfhip_async_query (struct _GstBaseTransform * trans, GstPadDirection direction, GstQuery * query, GstVfHipAsync * a, const GstVideoInfo * out_info,
+    gboolean (*parent) (struct _GstBaseTransform *, GstPadDirection, GstQuery *));
+GParamSpec *gst_vfhip_async_depth_pspec (void);
+
 /* device-resident buffers: caps feature memory:HIPMemory (gstvfhipmemory.c) */
 #define GST_CAPS_FEATURE_MEMORY_HIP "memory:HIPMemory"
 #define GST_MAP_VFHIP ((GstMapFlags) (GST_MAP_FLAG_LAST << 3))     /* map a device GstMemory to its DEVICE pointer */

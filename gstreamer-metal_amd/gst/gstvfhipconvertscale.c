@@ -30,14 +30,8 @@ typedef struct
   guint border_color;
   /* async-depth=1: one frame stays in flight across chain calls (cs_generate_output) */
   GstVfHipPinStats pin;
-  gint async_depth;
+  GstVfHipAsync async;                          /* async-depth=1: one frame stays in flight across chain calls */
   gboolean reconfigure_pending;
-  struct
-  {
-    GstBuffer *inbuf, *outbuf;
-    GstVideoFrame in, out;
-  } pending[2];
-  guint n_pending, pending_head;
 } GstVfHipConvertScale;
 
 typedef struct
@@ -261,160 +255,53 @@ cs_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
   return GST_FLOW_OK;
 }
 
-/* ---- async-depth=1: pipelined frames ---------------------------------------------------------
- * The reference's processFrame is synchronous: upload, render, read back, return — the GPU idles while the CPU copies and
- * vice versa.  With async-depth=1 the element keeps one frame in flight: chain(n) submits frame n
- * (libvfhip's submit / wait: upload, kernel and download queued on three streams) and pushes frame n-1, so frame n's
- * upload overlaps frame n-1's kernel and download.  Cost: one frame of latency (reported in the latency query); frames
- * still leave in order, and EOS / new caps / a segment / flush / state changes drain the pipeline first. */
-static GstBuffer *
-cs_finish_oldest (GstVfHipConvertScale * self)
+/* ---- async-depth=1 (gstvfhipasync.c) -------------------------------------------------------------------------------- */
+static int
+cs_async_submit (GstBaseTransform * trans, const VfHipFrame * in, VfHipFrame * out)
 {
-  const guint k = self->pending_head;
-  GstBuffer *out = self->pending[k].outbuf;
-  const int rc = vfhip_convertscale_wait (self->renderer);
-  gst_video_frame_unmap (&self->pending[k].out);
-  gst_video_frame_unmap (&self->pending[k].in);
-  gst_buffer_unref (self->pending[k].inbuf);
-  self->pending[k].inbuf = self->pending[k].outbuf = NULL;
-  self->pending_head ^= 1;
-  self->n_pending--;
-  if (rc != VFHIP_OK) {
-    GST_WARNING_OBJECT (self, "HIP processing failed: %s", vfhip_last_error_string ());
-    gst_buffer_unref (out);
-    return NULL;
-  }
-  return out;
+  return vfhip_convertscale_submit (CS (trans)->renderer, in, out);
 }
 
-/* streaming thread only */
-static GstFlowReturn
-cs_drain (GstVfHipConvertScale * self, gboolean push)
+static int
+cs_async_wait (GstBaseTransform * trans)
 {
-  GstFlowReturn ret = GST_FLOW_OK;
-  while (self->n_pending > 0) {
-    GstBuffer *out = cs_finish_oldest (self);
-    if (!out)
-      ret = GST_FLOW_ERROR;
-    else if (push && ret == GST_FLOW_OK)
-      ret = gst_pad_push (GST_BASE_TRANSFORM_SRC_PAD (self), out);
-    else
-      gst_buffer_unref (out);
-  }
-  return ret;
+  return vfhip_convertscale_wait (CS (trans)->renderer);
 }
 
 static GstFlowReturn
 cs_generate_output (GstBaseTransform * trans, GstBuffer ** outbuf)
 {
   GstVfHipConvertScale *self = CS (trans);
-  GstBaseTransformClass *bclass = GST_BASE_TRANSFORM_GET_CLASS (trans);
-  GstBuffer *inbuf, *out = NULL;
-  GstFlowReturn ret;
-  VfHipFrame vin, vout;
-  guint k;
-  gint dev;
   gboolean reconf;
-  if (self->async_depth < 1 || self->passthrough) {
-    if (self->n_pending && (ret = cs_drain (self, TRUE)) != GST_FLOW_OK)
-      return ret;
-    return GST_BASE_TRANSFORM_CLASS (gst_vfhip_convertscale_parent_class)->generate_output (trans, outbuf);
-  }
-  *outbuf = NULL;
-  inbuf = trans->queued_buf;
-  trans->queued_buf = NULL;
-  if (!inbuf)
-    return GST_FLOW_OK;                                       /* second call of the chain loop: nothing more this time */
-  if (!self->negotiated || !self->renderer) {
-    gst_buffer_unref (inbuf);
-    return self->negotiated ? GST_FLOW_ERROR : GST_FLOW_NOT_NEGOTIATED;
-  }
   GST_OBJECT_LOCK (self);
   reconf = self->reconfigure_pending;
   self->reconfigure_pending = FALSE;
   GST_OBJECT_UNLOCK (self);
   if (reconf) {                                               /* a property changed: the renderer reconfigures on an empty pipeline */
-    if ((ret = cs_drain (self, TRUE)) != GST_FLOW_OK) {
-      gst_buffer_unref (inbuf);
+    GstFlowReturn ret = gst_vfhip_async_drain (trans, &self->async, TRUE);
+    if (ret != GST_FLOW_OK)
       return ret;
-    }
     GST_OBJECT_LOCK (self);
-    cs_configure_locked (self);
+    if (self->negotiated && self->renderer && !self->passthrough)
+      cs_configure_locked (self);
     GST_OBJECT_UNLOCK (self);
   }
-  if ((ret = bclass->prepare_output_buffer (trans, inbuf, &out)) != GST_FLOW_OK || !out) {
-    gst_buffer_unref (inbuf);
-    return ret != GST_FLOW_OK ? ret : GST_FLOW_ERROR;
-  }
-  k = (self->pending_head + self->n_pending) & 1;
-  gst_vfhip_pin_foreign_memory (inbuf, &self->pin);
-  dev = gst_vfhip_element_device (self);
-  if (!gst_video_frame_map (&self->pending[k].in, &self->in_info, inbuf, (GstMapFlags) (GST_MAP_READ | gst_vfhip_map_flag (inbuf, dev)))) {
-    gst_buffer_unref (inbuf); gst_buffer_unref (out);
-    return GST_FLOW_ERROR;
-  }
-  if (!gst_video_frame_map (&self->pending[k].out, &self->out_info, out, (GstMapFlags) (GST_MAP_WRITE | gst_vfhip_map_flag (out, dev)))) {
-    gst_video_frame_unmap (&self->pending[k].in);
-    gst_buffer_unref (inbuf); gst_buffer_unref (out);
-    return GST_FLOW_ERROR;
-  }
-  gst_vfhip_frame (&self->pending[k].in, &vin);
-  gst_vfhip_frame (&self->pending[k].out, &vout);
-  if (vfhip_convertscale_submit (self->renderer, &vin, &vout) != VFHIP_OK) {
-    GST_WARNING_OBJECT (self, "HIP submit failed: %s", vfhip_last_error_string ());
-    gst_video_frame_unmap (&self->pending[k].out);
-    gst_video_frame_unmap (&self->pending[k].in);
-    gst_buffer_unref (inbuf); gst_buffer_unref (out);
-    return GST_FLOW_ERROR;
-  }
-  self->pending[k].inbuf = inbuf;
-  self->pending[k].outbuf = out;
-  self->n_pending++;
-  if (self->n_pending == 2) {                                 /* frame n is on its way: hand out frame n-1 */
-    *outbuf = cs_finish_oldest (self);
-    if (!*outbuf)
-      return GST_FLOW_ERROR;
-  }
-  return GST_FLOW_OK;
+  return gst_vfhip_async_generate_output (trans, outbuf, &self->async, &self->in_info, &self->out_info, self->negotiated && self->renderer != NULL,
+      GST_BASE_TRANSFORM_CLASS (gst_vfhip_convertscale_parent_class)->generate_output);
 }
 
 static gboolean
 cs_sink_event (GstBaseTransform * trans, GstEvent * event)
 {
-  GstVfHipConvertScale *self = CS (trans);
-  switch (GST_EVENT_TYPE (event)) {
-    case GST_EVENT_EOS:
-    case GST_EVENT_CAPS:
-    case GST_EVENT_SEGMENT:
-    case GST_EVENT_GAP:
-      cs_drain (self, TRUE);                                  /* serialized events travel behind every frame before them */
-      break;
-    case GST_EVENT_FLUSH_STOP:
-      cs_drain (self, FALSE);
-      break;
-    default:
-      break;
-  }
-  return GST_BASE_TRANSFORM_CLASS (gst_vfhip_convertscale_parent_class)->sink_event (trans, event);
+  return gst_vfhip_async_sink_event (trans, event, &CS (trans)->async, GST_BASE_TRANSFORM_CLASS (gst_vfhip_convertscale_parent_class)->sink_event);
 }
 
 static gboolean
 cs_query (GstBaseTransform * trans, GstPadDirection direction, GstQuery * query)
 {
   GstVfHipConvertScale *self = CS (trans);
-  gboolean ok = GST_BASE_TRANSFORM_CLASS (gst_vfhip_convertscale_parent_class)->query (trans, direction, query);
-  if (ok && GST_QUERY_TYPE (query) == GST_QUERY_LATENCY && direction == GST_PAD_SRC && self->async_depth > 0 && self->negotiated &&
-      GST_VIDEO_INFO_FPS_N (&self->out_info) > 0) {
-    gboolean live;
-    GstClockTime min, max;
-    const GstClockTime frame = gst_util_uint64_scale (GST_SECOND, GST_VIDEO_INFO_FPS_D (&self->out_info), GST_VIDEO_INFO_FPS_N (&self->out_info));
-    gst_query_parse_latency (query, &live, &min, &max);
-    min += frame;
-    if (GST_CLOCK_TIME_IS_VALID (max))
-      max += frame;
-    gst_query_set_latency (query, live, min, max);
-  }
-  return ok;
+  return gst_vfhip_async_query (trans, direction, query, &self->async, self->negotiated ? &self->out_info : NULL,
+      GST_BASE_TRANSFORM_CLASS (gst_vfhip_convertscale_parent_class)->query);
 }
 
 static void
@@ -428,14 +315,14 @@ cs_set_property (GObject * object, guint id, const GValue * value, GParamSpec * 
     case PROP_BORDER_COLOR: self->border_color = g_value_get_uint (value); break;
     case PROP_NUMERICS: self->numerics = g_value_get_enum (value); break;
     case PROP_DEVICE_ID: self->device_id = g_value_get_int (value); break;      /* takes effect for the next renderer */
-    case PROP_ASYNC_DEPTH: self->async_depth = g_value_get_int (value); break;
+    case PROP_ASYNC_DEPTH: self->async.depth = g_value_get_int (value); break;
     default:
       GST_OBJECT_UNLOCK (self);
       G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec);
       return;
   }
   if (id != PROP_DEVICE_ID && id != PROP_ASYNC_DEPTH && self->negotiated && self->renderer && !self->passthrough) {
-    if (self->async_depth > 0)
+    if (self->async.depth > 0)
       self->reconfigure_pending = TRUE;         /* frames may be in flight: the streaming thread reconfigures (cs_generate_output) */
     else
       cs_configure_locked (self);
@@ -453,7 +340,7 @@ cs_get_property (GObject * object, guint id, GValue * value, GParamSpec * pspec)
     case PROP_BORDER_COLOR: g_value_set_uint (value, self->border_color); break;
     case PROP_NUMERICS: g_value_set_enum (value, self->numerics); break;
     case PROP_DEVICE_ID: g_value_set_int (value, self->device_id); break;
-    case PROP_ASYNC_DEPTH: g_value_set_int (value, self->async_depth); break;
+    case PROP_ASYNC_DEPTH: g_value_set_int (value, self->async.depth); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
   }
 }
@@ -464,7 +351,7 @@ cs_change_state (GstElement * element, GstStateChange transition)
   GstVfHipConvertScale *self = CS (element);
   GstStateChangeReturn ret = GST_ELEMENT_CLASS (gst_vfhip_convertscale_parent_class)->change_state (element, transition);
   if (transition == GST_STATE_CHANGE_PAUSED_TO_READY) {     /* drop GPU resources, keep the handle */
-    cs_drain (self, FALSE);                                 /* the streaming thread has stopped: frames still in flight are dropped */
+    gst_vfhip_async_drain (GST_BASE_TRANSFORM (self), &self->async, FALSE);      /* the streaming thread has stopped: frames still in flight are dropped */
     GST_OBJECT_LOCK (self);
     if (self->renderer)
       vfhip_convertscale_cleanup (self->renderer);
@@ -533,9 +420,7 @@ gst_vfhip_convertscale_class_init (GstVfHipConvertScaleClass * klass)
           "Arithmetic family: bit-exact GStreamer CPU videoconvert+videoscale, or the vfmetal shaders' float maths",
           gst_vfhip_numerics_get_type (), VFHIP_NUMERICS_GST_EXACT, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
 
-  g_object_class_install_property (oc, PROP_ASYNC_DEPTH, g_param_spec_int ("async-depth", "Async depth",
-          "Frames kept in flight across buffers: 0 = synchronous like the reference, 1 = the upload of frame n overlaps the kernel and "
-          "download of frame n-1 (adds one frame of latency)", 0, 1, 0, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_ASYNC_DEPTH, gst_vfhip_async_depth_pspec ());
 
   gst_element_class_add_static_pad_template (ec, &cs_sink_template);
   gst_element_class_add_static_pad_template (ec, &cs_src_template);
@@ -551,7 +436,9 @@ gst_vfhip_convertscale_init (GstVfHipConvertScale * self)
   self->border_color = 0xFF000000u;
   self->numerics = VFHIP_NUMERICS_GST_EXACT;
   self->device_id = GST_VFHIP_DEFAULT_DEVICE_ID;
-  self->async_depth = 0;
+  self->async.depth = 0;
+  self->async.submit = cs_async_submit;
+  self->async.wait = cs_async_wait;
   self->negotiated = FALSE;
   self->renderer = NULL;                 /* created on first negotiation so that device-id is honoured */
 }

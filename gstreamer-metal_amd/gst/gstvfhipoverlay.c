@@ -23,13 +23,14 @@ typedef struct
   gdouble alpha, relative_x, relative_y;
   gchar *location;
   gboolean image_loaded, image_dirty;
+  GstVfHipAsync async;                          /* async-depth=1 (gstvfhipasync.c) */
 } GstVfHipOverlay;
 typedef struct
 {
   GstVideoFilterClass parent_class;
 } GstVfHipOverlayClass;
 
-enum { PROP_0, PROP_LOCATION, PROP_X, PROP_Y, PROP_WIDTH, PROP_HEIGHT, PROP_ALPHA, PROP_RELATIVE_X, PROP_RELATIVE_Y, PROP_DEVICE_ID };
+enum { PROP_0, PROP_LOCATION, PROP_X, PROP_Y, PROP_WIDTH, PROP_HEIGHT, PROP_ALPHA, PROP_RELATIVE_X, PROP_RELATIVE_Y, PROP_DEVICE_ID, PROP_ASYNC_DEPTH };
 
 static GstStaticPadTemplate ov_sink_template = GST_STATIC_PAD_TEMPLATE ("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
     GST_STATIC_CAPS (GST_VFHIP_CAPS (VFHIP_OV_FORMATS)));
@@ -92,25 +93,31 @@ ov_set_info (GstVideoFilter * filter, GstCaps * incaps, GstVideoInfo * in_info, 
   return TRUE;
 }
 
+static void
+ov_params (GstVfHipOverlay * self, int frame_w, int frame_h, VfHipOverlayParams * p)
+{
+  gdouble rx, ry;
+  gint ax, ay;
+  GST_OBJECT_LOCK (self);                        /* one consistent snapshot per frame */
+  p->alpha = (float) self->alpha;
+  p->width = (float) self->width;
+  p->height = (float) self->height;
+  rx = self->relative_x; ry = self->relative_y;
+  ax = self->x; ay = self->y;
+  GST_OBJECT_UNLOCK (self);
+  p->x = rx >= 0.0 ? (float) (rx * frame_w) : (float) ax;      /* relative overrides absolute */
+  p->y = ry >= 0.0 ? (float) (ry * frame_h) : (float) ay;
+}
+
 static GstFlowReturn
 ov_transform_frame (GstVideoFilter * filter, GstVideoFrame * in, GstVideoFrame * out)
 {
   GstVfHipOverlay *self = OV (filter);
   VfHipOverlayParams p;
   VfHipFrame vin, vout;
-  gdouble rx, ry;
-  gint ax, ay;
   if (!self->renderer)
     return GST_FLOW_ERROR;
-  GST_OBJECT_LOCK (self);                        /* one consistent snapshot per frame */
-  p.alpha = (float) self->alpha;
-  p.width = (float) self->width;
-  p.height = (float) self->height;
-  rx = self->relative_x; ry = self->relative_y;
-  ax = self->x; ay = self->y;
-  GST_OBJECT_UNLOCK (self);
-  p.x = rx >= 0.0 ? (float) (rx * GST_VIDEO_FRAME_WIDTH (in)) : (float) ax;      /* relative overrides absolute */
-  p.y = ry >= 0.0 ? (float) (ry * GST_VIDEO_FRAME_HEIGHT (in)) : (float) ay;
+  ov_params (self, GST_VIDEO_FRAME_WIDTH (in), GST_VIDEO_FRAME_HEIGHT (in), &p);
   gst_vfhip_frame (in, &vin);
   gst_vfhip_frame (out, &vout);
   if (vfhip_overlay_process (self->renderer, &vin, &vout, &p) != VFHIP_OK) {
@@ -153,6 +160,7 @@ ov_set_property (GObject * object, guint id, const GValue * value, GParamSpec * 
     case PROP_RELATIVE_X: self->relative_x = g_value_get_double (value); break;
     case PROP_RELATIVE_Y: self->relative_y = g_value_get_double (value); break;
     case PROP_DEVICE_ID: self->device_id = g_value_get_int (value); break;
+    case PROP_ASYNC_DEPTH: self->async.depth = g_value_get_int (value); break;
     default:
       GST_OBJECT_UNLOCK (self);
       G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec);
@@ -176,6 +184,7 @@ ov_get_property (GObject * object, guint id, GValue * value, GParamSpec * pspec)
     case PROP_RELATIVE_X: g_value_set_double (value, self->relative_x); break;
     case PROP_RELATIVE_Y: g_value_set_double (value, self->relative_y); break;
     case PROP_DEVICE_ID: g_value_set_int (value, self->device_id); break;
+    case PROP_ASYNC_DEPTH: g_value_set_int (value, self->async.depth); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
   }
   GST_OBJECT_UNLOCK (self);
@@ -191,6 +200,7 @@ ov_start (GstBaseTransform * trans)
 static gboolean
 ov_stop (GstBaseTransform * trans)
 {
+  gst_vfhip_async_drain (trans, &OV (trans)->async, FALSE);          /* the streaming thread has stopped: frames in flight are dropped */
   if (OV (trans)->renderer)
     vfhip_overlay_cleanup (OV (trans)->renderer);
   return TRUE;
@@ -219,6 +229,44 @@ ov_decide_allocation (GstBaseTransform * trans, GstQuery * query)
   return gst_vfhip_decide_allocation (trans, query, GST_BASE_TRANSFORM_CLASS (gst_vfhip_overlay_parent_class)->decide_allocation);
 }
 
+
+/* ---- async-depth=1 (gstvfhipasync.c) -------------------------------------------------------------------------------- */
+static int
+ov_async_submit (GstBaseTransform * trans, const VfHipFrame * in, VfHipFrame * out)
+{
+  VfHipOverlayParams p;
+  ov_params (OV (trans), in->info.width, in->info.height, &p);
+  return vfhip_overlay_submit (OV (trans)->renderer, in, out, &p);
+}
+
+static int
+ov_async_wait (GstBaseTransform * trans)
+{
+  return vfhip_overlay_wait (OV (trans)->renderer);
+}
+
+static GstFlowReturn
+ov_generate_output (GstBaseTransform * trans, GstBuffer ** outbuf)
+{
+  GstVideoFilter *f = GST_VIDEO_FILTER_CAST (trans);
+  return gst_vfhip_async_generate_output (trans, outbuf, &OV (trans)->async, &f->in_info, &f->out_info, f->negotiated && OV (trans)->renderer != NULL,
+      GST_BASE_TRANSFORM_CLASS (gst_vfhip_overlay_parent_class)->generate_output);
+}
+
+static gboolean
+ov_sink_event (GstBaseTransform * trans, GstEvent * event)
+{
+  return gst_vfhip_async_sink_event (trans, event, &OV (trans)->async, GST_BASE_TRANSFORM_CLASS (gst_vfhip_overlay_parent_class)->sink_event);
+}
+
+static gboolean
+ov_query (GstBaseTransform * trans, GstPadDirection direction, GstQuery * query)
+{
+  GstVideoFilter *f = GST_VIDEO_FILTER_CAST (trans);
+  return gst_vfhip_async_query (trans, direction, query, &OV (trans)->async, f->negotiated ? &f->out_info : NULL,
+      GST_BASE_TRANSFORM_CLASS (gst_vfhip_overlay_parent_class)->query);
+}
+
 static void
 gst_vfhip_overlay_class_init (GstVfHipOverlayClass * klass)
 {
@@ -238,6 +286,9 @@ gst_vfhip_overlay_class_init (GstVfHipOverlayClass * klass)
   GST_VIDEO_FILTER_CLASS (klass)->transform_frame = GST_DEBUG_FUNCPTR (ov_transform_frame);
   bc->transform_caps = GST_DEBUG_FUNCPTR (gst_vfhip_filter_transform_caps);
   bc->transform = GST_DEBUG_FUNCPTR (gst_vfhip_filter_transform);
+  bc->generate_output = GST_DEBUG_FUNCPTR (ov_generate_output);
+  bc->sink_event = GST_DEBUG_FUNCPTR (ov_sink_event);
+  bc->query = GST_DEBUG_FUNCPTR (ov_query);
 
   g_object_class_install_property (oc, PROP_LOCATION, g_param_spec_string ("location", "Location", "Path to overlay image file (PNG)", NULL, f));
   g_object_class_install_property (oc, PROP_X, g_param_spec_int ("x", "X Position", "Overlay X position in pixels", 0, G_MAXINT, 0, f));
@@ -252,6 +303,7 @@ gst_vfhip_overlay_class_init (GstVfHipOverlayClass * klass)
   g_object_class_install_property (oc, PROP_DEVICE_ID, g_param_spec_int ("device-id", "Device ID",
           "GPU ordinal to run on (-1: $VFHIP_DEVICE, else 0)", -1, 63, GST_VFHIP_DEFAULT_DEVICE_ID, f));
 
+  g_object_class_install_property (oc, PROP_ASYNC_DEPTH, gst_vfhip_async_depth_pspec ());
   gst_element_class_add_static_pad_template (ec, &ov_sink_template);
   gst_element_class_add_static_pad_template (ec, &ov_src_template);
   gst_element_class_set_static_metadata (ec, "HIP Video Overlay", "Filter/Effect/Video",
@@ -264,6 +316,8 @@ gst_vfhip_overlay_init (GstVfHipOverlay * self)
   self->alpha = 1.0;
   self->relative_x = self->relative_y = -1.0;
   self->device_id = GST_VFHIP_DEFAULT_DEVICE_ID;
+  self->async.submit = ov_async_submit;
+  self->async.wait = ov_async_wait;
   gst_base_transform_set_passthrough (GST_BASE_TRANSFORM (self), TRUE);
 }
 

@@ -18,13 +18,14 @@ typedef struct
   GstVideoFilter parent;
   VfHipTransform *renderer;
   gint device_id, method, crop_top, crop_bottom, crop_left, crop_right;
+  GstVfHipAsync async;                          /* async-depth=1 (gstvfhipasync.c) */
 } GstVfHipTransform;
 typedef struct
 {
   GstVideoFilterClass parent_class;
 } GstVfHipTransformClass;
 
-enum { PROP_0, PROP_METHOD, PROP_CROP_TOP, PROP_CROP_BOTTOM, PROP_CROP_LEFT, PROP_CROP_RIGHT, PROP_DEVICE_ID };
+enum { PROP_0, PROP_METHOD, PROP_CROP_TOP, PROP_CROP_BOTTOM, PROP_CROP_LEFT, PROP_CROP_RIGHT, PROP_DEVICE_ID, PROP_ASYNC_DEPTH };
 
 static GstStaticPadTemplate tr_sink_template = GST_STATIC_PAD_TEMPLATE ("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
     GST_STATIC_CAPS (GST_VFHIP_CAPS (VFHIP_TR_FORMATS)));
@@ -117,6 +118,7 @@ tr_set_property (GObject * object, guint id, const GValue * value, GParamSpec * 
     case PROP_CROP_LEFT: self->crop_left = g_value_get_int (value); break;
     case PROP_CROP_RIGHT: self->crop_right = g_value_get_int (value); break;
     case PROP_DEVICE_ID: self->device_id = g_value_get_int (value); break;
+    case PROP_ASYNC_DEPTH: self->async.depth = g_value_get_int (value); break;
     default:
       GST_OBJECT_UNLOCK (self);
       G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec);
@@ -138,6 +140,7 @@ tr_get_property (GObject * object, guint id, GValue * value, GParamSpec * pspec)
     case PROP_CROP_LEFT: g_value_set_int (value, self->crop_left); break;
     case PROP_CROP_RIGHT: g_value_set_int (value, self->crop_right); break;
     case PROP_DEVICE_ID: g_value_set_int (value, self->device_id); break;
+    case PROP_ASYNC_DEPTH: g_value_set_int (value, self->async.depth); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
   }
   GST_OBJECT_UNLOCK (self);
@@ -153,6 +156,7 @@ tr_start (GstBaseTransform * trans)
 static gboolean
 tr_stop (GstBaseTransform * trans)
 {
+  gst_vfhip_async_drain (trans, &TR (trans)->async, FALSE);          /* the streaming thread has stopped: frames in flight are dropped */
   if (TR (trans)->renderer)
     vfhip_transform_cleanup (TR (trans)->renderer);
   return TRUE;
@@ -180,6 +184,54 @@ tr_decide_allocation (GstBaseTransform * trans, GstQuery * query)
   return gst_vfhip_decide_allocation (trans, query, GST_BASE_TRANSFORM_CLASS (gst_vfhip_transform_parent_class)->decide_allocation);
 }
 
+
+/* ---- async-depth=1 (gstvfhipasync.c) -------------------------------------------------------------------------------- */
+static void
+tr_params (GstVfHipTransform * self, VfHipTransformParams * p)
+{
+  memset (p, 0, sizeof (*p));
+  GST_OBJECT_LOCK (self);
+  p->method = self->method;
+  p->crop_top = self->crop_top; p->crop_bottom = self->crop_bottom; p->crop_left = self->crop_left; p->crop_right = self->crop_right;
+  GST_OBJECT_UNLOCK (self);
+}
+
+static int
+tr_async_submit (GstBaseTransform * trans, const VfHipFrame * in, VfHipFrame * out)
+{
+  VfHipTransformParams p;
+  tr_params (TR (trans), &p);
+  return vfhip_transform_submit (TR (trans)->renderer, in, out, &p);
+}
+
+static int
+tr_async_wait (GstBaseTransform * trans)
+{
+  return vfhip_transform_wait (TR (trans)->renderer);
+}
+
+static GstFlowReturn
+tr_generate_output (GstBaseTransform * trans, GstBuffer ** outbuf)
+{
+  GstVideoFilter *f = GST_VIDEO_FILTER_CAST (trans);
+  return gst_vfhip_async_generate_output (trans, outbuf, &TR (trans)->async, &f->in_info, &f->out_info, f->negotiated && TR (trans)->renderer != NULL,
+      GST_BASE_TRANSFORM_CLASS (gst_vfhip_transform_parent_class)->generate_output);
+}
+
+static gboolean
+tr_sink_event (GstBaseTransform * trans, GstEvent * event)
+{
+  return gst_vfhip_async_sink_event (trans, event, &TR (trans)->async, GST_BASE_TRANSFORM_CLASS (gst_vfhip_transform_parent_class)->sink_event);
+}
+
+static gboolean
+tr_query (GstBaseTransform * trans, GstPadDirection direction, GstQuery * query)
+{
+  GstVideoFilter *f = GST_VIDEO_FILTER_CAST (trans);
+  return gst_vfhip_async_query (trans, direction, query, &TR (trans)->async, f->negotiated ? &f->out_info : NULL,
+      GST_BASE_TRANSFORM_CLASS (gst_vfhip_transform_parent_class)->query);
+}
+
 static void
 gst_vfhip_transform_class_init (GstVfHipTransformClass * klass)
 {
@@ -199,6 +251,9 @@ gst_vfhip_transform_class_init (GstVfHipTransformClass * klass)
   /* memory:HIPMemory on either pad (gstvfhipmemory.c): same video caps in both memories, device buffers mapped in place */
   GST_BASE_TRANSFORM_CLASS (klass)->transform_caps = GST_DEBUG_FUNCPTR (gst_vfhip_filter_transform_caps);
   GST_BASE_TRANSFORM_CLASS (klass)->transform = GST_DEBUG_FUNCPTR (gst_vfhip_filter_transform);
+  GST_BASE_TRANSFORM_CLASS (klass)->generate_output = GST_DEBUG_FUNCPTR (tr_generate_output);
+  GST_BASE_TRANSFORM_CLASS (klass)->sink_event = GST_DEBUG_FUNCPTR (tr_sink_event);
+  GST_BASE_TRANSFORM_CLASS (klass)->query = GST_DEBUG_FUNCPTR (tr_query);
 
   g_object_class_install_property (oc, PROP_METHOD, g_param_spec_enum ("method", "Method", "Flip/rotation method", tr_method_type (),
           VFHIP_TRANSFORM_IDENTITY, f));
@@ -209,6 +264,7 @@ gst_vfhip_transform_class_init (GstVfHipTransformClass * klass)
   g_object_class_install_property (oc, PROP_DEVICE_ID, g_param_spec_int ("device-id", "Device ID",
           "GPU ordinal to run on (-1: $VFHIP_DEVICE, else 0)", -1, 63, GST_VFHIP_DEFAULT_DEVICE_ID, f));
 
+  g_object_class_install_property (oc, PROP_ASYNC_DEPTH, gst_vfhip_async_depth_pspec ());
   gst_element_class_add_static_pad_template (ec, &tr_sink_template);
   gst_element_class_add_static_pad_template (ec, &tr_src_template);
   gst_element_class_set_static_metadata (ec, "HIP Video Transform", "Filter/Effect/Video",
@@ -220,6 +276,8 @@ gst_vfhip_transform_init (GstVfHipTransform * self)
 {
   self->method = VFHIP_TRANSFORM_IDENTITY;
   self->device_id = GST_VFHIP_DEFAULT_DEVICE_ID;
+  self->async.submit = tr_async_submit;
+  self->async.wait = tr_async_wait;
 }
 
 gboolean

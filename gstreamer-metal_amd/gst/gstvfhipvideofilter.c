@@ -26,6 +26,7 @@ typedef struct
   gdouble chroma_key_tolerance, chroma_key_smoothness;
   gchar *lut_file;
   guint frame_count;
+  GstVfHipAsync async;                          /* async-depth=1 (gstvfhipasync.c) */
 } GstVfHipVideoFilter;
 
 typedef struct
@@ -37,7 +38,7 @@ enum
 {
   PROP_0, PROP_BRIGHTNESS, PROP_CONTRAST, PROP_SATURATION, PROP_HUE, PROP_GAMMA, PROP_SHARPNESS, PROP_SEPIA, PROP_INVERT,
   PROP_NOISE, PROP_VIGNETTE, PROP_CHROMA_KEY_ENABLED, PROP_CHROMA_KEY_COLOR, PROP_CHROMA_KEY_TOLERANCE,
-  PROP_CHROMA_KEY_SMOOTHNESS, PROP_LUT_FILE, PROP_DEVICE_ID
+  PROP_CHROMA_KEY_SMOOTHNESS, PROP_LUT_FILE, PROP_DEVICE_ID, PROP_ASYNC_DEPTH
 };
 
 static GstStaticPadTemplate vf_sink_template = GST_STATIC_PAD_TEMPLATE ("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
@@ -93,38 +94,45 @@ vf_set_info (GstVideoFilter * filter, GstCaps * incaps, GstVideoInfo * in_info, 
   return TRUE;
 }
 
+/* one consistent snapshot of the properties per frame */
+static void
+vf_params (GstVfHipVideoFilter * self, VfHipVideoFilterParams * p)
+{
+  guint key;
+  memset (p, 0, sizeof (*p));
+  GST_OBJECT_LOCK (self);
+  p->brightness = (float) self->brightness;
+  p->contrast = (float) self->contrast;
+  p->saturation = (float) self->saturation;
+  p->hue = (float) (self->hue * G_PI);          /* property is -1..1 half-turns */
+  p->gamma = (float) self->gamma;
+  p->sharpness = (float) self->sharpness;
+  p->sepia = (float) self->sepia;
+  p->noise = (float) self->noise;
+  p->vignette = (float) self->vignette;
+  p->invert = self->invert;
+  p->chroma_key_enabled = self->chroma_key_enabled;
+  key = self->chroma_key_color;
+  p->chroma_key_tolerance = (float) self->chroma_key_tolerance;
+  p->chroma_key_smoothness = (float) self->chroma_key_smoothness;
+  p->frame_index = self->frame_count++;
+  GST_OBJECT_UNLOCK (self);
+  p->chroma_key_r = ((key >> 16) & 0xff) / 255.0f;
+  p->chroma_key_g = ((key >> 8) & 0xff) / 255.0f;
+  p->chroma_key_b = (key & 0xff) / 255.0f;
+}
+
 static GstFlowReturn
 vf_transform_frame (GstVideoFilter * filter, GstVideoFrame * in, GstVideoFrame * out)
 {
   GstVfHipVideoFilter *self = VF (filter);
   VfHipVideoFilterParams p;
   VfHipFrame vin, vout;
-  guint key;
   if (!self->renderer) {
     GST_WARNING_OBJECT (self, "no HIP renderer");
     return GST_FLOW_ERROR;
   }
-  memset (&p, 0, sizeof (p));
-  GST_OBJECT_LOCK (self);                       /* one consistent snapshot per frame */
-  p.brightness = (float) self->brightness;
-  p.contrast = (float) self->contrast;
-  p.saturation = (float) self->saturation;
-  p.hue = (float) (self->hue * G_PI);           /* property is -1..1 half-turns */
-  p.gamma = (float) self->gamma;
-  p.sharpness = (float) self->sharpness;
-  p.sepia = (float) self->sepia;
-  p.noise = (float) self->noise;
-  p.vignette = (float) self->vignette;
-  p.invert = self->invert;
-  p.chroma_key_enabled = self->chroma_key_enabled;
-  key = self->chroma_key_color;
-  p.chroma_key_tolerance = (float) self->chroma_key_tolerance;
-  p.chroma_key_smoothness = (float) self->chroma_key_smoothness;
-  p.frame_index = self->frame_count++;
-  GST_OBJECT_UNLOCK (self);
-  p.chroma_key_r = ((key >> 16) & 0xff) / 255.0f;
-  p.chroma_key_g = ((key >> 8) & 0xff) / 255.0f;
-  p.chroma_key_b = (key & 0xff) / 255.0f;
+  vf_params (self, &p);
   gst_vfhip_frame (in, &vin);
   gst_vfhip_frame (out, &vout);
   if (vfhip_videofilter_process (self->renderer, &vin, &vout, &p) != VFHIP_OK) {
@@ -156,6 +164,7 @@ vf_set_property (GObject * object, guint id, const GValue * value, GParamSpec * 
     case PROP_CHROMA_KEY_TOLERANCE: self->chroma_key_tolerance = g_value_get_double (value); break;
     case PROP_CHROMA_KEY_SMOOTHNESS: self->chroma_key_smoothness = g_value_get_double (value); break;
     case PROP_DEVICE_ID: self->device_id = g_value_get_int (value); break;
+    case PROP_ASYNC_DEPTH: self->async.depth = g_value_get_int (value); break;
     case PROP_LUT_FILE:
       g_free (self->lut_file);
       self->lut_file = g_value_dup_string (value);
@@ -201,6 +210,7 @@ vf_get_property (GObject * object, guint id, GValue * value, GParamSpec * pspec)
     case PROP_CHROMA_KEY_SMOOTHNESS: g_value_set_double (value, self->chroma_key_smoothness); break;
     case PROP_LUT_FILE: g_value_set_string (value, self->lut_file); break;
     case PROP_DEVICE_ID: g_value_set_int (value, self->device_id); break;
+    case PROP_ASYNC_DEPTH: g_value_set_int (value, self->async.depth); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
   }
   GST_OBJECT_UNLOCK (self);
@@ -217,6 +227,7 @@ vf_start (GstBaseTransform * trans)
 static gboolean
 vf_stop (GstBaseTransform * trans)
 {
+  gst_vfhip_async_drain (trans, &VF (trans)->async, FALSE);          /* the streaming thread has stopped: frames in flight are dropped */
   GstVfHipVideoFilter *self = VF (trans);
   if (self->renderer)
     vfhip_videofilter_cleanup (self->renderer);
@@ -252,6 +263,44 @@ vi_decide_allocation (GstBaseTransform * trans, GstQuery * query)
   return gst_vfhip_decide_allocation (trans, query, GST_BASE_TRANSFORM_CLASS (gst_vfhip_videofilter_parent_class)->decide_allocation);
 }
 
+
+/* ---- async-depth=1 (gstvfhipasync.c) -------------------------------------------------------------------------------- */
+static int
+vf_async_submit (GstBaseTransform * trans, const VfHipFrame * in, VfHipFrame * out)
+{
+  VfHipVideoFilterParams p;
+  vf_params (VF (trans), &p);
+  return vfhip_videofilter_submit (VF (trans)->renderer, in, out, &p);
+}
+
+static int
+vf_async_wait (GstBaseTransform * trans)
+{
+  return vfhip_videofilter_wait (VF (trans)->renderer);
+}
+
+static GstFlowReturn
+vf_generate_output (GstBaseTransform * trans, GstBuffer ** outbuf)
+{
+  GstVideoFilter *f = GST_VIDEO_FILTER_CAST (trans);
+  return gst_vfhip_async_generate_output (trans, outbuf, &VF (trans)->async, &f->in_info, &f->out_info, f->negotiated && VF (trans)->renderer != NULL,
+      GST_BASE_TRANSFORM_CLASS (gst_vfhip_videofilter_parent_class)->generate_output);
+}
+
+static gboolean
+vf_sink_event (GstBaseTransform * trans, GstEvent * event)
+{
+  return gst_vfhip_async_sink_event (trans, event, &VF (trans)->async, GST_BASE_TRANSFORM_CLASS (gst_vfhip_videofilter_parent_class)->sink_event);
+}
+
+static gboolean
+vf_query (GstBaseTransform * trans, GstPadDirection direction, GstQuery * query)
+{
+  GstVideoFilter *f = GST_VIDEO_FILTER_CAST (trans);
+  return gst_vfhip_async_query (trans, direction, query, &VF (trans)->async, f->negotiated ? &f->out_info : NULL,
+      GST_BASE_TRANSFORM_CLASS (gst_vfhip_videofilter_parent_class)->query);
+}
+
 static void
 gst_vfhip_videofilter_class_init (GstVfHipVideoFilterClass * klass)
 {
@@ -271,6 +320,9 @@ gst_vfhip_videofilter_class_init (GstVfHipVideoFilterClass * klass)
   /* memory:HIPMemory on either pad (gstvfhipmemory.c): same video caps in both memories, device buffers mapped in place */
   GST_BASE_TRANSFORM_CLASS (klass)->transform_caps = GST_DEBUG_FUNCPTR (gst_vfhip_filter_transform_caps);
   GST_BASE_TRANSFORM_CLASS (klass)->transform = GST_DEBUG_FUNCPTR (gst_vfhip_filter_transform);
+  GST_BASE_TRANSFORM_CLASS (klass)->generate_output = GST_DEBUG_FUNCPTR (vf_generate_output);
+  GST_BASE_TRANSFORM_CLASS (klass)->sink_event = GST_DEBUG_FUNCPTR (vf_sink_event);
+  GST_BASE_TRANSFORM_CLASS (klass)->query = GST_DEBUG_FUNCPTR (vf_query);
 
   DPROP (PROP_BRIGHTNESS, "brightness", "Brightness", "Brightness adjustment (-1.0 to 1.0)", -1.0, 1.0, 0.0);
   DPROP (PROP_CONTRAST, "contrast", "Contrast", "Contrast adjustment (0.0 to 2.0, 1.0 = normal)", 0.0, 2.0, 1.0);
@@ -294,6 +346,7 @@ gst_vfhip_videofilter_class_init (GstVfHipVideoFilterClass * klass)
   g_object_class_install_property (oc, PROP_DEVICE_ID, g_param_spec_int ("device-id", "Device ID",
           "GPU ordinal to run on (-1: $VFHIP_DEVICE, else 0)", -1, 63, GST_VFHIP_DEFAULT_DEVICE_ID, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
 
+  g_object_class_install_property (oc, PROP_ASYNC_DEPTH, gst_vfhip_async_depth_pspec ());
   gst_element_class_add_static_pad_template (ec, &vf_sink_template);
   gst_element_class_add_static_pad_template (ec, &vf_src_template);
   gst_element_class_set_static_metadata (ec, "HIP Video Filter", "Filter/Effect/Video",
@@ -308,6 +361,8 @@ gst_vfhip_videofilter_init (GstVfHipVideoFilter * self)
   self->chroma_key_tolerance = 0.2;
   self->chroma_key_smoothness = 0.1;
   self->device_id = GST_VFHIP_DEFAULT_DEVICE_ID;
+  self->async.submit = vf_async_submit;
+  self->async.wait = vf_async_wait;
 }
 
 gboolean

@@ -217,6 +217,10 @@ int vfhip_videofilter_process_device (VfHipVideoFilter *h, const VfHipFrame *in,
 /* batch: frame k at data[p] + k * pitch, filtered with params->frame_index + k */
 int vfhip_videofilter_process_device_batch (VfHipVideoFilter *h, const VfHipFrame *in0, VfHipFrame *out0,
     size_t in_frame_pitch, size_t out_frame_pitch, int n_frames, const VfHipVideoFilterParams *params, void *stream);
+/* pipelined host path, like vfhip_convertscale_submit / _wait (the parameters are copied at submit) */
+int vfhip_videofilter_submit (VfHipVideoFilter *h, const VfHipFrame *in, VfHipFrame *out, const VfHipVideoFilterParams *params);
+int vfhip_videofilter_wait (VfHipVideoFilter *h);
+int vfhip_videofilter_in_flight (VfHipVideoFilter *h);
 int vfhip_videofilter_load_lut (VfHipVideoFilter *h, const char *path);                       /* -loadLUTFromFile: (.cube only) */
 int vfhip_videofilter_set_lut (VfHipVideoFilter *h, const float *rgba, int size);             /* size^3 RGBA32F, R fastest */
 void vfhip_videofilter_clear_lut (VfHipVideoFilter *h);
@@ -276,6 +280,9 @@ int vfhip_transform_process_device (VfHipTransform *h, const VfHipFrame *in, VfH
     const VfHipTransformParams *params, void *stream);
 int vfhip_transform_process_device_batch (VfHipTransform *h, const VfHipFrame *in0, VfHipFrame *out0,
     size_t in_frame_pitch, size_t out_frame_pitch, int n_frames, const VfHipTransformParams *params, void *stream);
+int vfhip_transform_submit (VfHipTransform *h, const VfHipFrame *in, VfHipFrame *out, const VfHipTransformParams *params);
+int vfhip_transform_wait (VfHipTransform *h);
+int vfhip_transform_in_flight (VfHipTransform *h);
 void vfhip_transform_cleanup (VfHipTransform *h);
 void vfhip_transform_free (VfHipTransform *h);
 
@@ -299,6 +306,9 @@ int vfhip_overlay_process (VfHipOverlay *h, const VfHipFrame *in, VfHipFrame *ou
 int vfhip_overlay_process_device (VfHipOverlay *h, const VfHipFrame *in, VfHipFrame *out, const VfHipOverlayParams *params, void *stream);
 int vfhip_overlay_process_device_batch (VfHipOverlay *h, const VfHipFrame *in0, VfHipFrame *out0, size_t in_frame_pitch,
     size_t out_frame_pitch, int n_frames, const VfHipOverlayParams *params, void *stream);
+int vfhip_overlay_submit (VfHipOverlay *h, const VfHipFrame *in, VfHipFrame *out, const VfHipOverlayParams *params);
+int vfhip_overlay_wait (VfHipOverlay *h);
+int vfhip_overlay_in_flight (VfHipOverlay *h);
 void vfhip_overlay_cleanup (VfHipOverlay *h);
 void vfhip_overlay_free (VfHipOverlay *h);
 

@@ -336,3 +336,26 @@ def test_no_per_frame_leak_in_the_element_shells():
 
     a, b = peak_kb(150), peak_kb(1500)
     assert b < a * 1.08 + 20000, f"peak RSS grew from {a} kB (150 frames) to {b} kB (1500 frames)"
+
+
+@pytest.mark.parametrize("element,cin,cout", [
+    ("vfhipvideofilter brightness=0.1 sharpness=0.4 noise=0.2", ("BGRA", 320, 240), ("BGRA", 320, 240)),
+    ("vfhipvideofilter gamma=1.4 sepia=0.3", ("NV12", 320, 240), ("NV12", 320, 240)),
+    ("vfhiptransform method=clockwise crop-left=8", ("I420", 320, 240), ("I420", 320, 240)),
+    ("vfhipoverlay location=LOGO relative-x=0.5 y=20 alpha=0.7", ("BGRA", 320, 240), ("BGRA", 320, 240)),
+])
+@pytest.mark.parametrize("n", [1, 4])
+def test_async_depth_other_elements(tmp_path, element, cin, cout, n):
+    """async-depth=1 on the GstVideoFilter-based elements: same frames, same order (noise uses the per-frame counter), none
+    lost at EOS"""
+    logo = tmp_path / "logo.png"
+    _write_logo(logo)
+    element = element.replace("LOGO", str(logo))
+    outs = []
+    for depth in (1, 0):
+        path = tmp_path / f"d{depth}.raw"
+        r = gst_env.launch(f"videotestsrc num-buffers={n} pattern=ball ! {caps(*cin)} ! {element} async-depth={depth} ! {caps(*cout)} ! filesink location={path}")
+        assert r.returncode == 0, r.stderr
+        outs.append(np.fromfile(path, np.uint8))
+    assert outs[0].size == outs[1].size and outs[0].size > 0 and outs[0].size % n == 0
+    assert np.array_equal(outs[0], outs[1])

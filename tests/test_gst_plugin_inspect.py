@@ -41,7 +41,7 @@ def test_videofilter_api():
     t = gst_env.inspect("vfhipvideofilter").stdout
     want = {"brightness", "contrast", "saturation", "hue", "gamma", "sharpness", "sepia", "invert", "noise", "vignette",
             "chroma-key-enabled", "chroma-key-color", "chroma-key-tolerance", "chroma-key-smoothness", "lut-file"}
-    assert want <= props(t) and len(want) == 15
+    assert want <= props(t) and len(want) == 15 and "async-depth" in props(t)
     assert "GstVideoFilter" in t
     assert t.count("(string)BGRA, (string)RGBA, (string)NV12, (string)I420 }") == 4 and t.count("video/x-raw(memory:HIPMemory)") == 2
     assert "Range: 0.01 - 10 Default: 1 " in squeeze(t)      # gamma
