@@ -176,8 +176,10 @@ struct VfHipDeinterlace {
   Staging st;
   bool configured = false;
   VfHipVideoInfo info {};
-  // host path: two upload slots used alternately, the other one is the previous frame
-  int cur_slot = 0;
+  // host path: three upload slots used in turn (the previous one is the history; with two frames in flight the third is
+  // the only one no kernel can still be reading), outputs in slots 3 / 4
+  unsigned seq = 0;
+  Flights fl;                       // pipelined host path (submit / wait)
   bool has_prev = false;
   VfHipFrame prev_dev {};           // device-side previous input frame (host path: staging slot; device path: hist buffer)
   void *hist[2] = { nullptr, nullptr }; size_t hist_bytes = 0;   // device path: ping-pong history images
@@ -237,6 +239,7 @@ int vfhip_deinterlace_configure (VfHipDeinterlace *h, const VfHipVideoInfo *info
 {
   if (!h || !info) return set_error (VFHIP_ERR_INVALID, "null argument");
   std::lock_guard<std::mutex> lk (h->mu);
+  if (h->fl.count) return set_error (VFHIP_ERR_INVALID, "configure with %d submitted frame(s) still in flight: wait for them first", h->fl.count);
   if (info->width <= 0 || info->height <= 0 || info->width > 32768 || info->height > 32768)
     return set_error (VFHIP_ERR_INVALID, "bad frame size %dx%d", info->width, info->height);
   // pad template of the reference: BGRA, RGBA, NV12, I420 (deinterlace/gstvfmetaldeinterlace.m:43-55)
@@ -256,31 +259,73 @@ int vfhip_deinterlace_reset (VfHipDeinterlace *h)
   return VFHIP_OK;
 }
 
+// one frame onto the handle's streams: upload (or use in place) -> kernel with the history -> download queued behind it
+static int deint_submit_locked (VfHipDeinterlace *h, const VfHipFrame *in, VfHipFrame *out, const VfHipDeinterlaceParams *prm)
+{
+  if (h->fl.count >= 2) return set_error (VFHIP_ERR_INVALID, "two frames are already in flight: call vfhip_deinterlace_wait first");
+  const int k = (h->fl.head + h->fl.count) & 1;
+  const size_t in_slot = h->seq % 3, out_slot = 3 + (size_t) k;
+  VfHipFrame din, dout;
+  int rc;
+  if ((rc = upload_frame (h->st, in_slot, in, &din))) return rc;
+  if ((rc = output_frame (h->st, out_slot, &h->info, out, &dout))) return rc;
+  VFHIP_CHECK_HIP (hipStreamWaitEvent (h->st.s_compute, h->st.ev_h2d, 0));
+  if (in->flags & VFHIP_FRAME_FLAG_DEVICE) {
+    // device-resident input (memory:HIPMemory buffer): it belongs to the caller and may be recycled after this frame, so
+    // the history is copied device-to-device like in the process_device path
+    if ((rc = deint_device_locked (h, &din, &dout, 0, 0, 1, prm, h->st.s_compute))) return rc;
+  } else {
+    if ((rc = deint_launch (h, &din, h->has_prev ? &h->prev_dev : nullptr, &dout, prm, h->st.s_compute))) return rc;
+    h->prev_dev = din; h->has_prev = true;              // the staging slot of this frame is the next frame's history
+  }
+  VFHIP_CHECK_HIP (hipEventRecord (h->st.ev_compute, h->st.s_compute));
+  h->fl.f[k].out = *out;
+  if ((rc = download_begin (h->st, out_slot, &h->fl.f[k].out, h->fl.f[k].staged, h->st.ev_done[k]))) return rc;
+  h->fl.count++; h->seq++;
+  return VFHIP_OK;
+}
+
+static int deint_wait_locked (VfHipDeinterlace *h)
+{
+  if (h->fl.count == 0) return set_error (VFHIP_ERR_INVALID, "no frame in flight");
+  const int k = h->fl.head;
+  h->fl.head ^= 1; h->fl.count--;
+  return download_finish (h->st, 3 + (size_t) k, &h->fl.f[k].out, h->fl.f[k].staged, h->st.ev_done[k]);
+}
+
 int vfhip_deinterlace_process (VfHipDeinterlace *h, const VfHipFrame *in, VfHipFrame *out, const VfHipDeinterlaceParams *prm)
 {
   int rc = deint_check (h, in, out, prm);
   if (rc) return rc;
   std::lock_guard<std::mutex> lk (h->mu);
+  if (h->fl.count) return set_error (VFHIP_ERR_INVALID, "frames submitted with vfhip_deinterlace_submit are still in flight");
   VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
-  VfHipFrame din, dout;
-  if (in->flags & VFHIP_FRAME_FLAG_DEVICE) {
-    // device-resident input (memory:HIPMemory buffer): it belongs to the caller and may be recycled after this call,
-    // so the history is copied device-to-device like in the process_device path
-    if ((rc = upload_frame (h->st, 0, in, &din))) return rc;              // validates; no copy
-    if ((rc = output_frame (h->st, 2, &h->info, out, &dout))) return rc;
-    if ((rc = deint_device_locked (h, &din, &dout, 0, 0, 1, prm, h->st.s_compute))) return rc;
-    VFHIP_CHECK_HIP (hipEventRecord (h->st.ev_compute, h->st.s_compute));
-    return download_frame (h->st, 2, &dout, out);
-  }
-  const int slot = h->cur_slot;                         // slots 0/1 alternate: no device copy for the history
-  if ((rc = upload_frame (h->st, slot, in, &din))) return rc;
-  if ((rc = output_frame (h->st, 2, &h->info, out, &dout))) return rc;
-  VFHIP_CHECK_HIP (hipStreamWaitEvent (h->st.s_compute, h->st.ev_h2d, 0));
-  if ((rc = deint_launch (h, &din, h->has_prev ? &h->prev_dev : nullptr, &dout, prm, h->st.s_compute))) return rc;
-  VFHIP_CHECK_HIP (hipEventRecord (h->st.ev_compute, h->st.s_compute));
-  rc = download_frame (h->st, 2, &dout, out);
-  h->prev_dev = din; h->has_prev = true; h->cur_slot = 1 - slot;
-  return rc;
+  if ((rc = deint_submit_locked (h, in, out, prm))) return rc;
+  return deint_wait_locked (h);
+}
+
+int vfhip_deinterlace_submit (VfHipDeinterlace *h, const VfHipFrame *in, VfHipFrame *out, const VfHipDeinterlaceParams *prm)
+{
+  int rc = deint_check (h, in, out, prm);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk (h->mu);
+  VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
+  return deint_submit_locked (h, in, out, prm);
+}
+
+int vfhip_deinterlace_wait (VfHipDeinterlace *h)
+{
+  if (!h) return set_error (VFHIP_ERR_INVALID, "null handle");
+  std::lock_guard<std::mutex> lk (h->mu);
+  VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
+  return deint_wait_locked (h);
+}
+
+int vfhip_deinterlace_in_flight (VfHipDeinterlace *h)
+{
+  if (!h) return 0;
+  std::lock_guard<std::mutex> lk (h->mu);
+  return h->fl.count;
 }
 
 // history = the previous input frame, kept in one of two internal device images and filled by a stream-ordered
@@ -340,6 +385,7 @@ void vfhip_deinterlace_cleanup (VfHipDeinterlace *h)
   if (!h) return;
   std::lock_guard<std::mutex> lk (h->mu);
   (void) hipSetDevice (h->dev->ordinal);
+  flights_abandon (h->st, h->fl);
   for (int k = 0; k < 2; k++) { if (h->hist[k]) (void) hipFree (h->hist[k]); h->hist[k] = nullptr; }
   h->hist_bytes = 0;
   for (auto &b : h->st.slots) { if (b.host) (void) hipHostFree (b.host); if (b.devp) (void) hipFree (b.devp); }

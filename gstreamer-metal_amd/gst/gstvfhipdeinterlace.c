@@ -20,6 +20,7 @@ typedef struct
   VfHipDeinterlace *renderer;
   gint device_id, method, field_layout;
   gdouble motion_threshold;
+  GstVfHipAsync async;                          /* async-depth=1 (gstvfhipasync.c) */
 } GstVfHipDeinterlace;
 
 typedef struct
@@ -27,7 +28,7 @@ typedef struct
   GstVideoFilterClass parent_class;
 } GstVfHipDeinterlaceClass;
 
-enum { PROP_0, PROP_METHOD, PROP_FIELD_LAYOUT, PROP_MOTION_THRESHOLD, PROP_DEVICE_ID };
+enum { PROP_0, PROP_METHOD, PROP_FIELD_LAYOUT, PROP_MOTION_THRESHOLD, PROP_DEVICE_ID, PROP_ASYNC_DEPTH };
 enum { FIELDS_AUTO = 0, FIELDS_TFF = 1, FIELDS_BFF = 2 };
 
 static GstStaticPadTemplate di_sink_template = GST_STATIC_PAD_TEMPLATE ("sink", GST_PAD_SINK, GST_PAD_ALWAYS,
@@ -87,28 +88,35 @@ di_set_info (GstVideoFilter * filter, GstCaps * incaps, GstVideoInfo * in_info, 
   return TRUE;
 }
 
+/* one snapshot of the properties per frame; field order from the property, else from the buffer's TFF flag (reference :176-184) */
+static void
+di_params (GstVfHipDeinterlace * self, const VfHipFrame * in, VfHipDeinterlaceParams * p)
+{
+  gint layout;
+  memset (p, 0, sizeof (*p));
+  GST_OBJECT_LOCK (self);
+  layout = self->field_layout;
+  p->method = self->method;
+  p->motion_threshold = (float) self->motion_threshold;
+  GST_OBJECT_UNLOCK (self);
+  if (layout == FIELDS_TFF) p->top_field_first = 1;
+  else if (layout == FIELDS_BFF) p->top_field_first = 0;
+  else p->top_field_first = (in->flags & VFHIP_FRAME_FLAG_TFF) != 0;
+}
+
 static GstFlowReturn
 di_transform_frame (GstVideoFilter * filter, GstVideoFrame * in, GstVideoFrame * out)
 {
   GstVfHipDeinterlace *self = DI (filter);
   VfHipDeinterlaceParams p;
   VfHipFrame vin, vout;
-  gint layout;
   if (!self->renderer) {
     GST_WARNING_OBJECT (self, "no HIP renderer");
     return GST_FLOW_ERROR;
   }
   gst_vfhip_frame (in, &vin);
   gst_vfhip_frame (out, &vout);
-  memset (&p, 0, sizeof (p));
-  GST_OBJECT_LOCK (self);
-  layout = self->field_layout;
-  p.method = self->method;
-  p.motion_threshold = (float) self->motion_threshold;
-  GST_OBJECT_UNLOCK (self);
-  if (layout == FIELDS_TFF) p.top_field_first = 1;
-  else if (layout == FIELDS_BFF) p.top_field_first = 0;
-  else p.top_field_first = in->buffer ? ((vin.flags & VFHIP_FRAME_FLAG_TFF) != 0) : 1;
+  di_params (self, &vin, &p);
   if (vfhip_deinterlace_process (self->renderer, &vin, &vout, &p) != VFHIP_OK) {
     GST_WARNING_OBJECT (self, "HIP processing failed: %s", vfhip_last_error_string ());
     return GST_FLOW_ERROR;
@@ -126,6 +134,7 @@ di_set_property (GObject * object, guint id, const GValue * value, GParamSpec * 
     case PROP_FIELD_LAYOUT: self->field_layout = g_value_get_enum (value); break;
     case PROP_MOTION_THRESHOLD: self->motion_threshold = g_value_get_double (value); break;
     case PROP_DEVICE_ID: self->device_id = g_value_get_int (value); break;
+    case PROP_ASYNC_DEPTH: self->async.depth = g_value_get_int (value); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
   }
   GST_OBJECT_UNLOCK (self);
@@ -141,6 +150,7 @@ di_get_property (GObject * object, guint id, GValue * value, GParamSpec * pspec)
     case PROP_FIELD_LAYOUT: g_value_set_enum (value, self->field_layout); break;
     case PROP_MOTION_THRESHOLD: g_value_set_double (value, self->motion_threshold); break;
     case PROP_DEVICE_ID: g_value_set_int (value, self->device_id); break;
+    case PROP_ASYNC_DEPTH: g_value_set_int (value, self->async.depth); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
   }
   GST_OBJECT_UNLOCK (self);
@@ -150,6 +160,7 @@ static gboolean
 di_stop (GstBaseTransform * trans)
 {
   GstVfHipDeinterlace *self = DI (trans);
+  gst_vfhip_async_drain (trans, &self->async, FALSE);          /* the streaming thread has stopped: frames in flight are dropped */
   if (self->renderer)
     vfhip_deinterlace_cleanup (self->renderer);     /* also forgets the previous frame */
   return TRUE;
@@ -178,6 +189,44 @@ de_decide_allocation (GstBaseTransform * trans, GstQuery * query)
   return gst_vfhip_decide_allocation (trans, query, GST_BASE_TRANSFORM_CLASS (gst_vfhip_deinterlace_parent_class)->decide_allocation);
 }
 
+
+/* ---- async-depth=1 (gstvfhipasync.c) -------------------------------------------------------------------------------- */
+static int
+di_async_submit (GstBaseTransform * trans, const VfHipFrame * in, VfHipFrame * out)
+{
+  VfHipDeinterlaceParams p;
+  di_params (DI (trans), in, &p);
+  return vfhip_deinterlace_submit (DI (trans)->renderer, in, out, &p);
+}
+
+static int
+di_async_wait (GstBaseTransform * trans)
+{
+  return vfhip_deinterlace_wait (DI (trans)->renderer);
+}
+
+static GstFlowReturn
+di_generate_output (GstBaseTransform * trans, GstBuffer ** outbuf)
+{
+  GstVideoFilter *f = GST_VIDEO_FILTER_CAST (trans);
+  return gst_vfhip_async_generate_output (trans, outbuf, &DI (trans)->async, &f->in_info, &f->out_info, f->negotiated && DI (trans)->renderer != NULL,
+      GST_BASE_TRANSFORM_CLASS (gst_vfhip_deinterlace_parent_class)->generate_output);
+}
+
+static gboolean
+di_sink_event (GstBaseTransform * trans, GstEvent * event)
+{
+  return gst_vfhip_async_sink_event (trans, event, &DI (trans)->async, GST_BASE_TRANSFORM_CLASS (gst_vfhip_deinterlace_parent_class)->sink_event);
+}
+
+static gboolean
+di_query (GstBaseTransform * trans, GstPadDirection direction, GstQuery * query)
+{
+  GstVideoFilter *f = GST_VIDEO_FILTER_CAST (trans);
+  return gst_vfhip_async_query (trans, direction, query, &DI (trans)->async, f->negotiated ? &f->out_info : NULL,
+      GST_BASE_TRANSFORM_CLASS (gst_vfhip_deinterlace_parent_class)->query);
+}
+
 static void
 gst_vfhip_deinterlace_class_init (GstVfHipDeinterlaceClass * klass)
 {
@@ -194,6 +243,9 @@ gst_vfhip_deinterlace_class_init (GstVfHipDeinterlaceClass * klass)
   /* memory:HIPMemory on either pad (gstvfhipmemory.c): same video caps in both memories, device buffers mapped in place */
   GST_BASE_TRANSFORM_CLASS (klass)->transform_caps = GST_DEBUG_FUNCPTR (gst_vfhip_filter_transform_caps);
   GST_BASE_TRANSFORM_CLASS (klass)->transform = GST_DEBUG_FUNCPTR (gst_vfhip_filter_transform);
+  GST_BASE_TRANSFORM_CLASS (klass)->generate_output = GST_DEBUG_FUNCPTR (di_generate_output);
+  GST_BASE_TRANSFORM_CLASS (klass)->sink_event = GST_DEBUG_FUNCPTR (di_sink_event);
+  GST_BASE_TRANSFORM_CLASS (klass)->query = GST_DEBUG_FUNCPTR (di_query);
 
   g_object_class_install_property (oc, PROP_METHOD, g_param_spec_enum ("method", "Method", "Deinterlacing algorithm",
           di_method_type (), VFHIP_DEINTERLACE_BOB, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
@@ -204,6 +256,7 @@ gst_vfhip_deinterlace_class_init (GstVfHipDeinterlaceClass * klass)
   g_object_class_install_property (oc, PROP_DEVICE_ID, g_param_spec_int ("device-id", "Device ID",
           "GPU ordinal to run on (-1: $VFHIP_DEVICE, else 0)", -1, 63, GST_VFHIP_DEFAULT_DEVICE_ID, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
 
+  g_object_class_install_property (oc, PROP_ASYNC_DEPTH, gst_vfhip_async_depth_pspec ());
   gst_element_class_add_static_pad_template (ec, &di_sink_template);
   gst_element_class_add_static_pad_template (ec, &di_src_template);
   gst_element_class_set_static_metadata (ec, "HIP Video Deinterlace", "Filter/Effect/Video/Deinterlace",
@@ -217,6 +270,8 @@ gst_vfhip_deinterlace_init (GstVfHipDeinterlace * self)
   self->field_layout = FIELDS_AUTO;
   self->motion_threshold = 0.1;
   self->device_id = GST_VFHIP_DEFAULT_DEVICE_ID;
+  self->async.submit = di_async_submit;
+  self->async.wait = di_async_wait;
 }
 
 gboolean

@@ -192,6 +192,10 @@ int vfhip_deinterlace_process_device (VfHipDeinterlace *h, const VfHipFrame *in,
  * batch, of frame 0 the handle's stored history; afterwards the history is the last frame of the batch */
 int vfhip_deinterlace_process_device_batch (VfHipDeinterlace *h, const VfHipFrame *in0, VfHipFrame *out0,
     size_t in_frame_pitch, size_t out_frame_pitch, int n_frames, const VfHipDeinterlaceParams *params, void *stream);
+/* pipelined host path, like vfhip_convertscale_submit / _wait; frames are deinterlaced in submission order */
+int vfhip_deinterlace_submit (VfHipDeinterlace *h, const VfHipFrame *in, VfHipFrame *out, const VfHipDeinterlaceParams *params);
+int vfhip_deinterlace_wait (VfHipDeinterlace *h);
+int vfhip_deinterlace_in_flight (VfHipDeinterlace *h);
 int vfhip_deinterlace_reset (VfHipDeinterlace *h);                                            /* drop the 1-frame history */
 void vfhip_deinterlace_cleanup (VfHipDeinterlace *h);
 void vfhip_deinterlace_free (VfHipDeinterlace *h);

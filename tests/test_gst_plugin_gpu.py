@@ -342,9 +342,11 @@ def test_no_per_frame_leak_in_the_element_shells():
     ("vfhipvideofilter brightness=0.1 sharpness=0.4 noise=0.2", ("BGRA", 320, 240), ("BGRA", 320, 240)),
     ("vfhipvideofilter gamma=1.4 sepia=0.3", ("NV12", 320, 240), ("NV12", 320, 240)),
     ("vfhiptransform method=clockwise crop-left=8", ("I420", 320, 240), ("I420", 320, 240)),
+    ("vfhipdeinterlace method=greedyh field-layout=top-field-first motion-threshold=0.05", ("NV12", 320, 240), ("NV12", 320, 240)),
+    ("vfhipdeinterlace method=weave", ("BGRA", 320, 240), ("BGRA", 320, 240)),
     ("vfhipoverlay location=LOGO relative-x=0.5 y=20 alpha=0.7", ("BGRA", 320, 240), ("BGRA", 320, 240)),
 ])
-@pytest.mark.parametrize("n", [1, 4])
+@pytest.mark.parametrize("n", [1, 5])
 def test_async_depth_other_elements(tmp_path, element, cin, cout, n):
     """async-depth=1 on the GstVideoFilter-based elements: same frames, same order (noise uses the per-frame counter), none
     lost at EOS"""
