@@ -682,6 +682,7 @@ typedef struct
   GstVideoInfo out_info;
   gboolean have_out_info;
   guint64 n_frames;
+  GstVfHipPinStats pin;                         /* recurring pageable input memories are page-locked in place */
 } GstVfHipCompositor;
 typedef struct
 {
@@ -898,6 +899,7 @@ comp_aggregate (GstAggregator * agg, gboolean timeout)
     bufs[i] = gst_aggregator_pad_pop_buffer (GST_AGGREGATOR_PAD (cpad));
     if (!bufs[i] || !cpad->have_info || cpad->alpha == 0.0)
       continue;
+    gst_vfhip_pin_foreign_memory (bufs[i], &self->pin);
     if (!gst_video_frame_map (&frames[i], &cpad->info, bufs[i], (GstMapFlags) (GST_MAP_READ | gst_vfhip_map_flag (bufs[i], gst_vfhip_element_device (self)))))
       continue;
     comp_pad_rect (self, cpad, GST_VIDEO_INFO_PAR_N (&self->out_info), GST_VIDEO_INFO_PAR_D (&self->out_info), &w, &h, &xo, &yo);
@@ -944,6 +946,24 @@ done:
   }
   g_free (pads); g_free (frames); g_free (bufs); g_free (refs);
   return (GstFlowReturn) rc;
+}
+
+/* upstream of every sink pad is offered the device allocator (memory:HIPMemory caps) or the pinned host one, plus video meta */
+static gboolean
+comp_propose_allocation (GstAggregator * agg, GstAggregatorPad * pad, GstQuery * decide_query, GstQuery * query)
+{
+  GstCaps *caps = NULL;
+  GstAllocator *a;
+  GstAllocationParams params;
+  (void) pad; (void) decide_query;
+  gst_query_parse_allocation (query, &caps, NULL);
+  a = gst_vfhip_caps_has_hip_feature (caps) ? gst_vfhip_device_allocator_get (gst_vfhip_element_device (agg)) : gst_vfhip_pinned_allocator_get ();
+  gst_allocation_params_init (&params);
+  params.align = 63;
+  gst_query_add_allocation_param (query, a, &params);
+  gst_query_add_allocation_meta (query, GST_VIDEO_META_API_TYPE, NULL);
+  gst_object_unref (a);
+  return TRUE;
 }
 
 static gboolean
@@ -1056,6 +1076,7 @@ gst_vfhip_compositor_class_init (GstVfHipCompositorClass * klass)
   ac->negotiated_src_caps = GST_DEBUG_FUNCPTR (comp_negotiated_src_caps);
   ac->aggregate = GST_DEBUG_FUNCPTR (comp_aggregate);
   ac->stop = GST_DEBUG_FUNCPTR (comp_stop);
+  ac->propose_allocation = GST_DEBUG_FUNCPTR (comp_propose_allocation);
 
   g_object_class_install_property (oc, PROP_BACKGROUND, g_param_spec_enum ("background", "Background", "Background type",
           comp_background_type (), VFHIP_BG_CHECKER, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
