@@ -680,7 +680,7 @@ typedef struct
   gint device_id, background;
   gboolean zero_size_is_unscaled;
   GstVideoInfo out_info;
-  gboolean have_out_info;
+  gboolean have_out_info, out_is_device;
   guint64 n_frames;
   GstVfHipPinStats pin;                         /* recurring pageable input memories are page-locked in place */
 } GstVfHipCompositor;
@@ -692,7 +692,7 @@ typedef struct
 enum { PROP_0, PROP_BACKGROUND, PROP_ZERO_SIZE_IS_UNSCALED, PROP_DEVICE_ID };
 
 static GstStaticPadTemplate comp_src_template = GST_STATIC_PAD_TEMPLATE ("src", GST_PAD_SRC, GST_PAD_ALWAYS,
-    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE (VFHIP_COMP_FORMATS)));
+    GST_STATIC_CAPS (GST_VFHIP_CAPS (VFHIP_COMP_FORMATS)));
 /* sink pads also take memory:HIPMemory buffers from upstream vfhip elements (gstvfhipmemory.c) */
 static GstStaticPadTemplate comp_sink_template = GST_STATIC_PAD_TEMPLATE ("sink_%u", GST_PAD_SINK, GST_PAD_REQUEST,
     GST_STATIC_CAPS (GST_VFHIP_CAPS (VFHIP_COMP_FORMATS)));
@@ -810,6 +810,11 @@ comp_update_src_caps (GstAggregator * agg, GstCaps * caps, GstCaps ** ret)
     return GST_AGGREGATOR_FLOW_NEED_DATA;                 /* no pad has caps yet */
   if (fn <= 0 || fd <= 0) { fn = 25; fd = 1; }
   size = gst_caps_new_simple ("video/x-raw", "width", G_TYPE_INT, bw, "height", G_TYPE_INT, bh, "framerate", GST_TYPE_FRACTION, fn, fd, NULL);
+  {                                                           /* the output may stay in HBM for a downstream vfhip element */
+    GstCaps *both = gst_vfhip_caps_both_memories (size);
+    gst_caps_unref (size);
+    size = both;
+  }
   tmpl = gst_static_pad_template_get_caps (&comp_src_template);
   *ret = gst_caps_intersect (size, tmpl);
   gst_caps_unref (size); gst_caps_unref (tmpl);
@@ -842,6 +847,7 @@ comp_negotiated_src_caps (GstAggregator * agg, GstCaps * caps)
   if (!gst_video_info_from_caps (&self->out_info, caps))
     return FALSE;
   self->have_out_info = TRUE;
+  self->out_is_device = gst_vfhip_caps_has_hip_feature (caps);
   if (!self->renderer && !(self->renderer = vfhip_compositor_new (self->device_id))) {
     GST_ERROR_OBJECT (self, "no HIP renderer: %s", vfhip_last_error_string ());
     return FALSE;
@@ -915,10 +921,10 @@ comp_aggregate (GstAggregator * agg, gboolean timeout)
     rc = GST_FLOW_EOS;
     goto done;
   }
-  alloc = gst_vfhip_pinned_allocator_get ();
+  alloc = self->out_is_device ? gst_vfhip_device_allocator_get (gst_vfhip_element_device (self)) : gst_vfhip_pinned_allocator_get ();
   outbuf = gst_buffer_new_allocate (alloc, GST_VIDEO_INFO_SIZE (&self->out_info), NULL);
   gst_object_unref (alloc);
-  if (!outbuf || !gst_video_frame_map (&out, &self->out_info, outbuf, GST_MAP_WRITE)) {
+  if (!outbuf || !gst_video_frame_map (&out, &self->out_info, outbuf, (GstMapFlags) (GST_MAP_WRITE | gst_vfhip_map_flag (outbuf, gst_vfhip_element_device (self))))) {
     if (outbuf) gst_buffer_unref (outbuf);
     rc = GST_FLOW_ERROR;
     goto done;

@@ -361,3 +361,16 @@ def test_async_depth_other_elements(tmp_path, element, cin, cout, n):
         outs.append(np.fromfile(path, np.uint8))
     assert outs[0].size == outs[1].size and outs[0].size > 0 and outs[0].size % n == 0
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_compositor_output_in_hip_memory(tmp_path):
+    """the composited frame handed to a downstream vfhip element as memory:HIPMemory gives the same bytes as through system memory"""
+    a, b = tmp_path / "hip.raw", tmp_path / "sys.raw"
+    for path, mid in ((a, hipcaps('BGRA', 320, 240)), (b, caps('BGRA', 320, 240))):
+        r = gst_env.launch(f"vfhipcompositor name=comp background=white sink_1::xpos=40 sink_1::ypos=30 sink_1::alpha=0.6 ! {mid} ! vfhipvideofilter sepia=0.5 ! "
+                           f"{caps('BGRA', 320, 240)} ! filesink location={path} "
+                           f"videotestsrc num-buffers=3 ! {caps('BGRA', 320, 240)} ! comp. videotestsrc num-buffers=3 pattern=ball ! {caps('NV12', 160, 120)} ! comp.")
+        assert r.returncode == 0, r.stderr
+    x, y = np.fromfile(a, np.uint8), np.fromfile(b, np.uint8)
+    assert x.size == y.size == 3 * 320 * 240 * 4 and np.array_equal(x, y)
+    ok(f"vfhipcompositor name=comp ! fakesink videotestsrc num-buffers=3 ! {caps('BGRA', 320, 240)} ! comp.")         # HIPMemory straight into fakesink

@@ -72,7 +72,7 @@ def test_compositor_api():
         assert nick in t
     assert "GstAggregator" in t and "GstChildProxy" in t and "sink_%u" in t and "On request" in t
     assert "primary + 2" in t
-    assert t.count("(string)BGRA, (string)RGBA, (string)NV12, (string)I420 }") == 3          # src, sink_%u in both memories
+    assert t.count("(string)BGRA, (string)RGBA, (string)NV12, (string)I420 }") == 4          # src and sink_%u, each in both memories
     src = open(gst_env.PLUGIN_DIR + "/gstvfhipcompositor.c").read()
     for prop in ("xpos", "ypos", "width", "height", "alpha", "operator", "sizing-policy", "zorder"):
         assert f'("{prop}"' in src
