@@ -19,7 +19,9 @@
 
 #define GST_CAT_DEFAULT gst_vfhip_debug
 
-#if GST_CHECK_VERSION (1, 16, 0)
+/* -DVFHIP_COMPOSITOR_PLAIN_AGGREGATOR selects the GstAggregator variant (the one this repository compiles and tests) on any
+ * GStreamer version */
+#if GST_CHECK_VERSION (1, 16, 0) && !defined (VFHIP_COMPOSITOR_PLAIN_AGGREGATOR)
 #include <gst/video/gstvideoaggregator.h>
 
 #define VFHIP_COMP_FORMATS "{ BGRA, RGBA, NV12, I420 }"
@@ -529,7 +531,7 @@ gst_vfhip_compositor_register (GstPlugin * plugin)
   return ok;
 }
 
-#else /* GStreamer < 1.16: no GstVideoAggregator in gst-plugins-base */
+#else /* GStreamer < 1.16 (no GstVideoAggregator in gst-plugins-base), or VFHIP_COMPOSITOR_PLAIN_AGGREGATOR */
 
 /* A frame-synchronous compositor directly on GstAggregator (which IS in gst-plugins-base 1.14): every aggregate() takes
  * the next buffer of each sink pad, composites them in zorder and pushes one output frame.  Same element name, pad
