@@ -176,7 +176,7 @@ static int setup_plane (PlaneCfg &pc, int w, int h, int ow, int oh, int n)
   vertical_taps (h, oh, vt);
   if (ow == w) pc.hmode = 0;
   else if (n == 1 && w == 2 * ow && (oh == h || h == 2 * oh)) pc.hmode = 2;
-  else if (n == 1) { pc.hmode = 1; pc.hinc = ow > 1 ? (uint32_t) ((((uint64_t) (w - 1)) << 16) / (uint64_t) (ow - 1)) - 1 : 0; }
+  else if (n == 1) { pc.hmode = 1; pc.hinc = (ow > 1 && w > 1) ? (uint32_t) ((((uint64_t) (w - 1)) << 16) / (uint64_t) (ow - 1)) - 1 : 0; }   // a one-sample line is replicated
   else {
     pc.hmode = 3;
     ht.assign ((size_t) ow * 4, 0);
@@ -391,7 +391,7 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
     }
   }
   h->hscale_on = (method == VFHIP_SCALE_BILINEAR && h->rw != in->width) ? 1 : 0;
-  h->hinc = h->rw > 1 ? (uint32_t) ((((uint64_t) (in->width - 1)) << 16) / (uint64_t) (h->rw - 1)) - 1 : 0;
+  h->hinc = (h->rw > 1 && in->width > 1) ? (uint32_t) ((((uint64_t) (in->width - 1)) << 16) / (uint64_t) (h->rw - 1)) - 1 : 0;   // a one-pixel line is replicated
   h->vfirst = in->height > h->rh + 2 ? 1 : 0;      // GstVideoScaler pass order (oracle/gst114.c rule 3)
   VFHIP_CHECK_HIP (hipMalloc (&h->d_vtab, vt.size () * sizeof (int)));
   VFHIP_CHECK_HIP (hipMemcpy (h->d_vtab, vt.data (), vt.size () * sizeof (int), hipMemcpyHostToDevice));

@@ -345,7 +345,7 @@ __global__ __launch_bounds__ (256) void k_cs_taps (const CsParams p)
   int xa = dx, xb = dx, f = 0;
   if (p.hscale_on) {
     const uint32_t t = (uint32_t) dx * p.hinc;
-    xa = (int) (t >> 16); f = (int) ((t >> 8) & 0xff); xb = min (xa + 1, p.in_w - 1);
+    xa = min ((int) (t >> 16), p.in_w - 1); f = (int) ((t >> 8) & 0xff); xb = min (xa + 1, p.in_w - 1);
   }
   const int cw = (p.in_w + 1) >> 1, chh = (p.in_h + 1) >> 1;
   const uint32_t X = 0x80808080u, K1 = 0x01010101u;
@@ -493,7 +493,7 @@ __global__ __launch_bounds__ (256) void k_cs_generic (const CsParams p)
     int xa = dx, xb = dx, f = 0;
     if (p.hscale_on) {
       const uint32_t t = (uint32_t) dx * p.hinc;
-      xa = (int) (t >> 16); f = (int) ((t >> 8) & 0xff); xb = min (xa + 1, p.in_w - 1);
+      xa = min ((int) (t >> 16), p.in_w - 1); f = (int) ((t >> 8) & 0xff); xb = min (xa + 1, p.in_w - 1);
     }
     int a0[4], b0[4], a1[4], b1[4];
     cs_tap (p, in, xa, i0, a0); cs_tap (p, in, xb, i0, b0);

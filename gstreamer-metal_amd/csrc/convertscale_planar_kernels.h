@@ -109,7 +109,7 @@ __device__ __forceinline__ int plane_htap (const PlaneScaleParams &p, const uint
     case 0: return row[p.n * x + c];
     case 1: {
       const uint32_t t = (uint32_t) x * p.hinc;
-      const int i = (int) (t >> 16), f = (int) ((t >> 8) & 0xff), i1 = min (i + 1, p.w - 1);
+      const int i = min ((int) (t >> 16), p.w - 1), f = (int) ((t >> 8) & 0xff), i1 = min (i + 1, p.w - 1);
       return (row[i] * (256 - f) + row[i1] * f) >> 8;
     }
     case 2: return (row[2 * x] + row[2 * x + 1] + 1) >> 1;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__ (256) void k_scale_plane (const PlaneScaleParams p)
       switch (p.hmode) {
         case 1: {
           const uint32_t t = (uint32_t) x * p.hinc;
-          const int i = (int) (t >> 16), f = (int) ((t >> 8) & 0xff), j1 = min (i + 1, p.w - 1);
+          const int i = min ((int) (t >> 16), p.w - 1), f = (int) ((t >> 8) & 0xff), j1 = min (i + 1, p.w - 1);
           const int a = r0[i] + (((r1[i] - r0[i]) * wt + 128) >> 8), b = r0[j1] + (((r1[j1] - r0[j1]) * wt + 128) >> 8);
           v = (a * (256 - f) + b * f) >> 8; break;
         }

@@ -165,7 +165,7 @@ void gst114_vtaps (int in_h, int out_h, int y, int *i0, int *i1, int *w)
 
 uint32_t gst114_hinc (int in_w, int out_w)
 {
-  if (out_w <= 1) return 0;
+  if (out_w <= 1 || in_w <= 1) return 0;           /* a one-sample line is replicated (the formula below would wrap to -1) */
   return (uint32_t) ((((uint64_t) (in_w - 1)) << 16) / (uint64_t) (out_w - 1)) - 1;
 }
 

@@ -339,3 +339,14 @@ def test_i420_half_extremes_and_full_size_batch(vfhip, oracle):
     want = oracle.convertscale("I420", w, hs, top, "bt2020", "mpeg2", "bilinear", "BGRA", ow, hs // 2)
     assert np.array_equal(out[0, :hs // 2], want)
     cs.close()
+
+
+@pytest.mark.parametrize("ifmt,ofmt,w,h,ow,oh", [("BGRA", "BGRA", 1, 9, 30, 20), ("I420", "I420", 2, 15, 116, 92), ("RGBA", "I420", 2, 28, 76, 111),
+                                                 ("NV12", "BGRA", 2, 2, 64, 64), ("BGRA", "NV12", 1, 8, 9, 8)])
+def test_one_sample_lines_are_replicated(vfhip, oracle, ifmt, ofmt, w, h, ow, oh):
+    """a plane that is one sample wide: GStreamer's 16.16 increment formula would wrap to -1 there; both sides replicate the
+    sample instead (found by tools/fuzz_gst_exact.py — the kernel used to index far outside the row)"""
+    raw = np.random.default_rng(w * 100 + h).integers(0, 256, vfhip.plane_layout(ifmt, w, h)[1], dtype=np.uint8)
+    got, _ = run(vfhip, ifmt, w, h, raw, "bt709", "jpeg", "bilinear", ofmt, ow, oh)
+    want = oracle.convertscale(ifmt, w, h, raw, "bt709", "jpeg", "bilinear", ofmt, ow, oh)
+    assert np.array_equal(np.asarray(got).reshape(-1), np.asarray(want).reshape(-1))

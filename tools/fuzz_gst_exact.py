@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""One-off fuzz of the gst-exact convertscale cells on the GPU against the oracle: random formats, sizes, methods, matrices,
+sitings.  Prints every mismatch; exit status 1 if there is one.  usage: fuzz_gst_exact.py [cases] [seed]"""
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gstreamer-metal_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import oracle_lib  # noqa: E402
+import vfhip  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+orc = oracle_lib.load()
+bad = 0
+kernels = {}
+for case in range(N):
+    ifmt = ["NV12", "I420", "BGRA", "RGBA", "UYVY", "YUY2"][rng.integers(6)]
+    yuv_out_ok = ifmt in ("NV12", "I420", "BGRA", "RGBA")
+    ofmt = ["BGRA", "RGBA", "NV12", "I420"][rng.integers(4 if yuv_out_ok else 2)]
+    method = ["bilinear", "nearest", "bicubic"][rng.integers(3)] if ofmt in ("BGRA", "RGBA") else "bilinear"
+    big = rng.integers(4) == 0
+    w, h, ow, oh = (int(v) for v in rng.integers(2, 700 if big else 120, 4))
+    if rng.integers(5) == 0:
+        ow, oh = max(w // 2, 1), max(h // 2, 1)                     # exact halves: the fast paths
+        w, h = 2 * ow, 2 * oh
+    if ofmt in ("NV12", "I420"):
+        h, oh = max(h, 8), max(oh, 8)                                # GStreamer 1.14 mishandles tiny 4:2:0 outputs
+    if method == "bicubic" and not all(i == o or math.ceil(4 * max(1.0, i / o)) <= min(i, 64) for i, o in ((w, ow), (h, oh))):
+        method = "bilinear"
+    col, site = ["bt601", "bt709", "bt2020"][rng.integers(3)], ["jpeg", "mpeg2"][rng.integers(2)]
+    raw = rng.integers(0, 256, vfhip.plane_layout(ifmt, w, h)[1], dtype=np.uint8)
+    cs = vfhip.ConvertScale(0)
+    try:
+        cs.configure(ifmt, w, h, ofmt, ow, oh, method=method, colorimetry=col, chroma_site=site)
+        got = cs.process(raw)
+        k = cs.kernel_name
+    finally:
+        cs.close()
+    kernels[k] = kernels.get(k, 0) + 1
+    if k == "k_cs_metal":
+        continue                                                     # an unpinned cell (not gst-exact): nothing to compare
+    want = orc.convertscale(ifmt, w, h, raw, col, site, method, ofmt, ow, oh)
+    if not np.array_equal(np.asarray(got).reshape(-1), np.asarray(want).reshape(-1)):
+        bad += 1
+        d = (np.asarray(got).reshape(-1) != np.asarray(want).reshape(-1)).sum()
+        print("MISMATCH", ifmt, (w, h), "->", ofmt, (ow, oh), method, col, site, k, d, "bytes", flush=True)
+print("cases", N, "mismatches", bad, "kernels", kernels)
+sys.exit(1 if bad else 0)
