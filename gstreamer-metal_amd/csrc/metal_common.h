@@ -251,8 +251,11 @@ __device__ __forceinline__ void store_block (const OutImg &o, int bx, int by, co
       }
       return;
     }
-    default: {   // UYVY / YUY2: one macro-pixel per block row; an odd last column is dropped
-      if (bx >= o.w / 2) return;
+    default: {   // UYVY / YUY2: one macro-pixel per block row.  The reference dispatches width/2 macro-pixels
+      // (metalconvertscale_shaders.h:210) and leaves the half macro-pixel of an odd width UNWRITTEN (whatever the
+      // pool buffer held); here it is written from the edge pixel (callers clamp q to the last column — the clamp
+      // the reference's own p1 carries at :217), so every byte of the output is defined.
+      if (bx >= (o.w + 1) / 2) return;
 #pragma unroll
       for (int dy = 0; dy < 2; dy++) {
         if (y0 + dy >= o.h) break;

@@ -193,9 +193,10 @@ static void store_image (const MrImg *o, const uint32_t *q)
           else { o->p[1][(size_t) by * o->s[1] + bx] = (uint8_t) quant8 (U); o->p[2][(size_t) by * o->s[2] + bx] = (uint8_t) quant8 (V); }
         }
       break;
-    default:
+    default:   /* an odd width's last half macro-pixel: unwritten by the reference (width/2 threads, shaders.h:210); written
+                  here from the clamped edge pixel (the reference's p1 clamp, :217) so the output is fully defined */
       for (int y = 0; y < h; y++)
-        for (int bx = 0; bx < w / 2; bx++) {
+        for (int bx = 0; bx < (w + 1) / 2; bx++) {
           const F4 c0 = unpack_rgba8 (Q (2 * bx, y)), c1 = unpack_rgba8 (Q (2 * bx + 1, y));
           float ya, ua, va, yb, ub, vb;
           rgb_to_yuv (c0.r, c0.g, c0.b, o->m709, &ya, &ua, &va);

@@ -45,7 +45,8 @@ FORMATS6 = ["BGRA", "RGBA", "NV12", "I420", "UYVY", "YUY2"]
 @pytest.mark.parametrize("ofmt", FORMATS6)
 def test_convertscale_metal_matrix(vfhip, metalref, ifmt, ofmt):
     """the reference's full 6x6 format matrix (tests/test-convertscale.sh:62-99 shapes), metal numerics, with scaling"""
-    for (w, h, ow, oh, method) in [(64, 36, 40, 30, "bilinear"), (33, 17, 66, 35, "nearest"), (48, 32, 48, 32, "bilinear")]:
+    for (w, h, ow, oh, method) in [(64, 36, 40, 30, "bilinear"), (33, 17, 66, 35, "nearest"), (48, 32, 48, 32, "bilinear"),
+                                  (40, 30, 37, 21, "bilinear")]:      # odd output width: every byte of a packed row is defined
         raw = smooth(ifmt, w, h, 3)
         cs = vfhip.ConvertScale(0)
         cs.configure(ifmt, w, h, ofmt, ow, oh, method=method, numerics="metal", colorimetry="bt709")
