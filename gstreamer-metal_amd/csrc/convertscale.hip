@@ -23,6 +23,7 @@ static const int kRgb2Yuv[3][9] = {
 
 struct PlaneCfg {                 // stage-2 set-up of one output plane (gst-exact, 4:2:0 outputs)
   int w = 0, h = 0, ow = 0, oh = 0, n = 1, hmode = 0, vscale_on = 0, vfirst = 0;
+  int step = 1, off = 0, dup_last = 0;      // packed 4:2:2: bytes between samples, offset of the first one, spare-slot rule
   uint32_t hinc = 0;
   int *d_vtab = nullptr, *d_htab = nullptr;
 };
@@ -92,6 +93,40 @@ static double cubic_k (double a)
   return 0.0;
 }
 
+// GstVideoScaler's integer taps: floor(off + w * 2^prec) with a bisection on `off` (from .5, at most 64 steps) until they
+// sum to 2^prec.  Exact .5 ties have no such `off`: the search ends a few ulps below .5 and double rounding lifts the
+// LARGER tap (probed on the real element, oracle/gst114.c gst114_linear_taps; round-half-up is wrong on every tie).
+static double tap_offset (const double *m, int cnt, int prec)
+{
+  const double mul = (double) (1 << prec);
+  double lo = 0.0, hi = 1.0, off = 0.5;
+  for (int it = 0; it < 64; it++) {
+    int s = 0;
+    for (int l = 0; l < cnt; l++) s += (int) std::floor (off + m[l] * mul);
+    if (s == (1 << prec)) break;
+    if (lo == hi) break;
+    if (s < (1 << prec)) { if (off > lo) lo = off; off += (hi - lo) / 2; }
+    else { if (off < hi) hi = off; off -= (hi - lo) / 2; }
+  }
+  return off;
+}
+
+// 2-tap linear set-up for output sample j of an in -> out line: source indices and the two integer taps
+static void linear_taps (int in, int out, int j, int prec, int *i0, int *i1, int *t0, int *t1)
+{
+  double x = ((j + 0.5) / out) * in - 0.5;          // this order: the quotient first
+  x = x < 0.0 ? 0.0 : (x > in - 1.0 ? in - 1.0 : x);
+  const int xi = (int) std::floor (x);
+  double w0 = 1.0 - std::fabs (x - xi), w1 = 1.0 - std::fabs (x - (xi + 1));
+  if (w0 < 0.0) w0 = 0.0;
+  if (w1 < 0.0) w1 = 0.0;
+  const double sum = w0 + w1, m[2] = { w0 / sum, w1 / sum };
+  const double off = tap_offset (m, 2, prec), mul = (double) (1 << prec);
+  *i0 = xi < 0 ? 0 : (xi > in - 1 ? in - 1 : xi);
+  *i1 = xi + 1 > in - 1 ? in - 1 : xi + 1;
+  *t0 = (int) std::floor (off + m[0] * mul); *t1 = (int) std::floor (off + m[1] * mul);
+}
+
 static int cubic_n_taps (int in, int out)
 {
   const double scale = (double) in / (double) out;
@@ -118,15 +153,7 @@ static int cubic_table (int in, int out, std::vector<int2> &tab)
       if (cnt > 0 && pos[cnt - 1] == k) m[cnt - 1] += w[l] / sum;
       else { pos[cnt] = k; m[cnt] = w[l] / sum; cnt++; }
     }
-    double lo = 0.0, hi = 1.0, off = 0.5;            // rounding offset that makes the 6-bit taps sum to 64
-    for (int it = 0; it < 64; it++) {
-      int s = 0;
-      for (int l = 0; l < cnt; l++) s += (int) std::floor (off + m[l] * 64.0);
-      if (s == 64) break;
-      if (lo == hi) break;
-      if (s < 64) { if (off > lo) lo = off; off += (hi - lo) / 2; }
-      else { if (off < hi) hi = off; off -= (hi - lo) / 2; }
-    }
+    const double off = tap_offset (m, cnt, 6);      // rounding offset that makes the 6-bit taps sum to 64
     for (int l = 0; l < n; l++)
       tab[(size_t) j * n + l] = l < cnt ? make_int2 (pos[l], (int) std::floor (off + m[l] * 64.0)) : make_int2 (pos[cnt - 1], 0);
   }
@@ -155,37 +182,29 @@ static void vertical_taps (int in_h, int out_h, std::vector<int> &vt)
   vt.assign ((size_t) out_h * 4, 0);
   for (int y = 0; y < out_h; y++) {
     int i0 = y, i1 = y, w = 0;
-    if (out_h != in_h) {
-      const double p = (y + 0.5) * in_h / out_h - 0.5;
-      const int i = (int) std::floor (p);
-      w = (int) std::floor ((p - i) * 256.0 + 0.5);
-      i0 = i < 0 ? 0 : (i > in_h - 1 ? in_h - 1 : i);
-      i1 = i + 1 < 0 ? 0 : (i + 1 > in_h - 1 ? in_h - 1 : i + 1);
-    }
+    if (out_h != in_h) { int t0; linear_taps (in_h, out_h, y, 8, &i0, &i1, &t0, &w); }   // the line function uses the second tap only
     vt[4 * y] = i0; vt[4 * y + 1] = i1; vt[4 * y + 2] = w;
   }
 }
 
 // stage-2 configuration of one plane (rules: oracle/gst114.c gst114_scale_plane)
-static int setup_plane (PlaneCfg &pc, int w, int h, int ow, int oh, int n)
+static int setup_plane (PlaneCfg &pc, int w, int h, int ow, int oh, int n, bool table = false)
 {
   pc = PlaneCfg ();
-  pc.w = w; pc.h = h; pc.ow = ow; pc.oh = oh; pc.n = n;
+  pc.w = w; pc.h = h; pc.ow = ow; pc.oh = oh; pc.n = n; pc.step = n;
   pc.vscale_on = oh != h; pc.vfirst = h > oh + 2;
   std::vector<int> vt, ht;
   vertical_taps (h, oh, vt);
   if (ow == w) pc.hmode = 0;
-  else if (n == 1 && w == 2 * ow && (oh == h || h == 2 * oh)) pc.hmode = 2;
-  else if (n == 1) { pc.hmode = 1; pc.hinc = (ow > 1 && w > 1) ? (uint32_t) ((((uint64_t) (w - 1)) << 16) / (uint64_t) (ow - 1)) - 1 : 0; }   // a one-sample line is replicated
+  else if (n == 1 && !table && w == 2 * ow && (oh == h || h == 2 * oh)) pc.hmode = 2;
+  else if (n == 1 && !table) { pc.hmode = 1; pc.hinc = (ow > 1 && w > 1) ? (uint32_t) ((((uint64_t) (w - 1)) << 16) / (uint64_t) (ow - 1)) - 1 : 0; }   // a one-sample line is replicated
   else {
     pc.hmode = 3;
     ht.assign ((size_t) ow * 4, 0);
     for (int x = 0; x < ow; x++) {
-      const double p = (x + 0.5) * w / ow - 0.5;
-      const int i = (int) std::floor (p);
-      ht[4 * x] = i < 0 ? 0 : (i > w - 1 ? w - 1 : i);
-      ht[4 * x + 1] = i + 1 < 0 ? 0 : (i + 1 > w - 1 ? w - 1 : i + 1);
-      ht[4 * x + 2] = (int) std::floor ((p - i) * 64.0 + 0.5);
+      int t0;
+      linear_taps (w, ow, x, 6, &ht[4 * x], &ht[4 * x + 1], &t0, &ht[4 * x + 2]);
+      if (t0 + ht[4 * x + 2] != 64) return set_error (VFHIP_ERR_UNSUPPORTED, "6-bit taps of column %d (%d -> %d) do not sum to 64", x, w, ow);
     }
   }
   int rc = upload_ints (vt, &pc.d_vtab);
@@ -301,8 +320,14 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
   const bool in_yuv = in->format == VFHIP_FORMAT_NV12 || in->format == VFHIP_FORMAT_I420;
   const bool out_420 = out->format == VFHIP_FORMAT_NV12 || out->format == VFHIP_FORMAT_I420;
   // 4:2:0 outputs: pinned for the 2-tap method, no borders, and (YUV -> YUV) an unchanged matrix (no re-matrixing step)
-  const bool staged = numerics == VFHIP_NUMERICS_GST_EXACT && in_420_or_rgb && out_420 && method == VFHIP_SCALE_BILINEAR &&
-                      !h->add_borders && (!in_yuv || (in->color_matrix == out->color_matrix && in->chroma_site == out->chroma_site));
+  // packed 4:2:2 outputs (from all six formats) and packed -> 4:2:0 under the same conditions.  Not pinned: a 2-pixel-wide
+  // packed frame scaled horizontally (GStreamer 1.14 emits out-of-line garbage for it) -> metal arithmetic
+  const bool out_packed = out->format == VFHIP_FORMAT_UYVY || out->format == VFHIP_FORMAT_YUY2;
+  const bool any_yuv_in = in_yuv || in_packed;
+  const bool staged = numerics == VFHIP_NUMERICS_GST_EXACT && method == VFHIP_SCALE_BILINEAR && !h->add_borders &&
+                      ((in_420_or_rgb && out_420) || out_packed || (in_packed && out_420)) &&
+                      !(out_packed && in->width == 2 && out->width != 2) &&
+                      (!any_yuv_in || (in->color_matrix == out->color_matrix && in->chroma_site == out->chroma_site));
   if (method == VFHIP_SCALE_BICUBIC) {
     const int iw = in->width, ih = in->height, ow = out->width, oh = out->height;
     if (numerics != VFHIP_NUMERICS_GST_EXACT || !(in_420_or_rgb || in_packed) || !out_rgb || h->add_borders)
@@ -349,6 +374,26 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
     h->need_convert = in->format != out->format;
     h->need_scale = iw != ow || ih != oh;
     h->n_out_planes = out->format == VFHIP_FORMAT_NV12 ? 2 : 3;
+    if (out_packed) {
+      // videoscale on a packed frame: three interleaved lines (luma every 2 bytes, U and V every 4), each scaled like
+      // NV12's chroma plane (6-bit table taps), vertical pass over every byte
+      const int yuy2 = out->format == VFHIP_FORMAT_YUY2;
+      int rc = setup_plane (h->plane[0], iw, ih, ow, oh, 1, true);
+      if (!rc) rc = setup_plane (h->plane[1], (iw + 1) / 2, ih, (ow + 1) / 2, oh, 1, true);
+      if (!rc) rc = setup_plane (h->plane[2], (iw + 1) / 2, ih, (ow + 1) / 2, oh, 1, true);
+      if (rc) return rc;
+      h->plane[0].step = 2; h->plane[0].off = yuy2 ? 0 : 1; h->plane[0].dup_last = ow & 1;
+      h->plane[1].step = 4; h->plane[1].off = yuy2 ? 1 : 0;
+      h->plane[2].step = 4; h->plane[2].off = yuy2 ? 3 : 2;
+      for (int k = 0; k < 3; k++) h->plane[k].vfirst = ih > oh + 2;
+      if (h->need_convert && h->need_scale) {
+        h->mid_bytes = (((size_t) 4 * ((iw + 1) / 2) + 15) / 16 * 16) * ih + 1024;
+        VFHIP_CHECK_HIP (hipMalloc (&h->mid, h->mid_bytes));
+      }
+      h->kernel = VfHipConvertScale::K_STAGED; h->kernel_name = "k_cs_staged_422";
+      h->configured = true;
+      return VFHIP_OK;
+    }
     int rc = setup_plane (h->plane[0], iw, ih, ow, oh, 1);
     if (rc) return rc;
     if (out->format == VFHIP_FORMAT_NV12) rc = setup_plane (h->plane[1], (iw + 1) / 2, (ih + 1) / 2, (ow + 1) / 2, (oh + 1) / 2, 2);
@@ -380,13 +425,7 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
   } else {
     for (int y = 0; y < h->rh; y++) {
       int i0 = y, i1 = y, w = 0;
-      if (h->rh != in->height) {
-        const double p = (y + 0.5) * in->height / h->rh - 0.5;
-        const int i = (int) std::floor (p);
-        w = (int) std::floor ((p - i) * 256.0 + 0.5);
-        i0 = i < 0 ? 0 : (i > in->height - 1 ? in->height - 1 : i);
-        i1 = i + 1 < 0 ? 0 : (i + 1 > in->height - 1 ? in->height - 1 : i + 1);
-      }
+      if (h->rh != in->height) { int t0; linear_taps (in->height, h->rh, y, 8, &i0, &i1, &t0, &w); }
       vt[4 * y] = i0; vt[4 * y + 1] = i1; vt[4 * y + 2] = w;
     }
   }
@@ -433,9 +472,41 @@ static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
 {
   const int iw = h->in.width, ih = h->in.height;
   const bool out_planar = h->out.format == VFHIP_FORMAT_I420;
+  const bool out_packed = h->out.format == VFHIP_FORMAT_UYVY || h->out.format == VFHIP_FORMAT_YUY2;
+  const bool in_packed = h->in.format == VFHIP_FORMAT_UYVY || h->in.format == VFHIP_FORMAT_YUY2;
   // where stage 1 writes / stage 2 reads: the output itself (no scaling), the input itself (no conversion), or `mid`
   VfHipFrame mid {};
   mid.info = h->out; mid.info.width = iw; mid.info.height = ih;
+  if (out_packed) {
+    if (h->need_convert && h->need_scale) { mid.data[0] = h->mid; mid.stride[0] = (int) (((size_t) 4 * ((iw + 1) / 2) + 15) / 16 * 16); }
+    else if (h->need_convert) mid = *out;
+    else mid = *in;
+    if (h->need_convert) {
+      ToPackedParams p {};
+      for (int k = 0; k < 3; k++) { p.in[k] = (const uint8_t *) in->data[k]; p.is[k] = in->stride[k]; }
+      p.out = (uint8_t *) mid.data[0]; p.os = mid.stride[0];
+      p.w = iw; p.h = ih; p.in_fmt = h->in.format; p.out_yuy2 = h->out.format == VFHIP_FORMAT_YUY2;
+      p.cosited_in = h->in.chroma_site == VFHIP_CHROMA_SITE_H_COSITED; p.cosited_out = h->out.chroma_site == VFHIP_CHROMA_SITE_H_COSITED;
+      for (int k = 0; k < 9; k++) p.c[k] = kRgb2Yuv[h->out.color_matrix][k];
+      dim3 grid ((unsigned) (((iw + 1) / 2 + 63) / 64), (unsigned) ((ih + 3) / 4));
+      hipLaunchKernelGGL (k_to_packed422, grid, dim3 (64, 4), 0, s, p);
+      VFHIP_CHECK_HIP (hipGetLastError ());
+    }
+    if (h->need_scale || !h->need_convert) {
+      for (int k = 0; k < 3; k++) {
+        const PlaneCfg &pc = h->plane[k];
+        PlaneScaleParams p {};
+        p.in = (const uint8_t *) mid.data[0] + pc.off; p.is = mid.stride[0];
+        p.out = (uint8_t *) out->data[0] + pc.off; p.os = out->stride[0];
+        p.w = pc.w; p.h = pc.h; p.ow = pc.ow; p.oh = pc.oh; p.n = 1; p.istep = p.ostep = pc.step; p.dup_last = pc.dup_last; p.hmode = pc.hmode;
+        p.vscale_on = pc.vscale_on; p.vfirst = pc.vfirst; p.hinc = pc.hinc; p.vtab = pc.d_vtab; p.htab = pc.d_htab;
+        dim3 grid ((unsigned) ((pc.ow + 63) / 64), (unsigned) ((pc.oh + 3) / 4));
+        hipLaunchKernelGGL (k_scale_plane, grid, dim3 (64, 4), 0, s, p);
+        VFHIP_CHECK_HIP (hipGetLastError ());
+      }
+    }
+    return VFHIP_OK;
+  }
   if (h->need_convert && h->need_scale) {
     const size_t ys = ((size_t) iw + 15) / 16 * 16, cs = ((size_t) 2 * ((iw + 1) / 2) + 15) / 16 * 16;
     uint8_t *b = (uint8_t *) h->mid;
@@ -457,6 +528,15 @@ static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
       p.cosited = h->out.chroma_site == VFHIP_CHROMA_SITE_H_COSITED;
       for (int k = 0; k < 9; k++) p.c[k] = kRgb2Yuv[h->out.color_matrix][k];
       hipLaunchKernelGGL (k_rgb_to_yuv420, grid, dim3 (64, 4), 0, s, p);
+    } else if (in_packed) {
+      FromPackedParams p {};
+      p.in = (const uint8_t *) in->data[0]; p.is = in->stride[0];
+      p.y = (uint8_t *) mid.data[0]; p.ys = mid.stride[0];
+      p.u = (uint8_t *) mid.data[1]; p.us = mid.stride[1];
+      p.v = (uint8_t *) mid.data[2]; p.vs = mid.stride[2];
+      p.w = iw; p.h = ih; p.in_yuy2 = h->in.format == VFHIP_FORMAT_YUY2; p.planar = out_planar;
+      p.cosited_in = h->in.chroma_site == VFHIP_CHROMA_SITE_H_COSITED; p.cosited_out = h->out.chroma_site == VFHIP_CHROMA_SITE_H_COSITED;
+      hipLaunchKernelGGL (k_packed422_to_420, grid, dim3 (64, 4), 0, s, p);
     } else {
       RepackParams p {};
       p.iy = (const uint8_t *) in->data[0]; p.iys = in->stride[0];
@@ -476,7 +556,7 @@ static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
       PlaneScaleParams p {};
       p.in = (const uint8_t *) mid.data[k]; p.is = mid.stride[k];
       p.out = (uint8_t *) out->data[k]; p.os = out->stride[k];
-      p.w = pc.w; p.h = pc.h; p.ow = pc.ow; p.oh = pc.oh; p.n = pc.n; p.hmode = pc.hmode;
+      p.w = pc.w; p.h = pc.h; p.ow = pc.ow; p.oh = pc.oh; p.n = pc.n; p.istep = p.ostep = pc.n; p.hmode = pc.hmode;
       p.vscale_on = pc.vscale_on; p.vfirst = pc.vfirst; p.hinc = pc.hinc; p.vtab = pc.d_vtab; p.htab = pc.d_htab;
       dim3 grid ((unsigned) ((pc.ow + 63) / 64), (unsigned) ((pc.oh + 3) / 4));
       hipLaunchKernelGGL (k_scale_plane, grid, dim3 (64, 4), 0, s, p);

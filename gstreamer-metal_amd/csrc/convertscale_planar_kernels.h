@@ -1,4 +1,5 @@
-// csrc/convertscale_planar_kernels.h — gst-exact cells of vfhipconvertscale whose OUTPUT is 4:2:0 (NV12 / I420).
+// csrc/convertscale_planar_kernels.h — gst-exact cells of vfhipconvertscale whose OUTPUT is 4:2:0 (NV12 / I420) or packed
+// 4:2:2 (UYVY / YUY2).
 //
 // GStreamer's `videoconvert ! videoscale` does these in two steps and so do we (bit-exact, oracle/gst114.c
 // gst114_rgb_to_yuv420 / gst114_scale_plane; rules pinned by probing the real 1.14 elements):
@@ -32,7 +33,7 @@ __global__ __launch_bounds__ (256) void k_rgb_to_yuv420 (const Rgb2YuvParams p)
   // vertical averages (a+b+1)>>1 of the converted chroma at columns x-1, x, x+1 (edge rules: see oracle/gst114.c)
   int xs[3];
   xs[1] = x;
-  if (p.cosited) { xs[0] = x > 0 ? x - 1 : 0; xs[2] = (k == cw - 1) ? x : min (x + 1, p.w - 1); }
+  if (p.cosited) { xs[0] = x > 0 ? x - 1 : 0; xs[2] = (k == cw - 1 && k > 0) ? x : min (x + 1, p.w - 1); }   // the last sample ignores its right neighbour, unless it is also the first
   else { xs[0] = x; xs[2] = min (x + 1, p.w - 1); }
   int su[3], sv[3];
 #pragma unroll
@@ -96,7 +97,10 @@ struct PlaneScaleParams {
   const uint8_t *in; int is;
   uint8_t *out; int os;
   int w, h, ow, oh, n;
-  int hmode;               // 0: no horizontal scaling, 1: edge-aligned 16.16 (1 x u8), 2: pair average (1 x u8), 3: table (2 x u8, 6-bit taps)
+  int istep, ostep;        // bytes between consecutive samples of this plane (n for a plane of its own; 2 / 4 for the
+                           // luma / chroma lines interleaved in a packed 4:2:2 frame); hmode 1 / 2 need istep == 1
+  int dup_last;            // packed luma, odd width: the spare luma slot repeats the last sample (as GStreamer does)
+  int hmode;               // 0: no horizontal scaling, 1: edge-aligned 16.16 (1 x u8), 2: pair average (1 x u8), 3: table (6-bit taps)
   int vscale_on, vfirst;
   uint32_t hinc;
   const int *vtab;         // oh * {i0, i1, w, 0}
@@ -106,7 +110,7 @@ struct PlaneScaleParams {
 __device__ __forceinline__ int plane_htap (const PlaneScaleParams &p, const uint8_t *row, int x, int c)
 {
   switch (p.hmode) {
-    case 0: return row[p.n * x + c];
+    case 0: return row[p.istep * x + c];
     case 1: {
       const uint32_t t = (uint32_t) x * p.hinc;
       const int i = min ((int) (t >> 16), p.w - 1), f = (int) ((t >> 8) & 0xff), i1 = min (i + 1, p.w - 1);
@@ -115,7 +119,7 @@ __device__ __forceinline__ int plane_htap (const PlaneScaleParams &p, const uint
     case 2: return (row[2 * x] + row[2 * x + 1] + 1) >> 1;
     default: {
       const int i0 = p.htab[4 * x], i1 = p.htab[4 * x + 1], t = p.htab[4 * x + 2];
-      return (row[p.n * i0 + c] * (64 - t) + row[p.n * i1 + c] * t + 32) >> 6;
+      return (row[p.istep * i0 + c] * (64 - t) + row[p.istep * i1 + c] * t + 32) >> 6;
     }
   }
 }
@@ -130,7 +134,7 @@ __global__ __launch_bounds__ (256) void k_scale_plane (const PlaneScaleParams p)
   for (int c = 0; c < p.n; c++) {
     int v;
     if (!p.vscale_on) v = plane_htap (p, r0, x, c);
-    else if (p.hmode == 0) { const int a = r0[p.n * x + c], b = r1[p.n * x + c]; v = a + (((b - a) * wt + 128) >> 8); }
+    else if (p.hmode == 0) { const int a = r0[p.istep * x + c], b = r1[p.istep * x + c]; v = a + (((b - a) * wt + 128) >> 8); }
     else if (p.vfirst) {
       // vertical first: the horizontal taps run on vertically scaled samples -> scale each source column the tap touches
       switch (p.hmode) {
@@ -146,7 +150,7 @@ __global__ __launch_bounds__ (256) void k_scale_plane (const PlaneScaleParams p)
         }
         default: {
           const int j0 = p.htab[4 * x], j1 = p.htab[4 * x + 1], t = p.htab[4 * x + 2];
-          const int a0 = r0[p.n * j0 + c], a1 = r1[p.n * j0 + c], b0 = r0[p.n * j1 + c], b1 = r1[p.n * j1 + c];
+          const int a0 = r0[p.istep * j0 + c], a1 = r1[p.istep * j0 + c], b0 = r0[p.istep * j1 + c], b1 = r1[p.istep * j1 + c];
           const int a = a0 + (((a1 - a0) * wt + 128) >> 8), b = b0 + (((b1 - b0) * wt + 128) >> 8);
           v = (a * (64 - t) + b * t + 32) >> 6; break;
         }
@@ -155,8 +159,141 @@ __global__ __launch_bounds__ (256) void k_scale_plane (const PlaneScaleParams p)
       const int a = plane_htap (p, r0, x, c), b = plane_htap (p, r1, x, c);
       v = a + (((b - a) * wt + 128) >> 8);
     }
-    p.out[(size_t) y * p.os + p.n * x + c] = (uint8_t) v;
+    p.out[(size_t) y * p.os + p.ostep * x + c] = (uint8_t) v;
+    if (p.dup_last && x == p.ow - 1) p.out[(size_t) y * p.os + p.ostep * (x + 1) + c] = (uint8_t) v;
   }
+}
+
+// ---- packed 4:2:2 (UYVY / YUY2) outputs and packed -> 4:2:0: videoconvert's conversions at the input size ------------
+// (oracle/gst114.c gst114_rgb_to_packed422 / gst114_yuv420_to_packed422 / gst114_packed422_swizzle /
+// gst114_packed422_to_yuv420; every rule pinned by probing the real 1.14 element, tests/golden/convertscale_gst114_packedout.npz)
+
+// horizontally up-sampled chroma at full-resolution column x of a row of cw samples `step` bytes apart
+__device__ __forceinline__ int chroma_up_h (const uint8_t *row, int step, int cw, int x, int cosited)
+{
+  const int k = x >> 1;
+  const int c0 = row[k * step];
+  if (cosited) return (x & 1) ? (c0 + row[min (k + 1, cw - 1) * step] + 1) >> 1 : c0;
+  return (x & 1) ? (3 * c0 + row[min (k + 1, cw - 1) * step] + 2) >> 2 : (3 * c0 + row[max (k - 1, 0) * step] + 2) >> 2;
+}
+
+// the three full-resolution columns the horizontal 2:1 down-sampling of chroma sample k reads, and its result
+__device__ __forceinline__ void chroma_down_cols (int k, int cw, int w, int cosited, int xs[3])
+{
+  const int x = 2 * k;
+  xs[1] = x;
+  if (cosited) { xs[0] = x > 0 ? x - 1 : 0; xs[2] = (k == cw - 1 && k > 0) ? x : min (x + 1, w - 1); }
+  else { xs[0] = x; xs[2] = min (x + 1, w - 1); }
+}
+__device__ __forceinline__ int chroma_down (const int s[3], int cosited)
+{
+  return cosited ? (s[0] + 2 * s[1] + s[2] + 2) >> 2 : (s[1] + s[2] + 1) >> 1;
+}
+
+struct ToPackedParams {
+  const uint8_t *in[3]; int is[3];
+  uint8_t *out; int os;
+  int w, h, in_fmt, out_yuy2, cosited_in, cosited_out;
+  int c[9];                // RGB -> YUV matrix (RGB inputs)
+};
+
+// one lane = one macro-pixel (two luma samples + U + V) of the packed output
+__global__ __launch_bounds__ (256) void k_to_packed422 (const ToPackedParams p)
+{
+  const int k = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  const int cw = (p.w + 1) >> 1;
+  if (k >= cw || y >= p.h) return;
+  const int x = 2 * k, x1 = min (x + 1, p.w - 1);
+  int Y0, Y1, U, V;
+  switch (p.in_fmt) {
+    case VFHIP_FORMAT_BGRA: case VFHIP_FORMAT_RGBA: {
+      const int ro = p.in_fmt == VFHIP_FORMAT_RGBA ? 0 : 2, bo = 2 - ro;
+      const uint8_t *row = p.in[0] + (size_t) y * p.is[0];
+      int xs[3], su[3], sv[3];
+      chroma_down_cols (k, cw, p.w, p.cosited_out, xs);
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        const uint8_t *px = row + 4 * xs[t];
+        const int r = px[ro], g = px[1], b = px[bo];
+        su[t] = ((p.c[3] * r + p.c[4] * g + p.c[5] * b) >> 8) + 128;
+        sv[t] = ((p.c[6] * r + p.c[7] * g + p.c[8] * b) >> 8) + 128;
+      }
+      U = chroma_down (su, p.cosited_out); V = chroma_down (sv, p.cosited_out);
+      const uint8_t *a = row + 4 * x, *b = row + 4 * x1;
+      Y0 = ((p.c[0] * a[ro] + p.c[1] * a[1] + p.c[2] * a[bo]) >> 8) + 16;
+      Y1 = ((p.c[0] * b[ro] + p.c[1] * b[1] + p.c[2] * b[bo]) >> 8) + 16;
+      break;
+    }
+    case VFHIP_FORMAT_I420: {          // fast path: chroma row y >> 1 as it is
+      const int j = y >> 1;
+      U = p.in[1][(size_t) j * p.is[1] + k]; V = p.in[2][(size_t) j * p.is[2] + k];
+      Y0 = p.in[0][(size_t) y * p.is[0] + x]; Y1 = p.in[0][(size_t) y * p.is[0] + x1];
+      break;
+    }
+    case VFHIP_FORMAT_NV12: {          // generic path: up h (input siting), up v (3:1 with the nearer row), down h (output siting)
+      const int chh = (p.h + 1) >> 1, j = y >> 1, jn = (y & 1) ? min (j + 1, chh - 1) : max (j - 1, 0);
+      const uint8_t *r0 = p.in[1] + (size_t) j * p.is[1], *r1 = p.in[1] + (size_t) jn * p.is[1];
+      int xs[3], su[3], sv[3];
+      chroma_down_cols (k, cw, p.w, p.cosited_out, xs);
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        su[t] = (3 * chroma_up_h (r0, 2, cw, xs[t], p.cosited_in) + chroma_up_h (r1, 2, cw, xs[t], p.cosited_in) + 2) >> 2;
+        sv[t] = (3 * chroma_up_h (r0 + 1, 2, cw, xs[t], p.cosited_in) + chroma_up_h (r1 + 1, 2, cw, xs[t], p.cosited_in) + 2) >> 2;
+      }
+      U = chroma_down (su, p.cosited_out); V = chroma_down (sv, p.cosited_out);
+      Y0 = p.in[0][(size_t) y * p.is[0] + x]; Y1 = p.in[0][(size_t) y * p.is[0] + x1];
+      break;
+    }
+    default: {                         // UYVY <-> YUY2: byte swizzle
+      const uint8_t *m = p.in[0] + (size_t) y * p.is[0] + 4 * k;
+      const int yo = p.in_fmt == VFHIP_FORMAT_YUY2 ? 0 : 1;
+      Y0 = m[yo]; Y1 = x + 1 < p.w ? m[yo + 2] : m[yo]; U = m[1 - yo]; V = m[3 - yo];
+      break;
+    }
+  }
+  uint8_t *d = p.out + (size_t) y * p.os + 4 * k;
+  const uint32_t v = p.out_yuy2 ? (uint32_t) Y0 | (uint32_t) U << 8 | (uint32_t) Y1 << 16 | (uint32_t) V << 24
+                                : (uint32_t) U | (uint32_t) Y0 << 8 | (uint32_t) V << 16 | (uint32_t) Y1 << 24;
+  if (((uintptr_t) d & 3) == 0) *reinterpret_cast<uint32_t *> (d) = v;
+  else { d[0] = (uint8_t) v; d[1] = (uint8_t) (v >> 8); d[2] = (uint8_t) (v >> 16); d[3] = (uint8_t) (v >> 24); }
+}
+
+struct FromPackedParams {
+  const uint8_t *in; int is;
+  uint8_t *y, *u, *v; int ys, us, vs;     // NV12: u = uv plane, v unused
+  int w, h, in_yuy2, planar, cosited_in, cosited_out;
+};
+
+// one lane = one 4:2:0 chroma sample (and the 2x2 luma block under it)
+__global__ __launch_bounds__ (256) void k_packed422_to_420 (const FromPackedParams p)
+{
+  const int k = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+  const int cw = (p.w + 1) >> 1, chh = (p.h + 1) >> 1;
+  if (k >= cw || j >= chh) return;
+  const int yo = p.in_yuy2 ? 0 : 1, uo = 1 - yo, vo = 3 - yo;
+  const uint8_t *r0 = p.in + (size_t) (2 * j) * p.is, *r1 = p.in + (size_t) min (2 * j + 1, p.h - 1) * p.is;
+  int U, V;
+  if (p.planar) {                      // fast path: vertical pair average, no horizontal step
+    U = (r0[4 * k + uo] + r1[4 * k + uo] + 1) >> 1; V = (r0[4 * k + vo] + r1[4 * k + vo] + 1) >> 1;
+    p.u[(size_t) j * p.us + k] = (uint8_t) U; p.v[(size_t) j * p.vs + k] = (uint8_t) V;
+  } else {                             // generic path: up h (input siting), vertical pair average, down h (output siting)
+    int xs[3], su[3], sv[3];
+    chroma_down_cols (k, cw, p.w, p.cosited_out, xs);
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      su[t] = (chroma_up_h (r0 + uo, 4, cw, xs[t], p.cosited_in) + chroma_up_h (r1 + uo, 4, cw, xs[t], p.cosited_in) + 1) >> 1;
+      sv[t] = (chroma_up_h (r0 + vo, 4, cw, xs[t], p.cosited_in) + chroma_up_h (r1 + vo, 4, cw, xs[t], p.cosited_in) + 1) >> 1;
+    }
+    U = chroma_down (su, p.cosited_out); V = chroma_down (sv, p.cosited_out);
+    p.u[(size_t) j * p.us + 2 * k] = (uint8_t) U; p.u[(size_t) j * p.us + 2 * k + 1] = (uint8_t) V;
+  }
+#pragma unroll
+  for (int d = 0; d < 2; d++)
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const int xx = 2 * k + e, yy = 2 * j + d;
+      if (xx < p.w && yy < p.h) p.y[(size_t) yy * p.ys + xx] = p.in[(size_t) yy * p.is + 2 * xx + yo];
+    }
 }
 
 }  // namespace vfhip

@@ -187,6 +187,27 @@ cs_ensure_renderer (GstVfHipConvertScale * self)
   return self->renderer != NULL;
 }
 
+/* Output caps that do not say which matrix / chroma siting they mean: take what `videoconvert ! videoscale` would.
+ * There videoconvert runs at the INPUT size, so GStreamer's by-height defaults of its output are those of the input
+ * height (not of the scaled frame), and it copies colorimetry / chroma-site from YUV input caps that carry them when
+ * the output is YUV too (chroma-site only when the subsampling is unchanged).  Without this a 720p -> 360p NV12 -> UYVY
+ * conversion would re-matrix bt709 -> bt601, which the CPU pipeline does not do. */
+static void
+cs_effective_out_info (GstCaps * incaps, GstCaps * outcaps, const GstVideoInfo * in, GstVideoInfo * out)
+{
+  const GstStructure *si = gst_caps_get_structure (incaps, 0), *so = gst_caps_get_structure (outcaps, 0);
+  const gboolean both_yuv = GST_VIDEO_INFO_IS_YUV (in) && GST_VIDEO_INFO_IS_YUV (out);
+  GstVideoInfo at_in_size;
+  gst_video_info_init (&at_in_size);
+  gst_video_info_set_format (&at_in_size, GST_VIDEO_INFO_FORMAT (out), GST_VIDEO_INFO_WIDTH (in), GST_VIDEO_INFO_HEIGHT (in));
+  if (!gst_structure_has_field (so, "colorimetry"))
+    out->colorimetry = (both_yuv && gst_structure_has_field (si, "colorimetry")) ? in->colorimetry : at_in_size.colorimetry;
+  if (!gst_structure_has_field (so, "chroma-site") && GST_VIDEO_INFO_IS_YUV (out)) {
+    const gboolean same_sub = both_yuv && in->finfo->w_sub[1] == out->finfo->w_sub[1] && in->finfo->h_sub[1] == out->finfo->h_sub[1];
+    out->chroma_site = (same_sub && gst_structure_has_field (si, "chroma-site")) ? in->chroma_site : at_in_size.chroma_site;
+  }
+}
+
 static gboolean
 cs_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
 {
@@ -196,6 +217,7 @@ cs_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
     GST_ERROR_OBJECT (self, "unparsable caps");
     return FALSE;
   }
+  cs_effective_out_info (incaps, outcaps, &self->in_info, &self->out_info);
   same = GST_VIDEO_INFO_FORMAT (&self->in_info) == GST_VIDEO_INFO_FORMAT (&self->out_info) &&
       GST_VIDEO_INFO_WIDTH (&self->in_info) == GST_VIDEO_INFO_WIDTH (&self->out_info) &&
       GST_VIDEO_INFO_HEIGHT (&self->in_info) == GST_VIDEO_INFO_HEIGHT (&self->out_info);

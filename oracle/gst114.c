@@ -154,13 +154,37 @@ int gst114_convertscale_packed422 (const uint8_t *in, int is, int yuy2, int w, i
 
 /* ---- videoscale, 4 x u8 ---------------------------------------------------------------- */
 
+/* GstVideoResampler's 2-tap linear set-up, quantised the way GstVideoScaler does it: position x = ((j+.5)/out)*in - .5 in
+ * IEEE double IN THAT ORDER, clamped to [0, in-1]; weights 1-|x-i| normalised; integer taps floor(off + w * 2^prec) with a
+ * bisection on `off` (from .5, at most 64 steps) until they sum to 2^prec.  The bisection is what decides exact .5 ties:
+ * there is no `off` that splits them, the search ends a few ulps below .5 and the LARGER tap rounds up through double
+ * rounding (probed on 67 -> 64, 21 -> 448, 67 -> 256 ...: plain round-half-up is wrong on every tie). */
+void gst114_linear_taps (int in, int out, int j, int prec, int *i0, int *i1, int *t0, int *t1)
+{
+  double x = ((j + 0.5) / out) * in - 0.5;
+  x = x < 0.0 ? 0.0 : (x > in - 1.0 ? in - 1.0 : x);
+  const int xi = (int) __builtin_floor (x);
+  double w0 = 1.0 - __builtin_fabs (x - xi), w1 = 1.0 - __builtin_fabs (x - (xi + 1));
+  if (w0 < 0.0) w0 = 0.0;
+  if (w1 < 0.0) w1 = 0.0;
+  const double sum = w0 + w1, m0 = w0 / sum, m1 = w1 / sum, mul = (double) (1 << prec);
+  double lo = 0.0, hi = 1.0, off = 0.5;
+  int a = 0, b = 0;
+  for (int it = 0; it < 64; it++) {
+    a = (int) __builtin_floor (off + m0 * mul); b = (int) __builtin_floor (off + m1 * mul);
+    if (a + b == (1 << prec)) break;
+    if (lo == hi) break;
+    if (a + b < (1 << prec)) { if (off > lo) lo = off; off += (hi - lo) / 2; }
+    else { if (off < hi) hi = off; off -= (hi - lo) / 2; }
+  }
+  *i0 = clampi (xi, 0, in - 1); *i1 = clampi (xi + 1, 0, in - 1); *t0 = a; *t1 = b;
+}
+
 void gst114_vtaps (int in_h, int out_h, int y, int *i0, int *i1, int *w)
 {
-  /* centre-aligned; weight quantised to 8 bits */
-  double p = (y + 0.5) * in_h / out_h - 0.5;
-  int i = (int) __builtin_floor (p);
-  *w = (int) __builtin_floor ((p - i) * 256.0 + 0.5);
-  *i0 = clampi (i, 0, in_h - 1); *i1 = clampi (i + 1, 0, in_h - 1);
+  /* centre-aligned; 8-bit taps; the line function uses the second tap only: s1 + (((s2 - s1) * w + 128) >> 8) */
+  int t0;
+  gst114_linear_taps (in_h, out_h, y, 8, i0, i1, &t0, w);
 }
 
 uint32_t gst114_hinc (int in_w, int out_w)
@@ -355,7 +379,8 @@ int gst114_scale_4u8 (const uint8_t *in, int is, int w, int h, uint8_t *out, int
  *   4:4:4 -> 4:2:0: vertical (a+b+1)>>1 first (an odd last row pairs with itself), then horizontal:
  *   not co-sited: (a+b+1)>>1 (an odd last column pairs with itself); h-co-sited (mpeg2): (l + 2c + r + 2)>>2 with the
  *   left tap of the first sample AND the right tap of the LAST sample replaced by the centre (GStreamer quirk: the last
- *   sample ignores its right neighbour even when it exists). */
+ *   sample ignores its right neighbour even when it exists — except on a two-sample line, where the only chroma sample is
+ *   first and last and does use it). */
 static const int RGB2YUV[3][9] = {
   {  66, 129,  25,  -38,  -74, 112,  112,  -94, -18 },   /* bt601  */
   {  47, 157,  16,  -26,  -87, 112,  112, -102, -10 },   /* bt709  */
@@ -393,7 +418,7 @@ int gst114_rgb_to_yuv420 (const uint8_t *in, int is, int in_format, int w, int h
       int U, V;
       const int x = 2 * k;
       if (cosited) {
-        const int l = x > 0 ? x - 1 : 0, r = k == cw - 1 ? x : (x + 1 < w ? x + 1 : w - 1);
+        const int l = x > 0 ? x - 1 : 0, r = (k == cw - 1 && k > 0) ? x : (x + 1 < w ? x + 1 : w - 1);
         U = (ru[l] + 2 * ru[x] + ru[r] + 2) >> 2; V = (rv[l] + 2 * rv[x] + rv[r] + 2) >> 2;
       } else {
         const int r = x + 1 < w ? x + 1 : w - 1;
@@ -413,6 +438,18 @@ int gst114_rgb_to_yuv420 (const uint8_t *in, int is, int in_format, int w, int h
  *   exactly halved horizontally and vertically unchanged or exactly halved: then pairs average, (a+b+1)>>1;
  *   horizontal, 2 x u8 plane (NV12 chroma): centre-aligned with 6-bit taps: t = round(frac*64), (a(64-t) + b t + 32)>>6;
  *   pass order per plane: vertical first iff plane_in_h > plane_out_h + 2. */
+/* centre-aligned 2-tap with 6-bit taps (GstVideoScaler's generic n-tap u8 line function at 2 taps) */
+static void hscale_centre6 (const uint8_t *in, int is, int w, int h, int n, uint8_t *out, int os, int ow)
+{
+  for (int x = 0; x < ow; x++) {
+    int i0, i1, t0, t1;
+    gst114_linear_taps (w, ow, x, 6, &i0, &i1, &t0, &t1);
+    for (int y = 0; y < h; y++)
+      for (int c = 0; c < n; c++)
+        out[(size_t) y * os + n * x + c] = (uint8_t) clampi ((in[(size_t) y * is + n * i0 + c] * t0 + in[(size_t) y * is + n * i1 + c] * t1 + 32) >> 6, 0, 255);
+  }
+}
+
 static void hscale_plane (const uint8_t *in, int is, int w, int h, int n, uint8_t *out, int os, int ow, int half)
 {
   if (n == 1 && half) {
@@ -429,15 +466,7 @@ static void hscale_plane (const uint8_t *in, int is, int w, int h, int n, uint8_
       }
     return;
   }
-  for (int x = 0; x < ow; x++) {
-    const double p = (x + 0.5) * w / ow - 0.5;
-    const int i = (int) __builtin_floor (p);
-    const int t = (int) __builtin_floor ((p - i) * 64.0 + 0.5);
-    const int i0 = clampi (i, 0, w - 1), i1 = clampi (i + 1, 0, w - 1);
-    for (int y = 0; y < h; y++)
-      for (int c = 0; c < n; c++)
-        out[(size_t) y * os + n * x + c] = (uint8_t) ((in[(size_t) y * is + n * i0 + c] * (64 - t) + in[(size_t) y * is + n * i1 + c] * t + 32) >> 6);
-  }
+  hscale_centre6 (in, is, w, h, n, out, os, ow);
 }
 
 static void vscale_plane (const uint8_t *in, int is, int wb, int h, uint8_t *out, int os, int oh)
@@ -483,4 +512,191 @@ int gst114_convertscale_yuv420 (const uint8_t *yp, int ys, const uint8_t *up, in
   if (rc == 0) rc = gst114_scale_4u8 (full, w * 4, w, h, out, os, ow, oh, method);
   free (full);
   return rc;
+}
+
+/* ---- packed 4:2:2 OUTPUTS and packed -> 4:2:0 (videoconvert at the input size, then videoscale on the packed frame),
+ * pinned by probing the real elements (tools/gen_goldens.py packedout, tests/golden/convertscale_gst114_packedout.npz):
+ *   RGB -> packed: the RGB -> YUV matrix of the 4:2:0 path and only the HORIZONTAL half of its chroma step (output siting);
+ *   I420 -> packed: fast path, Y copied, chroma row y>>1 copied (no interpolation at all);
+ *   NV12 -> packed: generic path, chroma up-sampled to 4:4:4 (horizontal rule of the INPUT siting, then the 3:1 vertical
+ *     rule), then the horizontal down-sampling rule of the OUTPUT siting (note: videoconvert copies colorimetry AND
+ *     chroma-site from its input when the output caps carry no colorimetry);
+ *   UYVY <-> YUY2: byte swizzle;
+ *   packed -> I420: fast path, Y copied, chroma rows averaged in pairs (a+b+1)>>1 (an odd last row pairs with itself);
+ *   packed -> NV12: generic path, horizontal up-sample (input siting), vertical pair average, horizontal down-sample
+ *     (output siting).
+ *   videoscale on a packed frame (2-tap): Y (w samples), U and V ((w+1)/2 samples each) are three interleaved lines
+ *   scaled like NV12's chroma plane: centre-aligned 6-bit taps horizontally, the 8-bit 2-tap vertically over every byte,
+ *   vertical first iff in_h > out_h + 2.  GStreamer bug NOT restated: when the vertical pass runs first AND a horizontal
+ *   pass follows, it covers 2*w bytes only, so for an ODD width the last V sample of the intermediate line is never
+ *   written and the V outputs that tap it carry whatever the temporary line held (0 after a bare videoscale, garbage
+ *   after videoconvert).  This restatement uses the properly scaled sample; comparisons with the real element skip
+ *   those V outputs (tests/test_oracle_golden.py: undefined_v_mask). */
+static inline void pk_offsets (int yuy2, int *yo, int *uo, int *vo) { *yo = yuy2 ? 0 : 1; *uo = yuy2 ? 1 : 0; *vo = yuy2 ? 3 : 2; }
+
+static void down_h_row (const int *c, int w, int cosited, int *out)
+{
+  const int cw = (w + 1) / 2;
+  for (int k = 0; k < cw; k++) {
+    const int x = 2 * k;
+    if (cosited) {
+      const int l = x > 0 ? x - 1 : 0, r = (k == cw - 1 && k > 0) ? x : (x + 1 < w ? x + 1 : w - 1);
+      out[k] = (c[l] + 2 * c[x] + c[r] + 2) >> 2;
+    } else {
+      const int r = x + 1 < w ? x + 1 : w - 1;
+      out[k] = (c[x] + c[r] + 1) >> 1;
+    }
+  }
+}
+
+/* Y row + cw-sample U / V rows -> one packed row; an odd width's spare luma slot repeats the last luma sample */
+static void pk_store_row (uint8_t *o, int yuy2, int w, const uint8_t *y, const int *u, const int *v)
+{
+  int yo, uo, vo; pk_offsets (yuy2, &yo, &uo, &vo);
+  const int cw = (w + 1) / 2;
+  for (int k = 0; k < cw; k++) {
+    o[4 * k + yo] = y[2 * k];
+    o[4 * k + yo + 2] = y[2 * k + 1 < w ? 2 * k + 1 : w - 1];
+    o[4 * k + uo] = (uint8_t) u[k]; o[4 * k + vo] = (uint8_t) v[k];
+  }
+}
+
+int gst114_rgb_to_packed422 (const uint8_t *in, int is, int in_format, int w, int h, int matrix, int cosited, int yuy2, uint8_t *out, int os)
+{
+  if (w <= 0 || h <= 0 || matrix < 0 || matrix > 2) return -1;
+  const int *c = RGB2YUV[matrix];
+  const int ro = in_format == GST114_RGBA ? 0 : 2, bo = 2 - ro, cw = (w + 1) / 2;
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < h; y++) {
+    uint8_t *Y = malloc ((size_t) w);
+    int *u = malloc (sizeof (int) * (size_t) (2 * w + 2 * cw)), *v = u + w, *du = v + w, *dv = du + cw;
+    for (int x = 0; x < w; x++) {
+      const uint8_t *px = in + (size_t) y * is + 4 * x;
+      const int r = px[ro], g = px[1], b = px[bo];
+      Y[x] = (uint8_t) (((c[0] * r + c[1] * g + c[2] * b) >> 8) + 16);
+      u[x] = ((c[3] * r + c[4] * g + c[5] * b) >> 8) + 128;
+      v[x] = ((c[6] * r + c[7] * g + c[8] * b) >> 8) + 128;
+    }
+    down_h_row (u, w, cosited, du); down_h_row (v, w, cosited, dv);
+    pk_store_row (out + (size_t) y * os, yuy2, w, Y, du, dv);
+    free (Y); free (u);
+  }
+  return 0;
+}
+
+int gst114_yuv420_to_packed422 (const uint8_t *yp, int ys, const uint8_t *up, int us, const uint8_t *vp, int vs,
+    int planar, int w, int h, int cosited_in, int cosited_out, int yuy2, uint8_t *out, int os)
+{
+  if (w <= 0 || h <= 0) return -1;
+  const int cw = (w + 1) / 2, ch = (h + 1) / 2;
+  uint8_t *hu = NULL, *hv = NULL;
+  if (!planar) {
+    hu = malloc ((size_t) ch * w); hv = malloc ((size_t) ch * w);
+    if (!hu || !hv) { free (hu); free (hv); return -2; }
+    for (int j = 0; j < ch; j++) {
+      upsample_h (up + (size_t) j * us, 2, cw, w, cosited_in, hu + (size_t) j * w);
+      upsample_h (up + (size_t) j * us + 1, 2, cw, w, cosited_in, hv + (size_t) j * w);
+    }
+  }
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < h; y++) {
+    const int j = y >> 1;
+    int *u = malloc (sizeof (int) * (size_t) (2 * w + 2 * cw)), *v = u + w, *du = v + w, *dv = du + cw;
+    if (planar) {
+      for (int k = 0; k < cw; k++) { du[k] = up[(size_t) j * us + k]; dv[k] = vp[(size_t) j * vs + k]; }
+    } else {
+      const int jn = (y & 1) ? clampi (j + 1, 0, ch - 1) : clampi (j - 1, 0, ch - 1);
+      for (int x = 0; x < w; x++) {
+        u[x] = (3 * hu[(size_t) j * w + x] + hu[(size_t) jn * w + x] + 2) >> 2;
+        v[x] = (3 * hv[(size_t) j * w + x] + hv[(size_t) jn * w + x] + 2) >> 2;
+      }
+      down_h_row (u, w, cosited_out, du); down_h_row (v, w, cosited_out, dv);
+    }
+    pk_store_row (out + (size_t) y * os, yuy2, w, yp + (size_t) y * ys, du, dv);
+    free (u);
+  }
+  free (hu); free (hv);
+  return 0;
+}
+
+int gst114_packed422_swizzle (const uint8_t *in, int is, int in_yuy2, int w, int h, int out_yuy2, uint8_t *out, int os)
+{
+  if (w <= 0 || h <= 0) return -1;
+  const int cw = (w + 1) / 2;
+  for (int y = 0; y < h; y++)
+    for (int k = 0; k < cw; k++) {
+      const uint8_t *s = in + (size_t) y * is + 4 * k; uint8_t *d = out + (size_t) y * os + 4 * k;
+      if (in_yuy2 == out_yuy2) { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3]; }
+      else { d[0] = s[1]; d[1] = s[0]; d[2] = s[3]; d[3] = s[2]; }
+    }
+  return 0;
+}
+
+int gst114_packed422_to_yuv420 (const uint8_t *in, int is, int yuy2, int w, int h, int cosited_in, int cosited_out, int planar,
+    uint8_t *yp, int ys, uint8_t *up, int us, uint8_t *vp, int vs)
+{
+  if (w <= 0 || h <= 0) return -1;
+  int yo, uo, vo; pk_offsets (yuy2, &yo, &uo, &vo);
+  const int cw = (w + 1) / 2, ch = (h + 1) / 2;
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) yp[(size_t) y * ys + x] = in[(size_t) y * is + 2 * x + yo];
+#pragma omp parallel for schedule(static)
+  for (int j = 0; j < ch; j++) {
+    const uint8_t *r0 = in + (size_t) (2 * j) * is, *r1 = in + (size_t) (2 * j + 1 < h ? 2 * j + 1 : h - 1) * is;
+    if (planar) {
+      for (int k = 0; k < cw; k++) {
+        up[(size_t) j * us + k] = (uint8_t) ((r0[4 * k + uo] + r1[4 * k + uo] + 1) >> 1);
+        vp[(size_t) j * vs + k] = (uint8_t) ((r0[4 * k + vo] + r1[4 * k + vo] + 1) >> 1);
+      }
+    } else {
+      uint8_t *a = malloc ((size_t) 4 * w), *b = a + w, *c = b + w, *d = c + w;
+      int *u = malloc (sizeof (int) * (size_t) (2 * w + 2 * cw)), *v = u + w, *du = v + w, *dv = du + cw;
+      upsample_h (r0 + uo, 4, cw, w, cosited_in, a); upsample_h (r1 + uo, 4, cw, w, cosited_in, b);
+      upsample_h (r0 + vo, 4, cw, w, cosited_in, c); upsample_h (r1 + vo, 4, cw, w, cosited_in, d);
+      for (int x = 0; x < w; x++) { u[x] = (a[x] + b[x] + 1) >> 1; v[x] = (c[x] + d[x] + 1) >> 1; }
+      down_h_row (u, w, cosited_out, du); down_h_row (v, w, cosited_out, dv);
+      for (int k = 0; k < cw; k++) { up[(size_t) j * us + 2 * k] = (uint8_t) du[k]; up[(size_t) j * us + 2 * k + 1] = (uint8_t) dv[k]; }
+      free (a); free (u);
+    }
+  }
+  return 0;
+}
+
+/* videoscale method=bilinear on a packed 4:2:2 frame */
+int gst114_scale_packed422 (const uint8_t *in, int is, int yuy2, int w, int h, uint8_t *out, int os, int ow, int oh)
+{
+  if (w <= 0 || h <= 0 || ow <= 0 || oh <= 0) return -1;
+  int yo, uo, vo; pk_offsets (yuy2, &yo, &uo, &vo);
+  const int cw = (w + 1) / 2, cow = (ow + 1) / 2;
+  const int vfirst = h > oh + 2, hs = ow != w, vs_ = oh != h;
+  /* three planes of ints, processed in the pinned order */
+  const int mh = h > oh ? h : oh, mw = w > ow ? w : ow;
+  uint8_t *A = malloc ((size_t) 3 * mh * mw), *B = malloc ((size_t) 3 * mh * mw);
+  if (!A || !B) { free (A); free (B); return -2; }
+  for (int p = 0; p < 3; p++) {
+    const int pw = p ? cw : w, pow_ = p ? cow : ow, off = p == 0 ? yo : p == 1 ? uo : vo, step = p ? 4 : 2;
+    uint8_t *a = A + (size_t) p * mh * mw, *b = B + (size_t) p * mh * mw;
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < pw; x++) a[(size_t) y * mw + x] = in[(size_t) y * is + step * x + off];
+    int cur_w = pw, cur_h = h;
+    uint8_t *src = a, *dst = b;
+    for (int pass = 0; pass < 2; pass++) {
+      const int vertical = (pass == 0) == (vfirst != 0);
+      if (vertical && vs_) {
+        vscale_plane (src, mw, cur_w, cur_h, dst, mw, oh);
+        cur_h = oh;
+        uint8_t *t = src; src = dst; dst = t;
+      } else if (!vertical && hs) {
+        hscale_centre6 (src, mw, cur_w, cur_h, 1, dst, mw, pow_);
+        cur_w = pow_;
+        uint8_t *t = src; src = dst; dst = t;
+      }
+    }
+    for (int y = 0; y < oh; y++)
+      for (int x = 0; x < pow_; x++) out[(size_t) y * os + step * x + off] = src[(size_t) y * mw + x];
+  }
+  if (ow & 1)                                            /* spare luma slot of an odd width: GStreamer repeats the last luma sample */
+    for (int y = 0; y < oh; y++) out[(size_t) y * os + 2 * ow + yo] = out[(size_t) y * os + 2 * (ow - 1) + yo];
+  free (A); free (B);
+  return 0;
 }

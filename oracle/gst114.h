@@ -13,6 +13,7 @@ int gst114_set_threads (int n);
 void gst114_yuv_to_rgb (int matrix, int Y, int U, int V, int *r, int *g, int *b);
 int gst114_yuv420_to_rgb (const uint8_t *yp, int ys, const uint8_t *up, int us, const uint8_t *vp, int vs,
     int planar, int w, int h, int matrix, int cosited, int out_format, uint8_t *out, int os);
+void gst114_linear_taps (int in, int out, int j, int prec, int *i0, int *i1, int *t0, int *t1);
 void gst114_vtaps (int in_h, int out_h, int y, int *i0, int *i1, int *w);
 uint32_t gst114_hinc (int in_w, int out_w);
 int gst114_nearest_index (int in, int out, int j);
@@ -25,6 +26,14 @@ int gst114_scale_plane (const uint8_t *in, int is, int w, int h, int n, uint8_t 
 int gst114_packed422_to_rgb (const uint8_t *in, int is, int yuy2, int w, int h, int matrix, int cosited, int out_format, uint8_t *out, int os);
 int gst114_convertscale_packed422 (const uint8_t *in, int is, int yuy2, int w, int h, int matrix, int cosited, int out_format, int method,
     uint8_t *out, int os, int ow, int oh);
+/* packed 4:2:2 outputs / packed -> 4:2:0 (see gst114.c) */
+int gst114_rgb_to_packed422 (const uint8_t *in, int is, int in_format, int w, int h, int matrix, int cosited, int yuy2, uint8_t *out, int os);
+int gst114_yuv420_to_packed422 (const uint8_t *yp, int ys, const uint8_t *up, int us, const uint8_t *vp, int vs,
+    int planar, int w, int h, int cosited_in, int cosited_out, int yuy2, uint8_t *out, int os);
+int gst114_packed422_swizzle (const uint8_t *in, int is, int in_yuy2, int w, int h, int out_yuy2, uint8_t *out, int os);
+int gst114_packed422_to_yuv420 (const uint8_t *in, int is, int yuy2, int w, int h, int cosited_in, int cosited_out, int planar,
+    uint8_t *yp, int ys, uint8_t *up, int us, uint8_t *vp, int vs);
+int gst114_scale_packed422 (const uint8_t *in, int is, int yuy2, int w, int h, uint8_t *out, int os, int ow, int oh);
 int gst114_default_matrix (int height);
 int gst114_default_cosited (int height);
 int gst114_convertscale_yuv420 (const uint8_t *yp, int ys, const uint8_t *up, int us, const uint8_t *vp, int vs,

@@ -70,7 +70,7 @@ class Oracle:
         mat = MATRIX[colorimetry]
         L = self.lib
         yuv_in, yuv_out = fmt in ("NV12", "I420"), out_format in ("NV12", "I420")
-        if not yuv_out:
+        if out_format in ("BGRA", "RGBA"):
             out = np.zeros((oh, ow, 4), np.uint8)
             ofmt = 1 if out_format == "RGBA" else 0
             if fmt == "NV12":
@@ -92,7 +92,26 @@ class Oracle:
             if rc != 0:
                 raise RuntimeError(f"oracle rc={rc}")
             return out
-        assert method == "bilinear", "planar nearest scaling is not restated"
+        assert method == "bilinear", "planar / packed nearest and bicubic scaling are not restated"
+        if out_format in ("UYVY", "YUY2"):
+            # videoconvert at the input size -> packed frame of the output format, then videoscale on the packed frame
+            ms, yuy2 = r4(2 * w), int(out_format == "YUY2")
+            mid = np.zeros(ms * h, np.uint8)
+            if fmt == "NV12":
+                (y, ys), (uv, us) = pl
+                rc = L.gst114_yuv420_to_packed422(self._p(y), ys, self._p(uv), us, self._p(uv, 1), us, 0, w, h, cos, cos, yuy2, self._p(mid), ms)
+            elif fmt == "I420":
+                (y, ys), (u, us), (v, vs) = pl
+                rc = L.gst114_yuv420_to_packed422(self._p(y), ys, self._p(u), us, self._p(v), vs, 1, w, h, cos, cos, yuy2, self._p(mid), ms)
+            elif fmt in ("UYVY", "YUY2"):
+                rc = L.gst114_packed422_swizzle(self._p(raw), ms, int(fmt == "YUY2"), w, h, yuy2, self._p(mid), ms)
+            else:
+                rc = L.gst114_rgb_to_packed422(self._p(pl[0][0]), 4 * w, 1 if fmt == "RGBA" else 0, w, h, mat, cos, yuy2, self._p(mid), ms)
+            assert rc == 0
+            os_ = r4(2 * ow)
+            out = np.zeros(os_ * oh, np.uint8)
+            assert L.gst114_scale_packed422(self._p(mid), ms, yuy2, w, h, self._p(out), os_, ow, oh) == 0
+            return out
         # stage 1: videoconvert at the input size -> planes of the output format
         cw, ch = (w + 1) // 2, (h + 1) // 2
         Y = np.zeros((h, w), np.uint8)
@@ -100,7 +119,14 @@ class Oracle:
             C = [np.zeros((ch, 2 * cw), np.uint8)]
         else:
             C = [np.zeros((ch, cw), np.uint8), np.zeros((ch, cw), np.uint8)]
-        if not yuv_in:
+        if fmt in ("UYVY", "YUY2"):
+            planar = out_format == "I420"
+            up = C[0]
+            vp = C[1] if planar else C[0]
+            rc = L.gst114_packed422_to_yuv420(self._p(raw), r4(2 * w), int(fmt == "YUY2"), w, h, cos, cos, int(planar), self._p(Y), w,
+                                              self._p(up), up.strides[0], self._p(vp, 0 if planar else 1), vp.strides[0])
+            assert rc == 0
+        elif not yuv_in:
             src = pl[0][0]
             planar = out_format == "I420"
             up = C[0]

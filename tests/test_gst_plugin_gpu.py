@@ -374,3 +374,19 @@ def test_compositor_output_in_hip_memory(tmp_path):
     x, y = np.fromfile(a, np.uint8), np.fromfile(b, np.uint8)
     assert x.size == y.size == 3 * 320 * 240 * 4 and np.array_equal(x, y)
     ok(f"vfhipcompositor name=comp ! fakesink videotestsrc num-buffers=3 ! {caps('BGRA', 320, 240)} ! comp.")         # HIPMemory straight into fakesink
+
+
+@pytest.mark.parametrize("ifmt,iw,ih,ofmt,ow,oh", [("NV12", 1280, 720, "UYVY", 640, 360), ("BGRA", 640, 480, "YUY2", 320, 200), ("I420", 640, 360, "UYVY", 1280, 720),
+                                                   ("UYVY", 1280, 720, "I420", 640, 480), ("YUY2", 720, 576, "NV12", 1024, 576), ("UYVY", 720, 480, "YUY2", 360, 240),
+                                                   ("NV12", 1280, 720, "NV12", 640, 360), ("BGRA", 1920, 1080, "I420", 640, 480), ("I420", 1280, 720, "NV12", 854, 480)])
+def test_pixel_parity_yuv_outputs_with_cpu_elements(tmp_path, ifmt, iw, ih, ofmt, ow, oh):
+    """packed 4:2:2 / 4:2:0 outputs as real pipelines, caps WITHOUT colorimetry across an HD -> SD size change (GStreamer's
+    by-height defaults come from the input height there): vfhipconvertscale == videoconvert ! videoscale, byte for byte"""
+    a, b = tmp_path / "cpu.raw", tmp_path / "hip.raw"
+    r = gst_env.launch(f"videotestsrc num-buffers=2 ! {caps(ifmt, iw, ih)} ! tee name=t "
+                       f"t. ! queue ! videoconvert ! videoscale ! {caps(ofmt, ow, oh)} ! filesink location={a} "
+                       f"t. ! queue ! vfhipconvertscale ! {caps(ofmt, ow, oh)} ! filesink location={b}", timeout=300)
+    assert r.returncode == 0, r.stderr
+    x, y = np.fromfile(a, np.uint8), np.fromfile(b, np.uint8)
+    assert x.size == y.size and x.size > 0
+    assert np.array_equal(x, y), f"max diff {np.abs(x.astype(int) - y.astype(int)).max()}, {(x != y).sum()} bytes differ"

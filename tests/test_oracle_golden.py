@@ -55,8 +55,15 @@ MANIFEST_Y, ZY = oracle_lib.load_golden("convertscale_gst114_yuvout.npz")
 
 
 def meaningful(fmt, w, h, raw):
-    """the bytes GStreamer defines: rows without their stride padding"""
+    """the bytes GStreamer defines: rows without their stride padding (packed 4:2:2: whole macro-pixels minus the spare
+    luma slot of an odd width)"""
     out = []
+    if fmt in ("UYVY", "YUY2"):
+        stride, cw = oracle_lib.r4(2 * w), (w + 1) // 2
+        rows = np.asarray(raw[: stride * h]).reshape(h, stride)[:, : 4 * cw]
+        if w & 1:
+            rows = np.delete(rows, 2 * w + (0 if fmt == "YUY2" else 1), axis=1)
+        return rows.reshape(-1)
     for i, (off, stride) in enumerate(oracle_lib.raw_layout(fmt, w, h)[0]):
         rows = h if i == 0 else (h + 1) // 2
         wb = w if i == 0 else (w + 1) // 2 * (2 if fmt == "NV12" else 1)
@@ -70,6 +77,65 @@ def test_oracle_matches_gstreamer_yuv_outputs(oracle, case):
     got = oracle.convertscale(c["in_format"], c["w"], c["h"], ZY[c["name"] + "_in"], c["colorimetry"], c["chroma_site"],
                               c["method"], c["out_format"], c["ow"], c["oh"])
     want = ZY[c["name"] + "_out"]
+    assert np.array_equal(meaningful(c["out_format"], c["ow"], c["oh"], got), meaningful(c["out_format"], c["ow"], c["oh"], want))
+
+
+# ---- packed 4:2:2 outputs and packed -> 4:2:0 (128 vectors from the real elements) --------------------------------------
+MANIFEST_PO, ZPO = oracle_lib.load_golden("convertscale_gst114_packedout.npz")
+
+
+def gst_undefined_packed(oracle, c, frames):
+    """Two GStreamer 1.14 bugs in videoscale on packed 4:2:2 frames that no restatement can follow (oracle/gst114.c):
+    (1) a 2-pixel-wide frame scaled horizontally comes out as out-of-line garbage -> returns None (skip the case);
+    (2) vertical-first + horizontal pass on an ODD width never writes the last V sample of the intermediate line: the V
+        outputs that tap it are undefined -> they are zeroed in every frame of `frames` before the comparison."""
+    import ctypes as C
+    if c["out_format"] not in ("UYVY", "YUY2"):
+        return frames
+    w, h, ow, oh = c["w"], c["h"], c["ow"], c["oh"]
+    if w == 2 and ow != w:
+        return None
+    if not (h > oh + 2 and ow != w and oh != h and (w & 1)):
+        return frames
+    cw, cow, stride = (w + 1) // 2, (ow + 1) // 2, oracle_lib.r4(2 * ow)
+    vo = 3 if c["out_format"] == "YUY2" else 2
+    out = [np.array(f[: stride * oh]).reshape(oh, stride) for f in frames]
+    for k in range(cow):
+        i0, i1, t0, t1 = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        oracle.lib.gst114_linear_taps(cw, cow, k, 6, C.byref(i0), C.byref(i1), C.byref(t0), C.byref(t1))
+        if cw - 1 in (i0.value, i1.value):
+            for f in out:
+                f[:, 4 * k + vo] = 0
+    return [f.reshape(-1) for f in out]
+
+
+@pytest.mark.parametrize("case", MANIFEST_PO, ids=[c["name"] for c in MANIFEST_PO])
+def test_oracle_matches_gstreamer_packed_outputs(oracle, case):
+    c = case
+    got = oracle.convertscale(c["in_format"], c["w"], c["h"], ZPO[c["name"] + "_in"], c["colorimetry"], c["chroma_site"],
+                              c["method"], c["out_format"], c["ow"], c["oh"])
+    want = ZPO[c["name"] + "_out"]
+    frames = gst_undefined_packed(oracle, c, [got, want])
+    if frames is None:
+        pytest.skip("GStreamer 1.14 emits out-of-line garbage for a 2-pixel-wide packed frame scaled horizontally")
+    got, want = frames
+    assert np.array_equal(meaningful(c["out_format"], c["ow"], c["oh"], got), meaningful(c["out_format"], c["ow"], c["oh"], want))
+
+
+# ---- exact .5 ties of the tap quantisers (16 vectors from the real elements) ------------------------------------------
+MANIFEST_T, ZT = oracle_lib.load_golden("convertscale_gst114_ties.npz")
+
+
+@pytest.mark.parametrize("case", MANIFEST_T, ids=[c["name"] for c in MANIFEST_T])
+def test_oracle_matches_gstreamer_on_tap_ties(oracle, case):
+    c = case
+    got = oracle.convertscale(c["in_format"], c["w"], c["h"], ZT[c["name"] + "_in"], c["colorimetry"], c["chroma_site"],
+                              c["method"], c["out_format"], c["ow"], c["oh"])
+    want = ZT[c["name"] + "_out"]
+    if c["out_format"] in ("BGRA", "RGBA"):
+        assert np.array_equal(got.reshape(-1), want)
+        return
+    got, want = gst_undefined_packed(oracle, c, [got, want])
     assert np.array_equal(meaningful(c["out_format"], c["ow"], c["oh"], got), meaningful(c["out_format"], c["ow"], c["oh"], want))
 
 

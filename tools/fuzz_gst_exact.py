@@ -19,8 +19,7 @@ bad = 0
 kernels = {}
 for case in range(N):
     ifmt = ["NV12", "I420", "BGRA", "RGBA", "UYVY", "YUY2"][rng.integers(6)]
-    yuv_out_ok = ifmt in ("NV12", "I420", "BGRA", "RGBA")
-    ofmt = ["BGRA", "RGBA", "NV12", "I420"][rng.integers(4 if yuv_out_ok else 2)]
+    ofmt = ["BGRA", "RGBA", "NV12", "I420", "UYVY", "YUY2"][rng.integers(6)]
     method = ["bilinear", "nearest", "bicubic"][rng.integers(3)] if ofmt in ("BGRA", "RGBA") else "bilinear"
     big = rng.integers(4) == 0
     w, h, ow, oh = (int(v) for v in rng.integers(2, 700 if big else 120, 4))

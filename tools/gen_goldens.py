@@ -230,6 +230,83 @@ def gen_packed():
     print("wrote", len(cases), "packed-input cases")
 
 
+def gen_packed_outputs():
+    """cells whose OUTPUT is UYVY / YUY2 (from all six input formats) and UYVY / YUY2 -> NV12 / I420, through
+    `videoconvert ! videoscale` (bilinear) -> tests/golden/convertscale_gst114_packedout.npz"""
+    cases, arrays = [], {}
+    rng = np.random.default_rng(20261007)
+    cols, sites = ["bt601", "bt709", "bt2020"], ["jpeg", "mpeg2"]
+    fixed = [(64, 36, 64, 36), (64, 36, 32, 18), (64, 36, 100, 50), (33, 17, 33, 17), (33, 17, 16, 8), (17, 9, 40, 21), (48, 40, 20, 37),
+             (200, 8, 100, 4), (2, 2, 2, 2), (31, 30, 31, 12), (50, 20, 125, 20), (35, 29, 18, 7), (3, 5, 7, 3), (16, 16, 1, 1)]
+    pairs = [(i, o) for i in ["BGRA", "RGBA", "NV12", "I420", "UYVY", "YUY2"] for o in ["UYVY", "YUY2"]]
+    pairs += [(i, o) for i in ["UYVY", "YUY2"] for o in ["NV12", "I420"]]
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = build_helper(tmp)
+        t = 0
+        for (ifmt, ofmt) in pairs:
+            for (w, h, ow, oh) in fixed[(t % 4)::4] + [tuple(int(v) for v in rng.integers(2, 90, 4)) for _ in range(4)]:
+                col, site = cols[t % 3], sites[(t // 3) % 2]
+                if ifmt in ("BGRA", "RGBA"):
+                    size = w * h * 4
+                elif ifmt == "NV12":
+                    size = nv12_layout(w, h)[3]
+                elif ifmt == "I420":
+                    size = i420_layout(w, h)[4]
+                else:
+                    size = r4(2 * w) * h
+                raw = rng.integers(0, 256, size, dtype=np.uint8).tobytes()
+                incaps = f"video/x-raw,format={ifmt},width={w},height={h},framerate=1/1"
+                if ifmt not in ("BGRA", "RGBA"):
+                    incaps += f",colorimetry={col},chroma-site={site}"
+                out = gst_run(exe, tmp, raw, len(raw), incaps, "videoconvert ! videoscale",
+                              f"video/x-raw,format={ofmt},width={ow},height={oh},colorimetry={col},chroma-site={site}")
+                name = f"{ifmt.lower()}_to_{ofmt.lower()}_{t:03d}_{w}x{h}_to_{ow}x{oh}"
+                arrays[name + "_in"], arrays[name + "_out"] = np.frombuffer(raw, np.uint8), np.frombuffer(out, np.uint8)
+                cases.append(dict(name=name, in_format=ifmt, w=w, h=h, colorimetry=col, chroma_site=site, method="bilinear", out_format=ofmt,
+                                  ow=ow, oh=oh, in_sha256=hashlib.sha256(raw).hexdigest(), out_sha256=hashlib.sha256(out).hexdigest()))
+                t += 1
+    arrays["manifest"] = np.frombuffer(json.dumps(cases).encode(), np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "convertscale_gst114_packedout.npz"), **arrays)
+    print("wrote", len(cases), "packed-output cases")
+
+
+def gen_ties():
+    """sizes whose 2-tap weights fall on exact .5 ties of the 8-bit (vertical) or 6-bit (packed / NV12-chroma horizontal)
+    quantiser, where GstVideoScaler's bisection - not round-half-up - decides: tests/golden/convertscale_gst114_ties.npz"""
+    cases, arrays = [], {}
+    rng = np.random.default_rng(20261008)
+    todo = [("BGRA", "BGRA", 8, 67, 8, 256), ("RGBA", "BGRA", 8, 13, 8, 768), ("BGRA", "RGBA", 45, 67, 20, 64), ("NV12", "BGRA", 16, 67, 16, 256),
+            ("I420", "RGBA", 12, 21, 12, 448), ("NV12", "NV12", 134, 20, 128, 20), ("NV12", "NV12", 134, 134, 128, 512), ("I420", "I420", 90, 134, 128, 512),
+            ("BGRA", "NV12", 134, 67, 128, 256), ("NV12", "I420", 42, 26, 448, 64), ("YUY2", "YUY2", 67, 10, 64, 10), ("UYVY", "UYVY", 67, 67, 64, 256),
+            ("BGRA", "UYVY", 45, 8, 64, 8), ("I420", "YUY2", 21, 13, 448, 24), ("UYVY", "NV12", 134, 67, 128, 256), ("YUY2", "BGRA", 16, 67, 16, 256)]
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = build_helper(tmp)
+        for t, (ifmt, ofmt, w, h, ow, oh) in enumerate(todo):
+            col, site = ["bt601", "bt709"][t % 2], ["jpeg", "mpeg2"][(t // 2) % 2]
+            size = {"BGRA": w * h * 4, "RGBA": w * h * 4, "NV12": nv12_layout(w, h)[3], "I420": i420_layout(w, h)[4]}.get(ifmt, r4(2 * w) * h)
+            raw = rng.integers(0, 256, size, dtype=np.uint8).tobytes()
+            incaps = f"video/x-raw,format={ifmt},width={w},height={h},framerate=1/1"
+            if ifmt not in ("BGRA", "RGBA"):
+                incaps += f",colorimetry={col},chroma-site={site}"
+            outcaps = f"video/x-raw,format={ofmt},width={ow},height={oh}"
+            if ofmt not in ("BGRA", "RGBA"):
+                outcaps += f",colorimetry={col},chroma-site={site}"
+            out = gst_run(exe, tmp, raw, len(raw), incaps, "videoconvert ! videoscale", outcaps)
+            name = f"tie_{ifmt.lower()}_to_{ofmt.lower()}_{t:02d}_{w}x{h}_to_{ow}x{oh}"
+            arrays[name + "_in"], arrays[name + "_out"] = np.frombuffer(raw, np.uint8), np.frombuffer(out, np.uint8)
+            cases.append(dict(name=name, in_format=ifmt, w=w, h=h, colorimetry=col, chroma_site=site, method="bilinear", out_format=ofmt,
+                              ow=ow, oh=oh, in_sha256=hashlib.sha256(raw).hexdigest(), out_sha256=hashlib.sha256(out).hexdigest()))
+    arrays["manifest"] = np.frombuffer(json.dumps(cases).encode(), np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "convertscale_gst114_ties.npz"), **arrays)
+    print("wrote", len(cases), "tie cases")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ties":
+    gen_ties()
+    sys.exit(0)
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "packedout":
+    gen_packed_outputs()
+    sys.exit(0)
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "packed":
     gen_packed()
     sys.exit(0)
