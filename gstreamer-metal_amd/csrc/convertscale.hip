@@ -188,13 +188,25 @@ static void vertical_taps (int in_h, int out_h, std::vector<int> &vt)
 }
 
 // stage-2 configuration of one plane (rules: oracle/gst114.c gst114_scale_plane)
-static int setup_plane (PlaneCfg &pc, int w, int h, int ow, int oh, int n, bool table = false)
+static int nearest_index (int in, int out, int j);
+
+// `nearest`: every tap table holds the nearest source index with a zero second tap (the 2-tap formulas then return the sample)
+static int setup_plane (PlaneCfg &pc, int w, int h, int ow, int oh, int n, bool table = false, bool nearest = false)
 {
   pc = PlaneCfg ();
   pc.w = w; pc.h = h; pc.ow = ow; pc.oh = oh; pc.n = n; pc.step = n;
   pc.vscale_on = oh != h; pc.vfirst = h > oh + 2;
   std::vector<int> vt, ht;
   vertical_taps (h, oh, vt);
+  if (nearest) {
+    for (int y = 0; y < oh; y++) { vt[4 * y] = vt[4 * y + 1] = nearest_index (h, oh, y); vt[4 * y + 2] = 0; }
+    pc.vfirst = 0;
+    if (ow != w) {
+      pc.hmode = 3;
+      ht.assign ((size_t) ow * 4, 0);
+      for (int x = 0; x < ow; x++) ht[4 * x] = ht[4 * x + 1] = nearest_index (w, ow, x);
+    }
+  } else
   if (ow == w) pc.hmode = 0;
   else if (n == 1 && !table && w == 2 * ow && (oh == h || h == 2 * oh)) pc.hmode = 2;
   else if (n == 1 && !table) { pc.hmode = 1; pc.hinc = (ow > 1 && w > 1) ? (uint32_t) ((((uint64_t) (w - 1)) << 16) / (uint64_t) (ow - 1)) - 1 : 0; }   // a one-sample line is replicated
@@ -213,7 +225,7 @@ static int setup_plane (PlaneCfg &pc, int w, int h, int ow, int oh, int n, bool 
 }
 
 // GStreamer 1.14 nearest-neighbour source index: floor(((j + .5) / out) * in) in IEEE double, in that order.
-static int nearest_index (int in, int out, int j)
+static int nearest_index (int in, int out, int j)   // (declared above setup_plane)
 {
   volatile double t = ((double) j + 0.5) / (double) out;
   volatile double p = t * (double) in;
@@ -324,7 +336,7 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
   // packed frame scaled horizontally (GStreamer 1.14 emits out-of-line garbage for it) -> metal arithmetic
   const bool out_packed = out->format == VFHIP_FORMAT_UYVY || out->format == VFHIP_FORMAT_YUY2;
   const bool any_yuv_in = in_yuv || in_packed;
-  const bool staged = numerics == VFHIP_NUMERICS_GST_EXACT && method == VFHIP_SCALE_BILINEAR && !h->add_borders &&
+  const bool staged = numerics == VFHIP_NUMERICS_GST_EXACT && (method == VFHIP_SCALE_BILINEAR || method == VFHIP_SCALE_NEAREST) && !h->add_borders &&
                       ((in_420_or_rgb && out_420) || out_packed || (in_packed && out_420)) &&
                       !(out_packed && in->width == 2 && out->width != 2) &&
                       (!any_yuv_in || (in->color_matrix == out->color_matrix && in->chroma_site == out->chroma_site));
@@ -378,14 +390,15 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
       // videoscale on a packed frame: three interleaved lines (luma every 2 bytes, U and V every 4), each scaled like
       // NV12's chroma plane (6-bit table taps), vertical pass over every byte
       const int yuy2 = out->format == VFHIP_FORMAT_YUY2;
-      int rc = setup_plane (h->plane[0], iw, ih, ow, oh, 1, true);
-      if (!rc) rc = setup_plane (h->plane[1], (iw + 1) / 2, ih, (ow + 1) / 2, oh, 1, true);
-      if (!rc) rc = setup_plane (h->plane[2], (iw + 1) / 2, ih, (ow + 1) / 2, oh, 1, true);
+      const bool nn = method == VFHIP_SCALE_NEAREST;
+      int rc = setup_plane (h->plane[0], iw, ih, ow, oh, 1, true, nn);
+      if (!rc) rc = setup_plane (h->plane[1], (iw + 1) / 2, ih, (ow + 1) / 2, oh, 1, true, nn);
+      if (!rc) rc = setup_plane (h->plane[2], (iw + 1) / 2, ih, (ow + 1) / 2, oh, 1, true, nn);
       if (rc) return rc;
       h->plane[0].step = 2; h->plane[0].off = yuy2 ? 0 : 1; h->plane[0].dup_last = ow & 1;
       h->plane[1].step = 4; h->plane[1].off = yuy2 ? 1 : 0;
       h->plane[2].step = 4; h->plane[2].off = yuy2 ? 3 : 2;
-      for (int k = 0; k < 3; k++) h->plane[k].vfirst = ih > oh + 2;
+      for (int k = 0; k < 3; k++) h->plane[k].vfirst = !nn && ih > oh + 2;
       if (h->need_convert && h->need_scale) {
         h->mid_bytes = (((size_t) 4 * ((iw + 1) / 2) + 15) / 16 * 16) * ih + 1024;
         VFHIP_CHECK_HIP (hipMalloc (&h->mid, h->mid_bytes));
@@ -394,11 +407,12 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
       h->configured = true;
       return VFHIP_OK;
     }
-    int rc = setup_plane (h->plane[0], iw, ih, ow, oh, 1);
+    const bool nn = method == VFHIP_SCALE_NEAREST;
+    int rc = setup_plane (h->plane[0], iw, ih, ow, oh, 1, nn, nn);
     if (rc) return rc;
-    if (out->format == VFHIP_FORMAT_NV12) rc = setup_plane (h->plane[1], (iw + 1) / 2, (ih + 1) / 2, (ow + 1) / 2, (oh + 1) / 2, 2);
-    else { rc = setup_plane (h->plane[1], (iw + 1) / 2, (ih + 1) / 2, (ow + 1) / 2, (oh + 1) / 2, 1);
-           if (!rc) rc = setup_plane (h->plane[2], (iw + 1) / 2, (ih + 1) / 2, (ow + 1) / 2, (oh + 1) / 2, 1); }
+    if (out->format == VFHIP_FORMAT_NV12) rc = setup_plane (h->plane[1], (iw + 1) / 2, (ih + 1) / 2, (ow + 1) / 2, (oh + 1) / 2, 2, nn, nn);
+    else { rc = setup_plane (h->plane[1], (iw + 1) / 2, (ih + 1) / 2, (ow + 1) / 2, (oh + 1) / 2, 1, nn, nn);
+           if (!rc) rc = setup_plane (h->plane[2], (iw + 1) / 2, (ih + 1) / 2, (ow + 1) / 2, (oh + 1) / 2, 1, nn, nn); }
     if (rc) return rc;
     if (h->need_convert && h->need_scale) {        // intermediate frame: output format at the input size
       const size_t ys = ((size_t) iw + 15) / 16 * 16, cs = ((size_t) 2 * ((iw + 1) / 2) + 15) / 16 * 16;

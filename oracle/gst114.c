@@ -700,3 +700,36 @@ int gst114_scale_packed422 (const uint8_t *in, int is, int yuy2, int w, int h, u
   free (A); free (B);
   return 0;
 }
+
+/* ---- videoscale method=nearest-neighbour on YUV frames (pinned by probing: every plane / interleaved line takes the
+ * nearest index of its own size, gst114_nearest_index) */
+int gst114_scale_plane_nearest (const uint8_t *in, int is, int w, int h, int n, uint8_t *out, int os, int ow, int oh)
+{
+  if (w <= 0 || h <= 0 || ow <= 0 || oh <= 0 || n < 1) return -1;
+  for (int y = 0; y < oh; y++) {
+    const uint8_t *row = in + (size_t) gst114_nearest_index (h, oh, y) * is;
+    for (int x = 0; x < ow; x++) {
+      const int i = gst114_nearest_index (w, ow, x);
+      for (int c = 0; c < n; c++) out[(size_t) y * os + n * x + c] = row[n * i + c];
+    }
+  }
+  return 0;
+}
+
+int gst114_scale_packed422_nearest (const uint8_t *in, int is, int yuy2, int w, int h, uint8_t *out, int os, int ow, int oh)
+{
+  if (w <= 0 || h <= 0 || ow <= 0 || oh <= 0) return -1;
+  int yo, uo, vo; pk_offsets (yuy2, &yo, &uo, &vo);
+  const int cw = (w + 1) / 2, cow = (ow + 1) / 2;
+  for (int y = 0; y < oh; y++) {
+    const uint8_t *row = in + (size_t) gst114_nearest_index (h, oh, y) * is;
+    uint8_t *o = out + (size_t) y * os;
+    for (int x = 0; x < ow; x++) o[2 * x + yo] = row[2 * gst114_nearest_index (w, ow, x) + yo];
+    if (ow & 1) o[2 * ow + yo] = o[2 * (ow - 1) + yo];
+    for (int k = 0; k < cow; k++) {
+      const int i = gst114_nearest_index (cw, cow, k);
+      o[4 * k + uo] = row[4 * i + uo]; o[4 * k + vo] = row[4 * i + vo];
+    }
+  }
+  return 0;
+}

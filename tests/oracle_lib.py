@@ -92,7 +92,8 @@ class Oracle:
             if rc != 0:
                 raise RuntimeError(f"oracle rc={rc}")
             return out
-        assert method == "bilinear", "planar / packed nearest and bicubic scaling are not restated"
+        assert method in ("bilinear", "nearest"), "planar / packed bicubic scaling is not restated"
+        near = method == "nearest"
         if out_format in ("UYVY", "YUY2"):
             # videoconvert at the input size -> packed frame of the output format, then videoscale on the packed frame
             ms, yuy2 = r4(2 * w), int(out_format == "YUY2")
@@ -110,7 +111,7 @@ class Oracle:
             assert rc == 0
             os_ = r4(2 * ow)
             out = np.zeros(os_ * oh, np.uint8)
-            assert L.gst114_scale_packed422(self._p(mid), ms, yuy2, w, h, self._p(out), os_, ow, oh) == 0
+            assert (L.gst114_scale_packed422_nearest if near else L.gst114_scale_packed422)(self._p(mid), ms, yuy2, w, h, self._p(out), os_, ow, oh) == 0
             return out
         # stage 1: videoconvert at the input size -> planes of the output format
         cw, ch = (w + 1) // 2, (h + 1) // 2
@@ -153,7 +154,7 @@ class Oracle:
 
         def scale(src, sw, sh, n, off, stride, dw, dh):
             src = np.ascontiguousarray(src)
-            rc = L.gst114_scale_plane(self._p(src), src.strides[0], sw, sh, n, self._p(out, off), stride, dw, dh)
+            rc = (L.gst114_scale_plane_nearest if near else L.gst114_scale_plane)(self._p(src), src.strides[0], sw, sh, n, self._p(out, off), stride, dw, dh)
             assert rc == 0
         scale(Y, w, h, 1, lay[0][0], lay[0][1], ow, oh)
         if out_format == "NV12":

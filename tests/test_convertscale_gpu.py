@@ -353,7 +353,7 @@ def test_one_sample_lines_are_replicated(vfhip, oracle, ifmt, ofmt, w, h, ow, oh
 
 
 # ---- packed 4:2:2 outputs, packed -> 4:2:0, and the tap-quantiser ties ----------------------------------------------
-from test_oracle_golden import MANIFEST_PO, ZPO, MANIFEST_T, ZT, gst_undefined_packed  # noqa: E402
+from test_oracle_golden import MANIFEST_PO, ZPO, MANIFEST_T, ZT, MANIFEST_N, ZN, gst_undefined_packed  # noqa: E402
 
 
 @pytest.mark.parametrize("case", MANIFEST_PO, ids=[c["name"] for c in MANIFEST_PO])
@@ -393,3 +393,13 @@ def test_packed_outputs_hd_vs_oracle(vfhip, oracle, ifmt, ofmt):
         got, _ = run(vfhip, ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", ofmt, ow, oh)
         want = oracle.convertscale(ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", ofmt, ow, oh)
         assert np.array_equal(meaningful(ofmt, ow, oh, got), meaningful(ofmt, ow, oh, want))
+
+
+@pytest.mark.parametrize("case", MANIFEST_N, ids=[c["name"] for c in MANIFEST_N])
+def test_golden_gstreamer_vectors_nearest_yuv_outputs(vfhip, case):
+    c = case
+    got, kname = run(vfhip, c["in_format"], c["w"], c["h"], ZN[c["name"] + "_in"], c["colorimetry"], c["chroma_site"],
+                     c["method"], c["out_format"], c["ow"], c["oh"])
+    assert kname.startswith("k_cs_staged")
+    a, b = meaningful(c["out_format"], c["ow"], c["oh"], got), meaningful(c["out_format"], c["ow"], c["oh"], ZN[c["name"] + "_out"])
+    assert np.array_equal(a, b), f"max diff {np.abs(a.astype(int) - b.astype(int)).max()}"

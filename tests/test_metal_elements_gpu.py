@@ -60,9 +60,9 @@ def test_convertscale_metal_matrix(vfhip, metalref, ifmt, ofmt):
 def test_convertscale_gst_exact_falls_back_to_metal_for_unpinned_cells(vfhip, metalref):
     raw = smooth("UYVY", 64, 32, 1)
     cs = vfhip.ConvertScale(0)
-    cs.configure("UYVY", 64, 32, "NV12", 32, 16, method="nearest", numerics="gst-exact")     # nearest with a 4:2:0 output: not pinned
+    cs.configure("UYVY", 64, 32, "NV12", 32, 32, add_borders=True, numerics="gst-exact")     # borders with a YUV output: not pinned
     assert cs.kernel_name == "k_cs_metal"
-    close(cs.process(raw), metalref.convertscale("UYVY", 64, 32, raw, "NV12", 32, 16, linear=False), "UYVY->NV12 nearest")
+    close(cs.process(raw), metalref.convertscale("UYVY", 64, 32, raw, "NV12", 32, 32, add_borders=True), "UYVY->NV12 borders")
     cs.close()
 
 

@@ -139,6 +139,18 @@ def test_oracle_matches_gstreamer_on_tap_ties(oracle, case):
     assert np.array_equal(meaningful(c["out_format"], c["ow"], c["oh"], got), meaningful(c["out_format"], c["ow"], c["oh"], want))
 
 
+# ---- method=nearest with YUV outputs (48 vectors from the real elements) ------------------------------------------------
+MANIFEST_N, ZN = oracle_lib.load_golden("convertscale_gst114_yuvnearest.npz")
+
+
+@pytest.mark.parametrize("case", MANIFEST_N, ids=[c["name"] for c in MANIFEST_N])
+def test_oracle_matches_gstreamer_nearest_yuv_outputs(oracle, case):
+    c = case
+    got = oracle.convertscale(c["in_format"], c["w"], c["h"], ZN[c["name"] + "_in"], c["colorimetry"], c["chroma_site"],
+                              c["method"], c["out_format"], c["ow"], c["oh"])
+    assert np.array_equal(meaningful(c["out_format"], c["ow"], c["oh"], got), meaningful(c["out_format"], c["ow"], c["oh"], ZN[c["name"] + "_out"]))
+
+
 # ---- bicubic (videoscale method=catrom): 76 vectors from the real elements ------------------------------------------
 MANIFEST_B, ZB = oracle_lib.load_golden("convertscale_gst114_bicubic.npz")
 

@@ -20,7 +20,7 @@ kernels = {}
 for case in range(N):
     ifmt = ["NV12", "I420", "BGRA", "RGBA", "UYVY", "YUY2"][rng.integers(6)]
     ofmt = ["BGRA", "RGBA", "NV12", "I420", "UYVY", "YUY2"][rng.integers(6)]
-    method = ["bilinear", "nearest", "bicubic"][rng.integers(3)] if ofmt in ("BGRA", "RGBA") else "bilinear"
+    method = ["bilinear", "nearest", "bicubic"][rng.integers(3)] if ofmt in ("BGRA", "RGBA") else ["bilinear", "nearest"][rng.integers(2)]
     big = rng.integers(4) == 0
     w, h, ow, oh = (int(v) for v in rng.integers(2, 700 if big else 120, 4))
     if rng.integers(5) == 0:

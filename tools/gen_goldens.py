@@ -301,6 +301,40 @@ def gen_ties():
     print("wrote", len(cases), "tie cases")
 
 
+def gen_yuv_nearest():
+    """`videoscale method=nearest-neighbour` with YUV outputs (4:2:0 and packed 4:2:2) from all six input formats ->
+    tests/golden/convertscale_gst114_yuvnearest.npz"""
+    cases, arrays = [], {}
+    rng = np.random.default_rng(20261009)
+    cols, sites = ["bt601", "bt709", "bt2020"], ["jpeg", "mpeg2"]
+    fixed = [(64, 36, 32, 18), (64, 36, 100, 50), (33, 17, 16, 9), (17, 9, 40, 21), (48, 40, 20, 37), (31, 30, 31, 12), (50, 20, 125, 20), (35, 29, 18, 8)]
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = build_helper(tmp)
+        t = 0
+        for ifmt in ["BGRA", "RGBA", "NV12", "I420", "UYVY", "YUY2"]:
+            for ofmt in ["NV12", "I420", "UYVY", "YUY2"]:
+                for (w, h, ow, oh) in [fixed[t % 8], tuple(int(v) for v in rng.integers(8, 90, 4))]:
+                    col, site = cols[t % 3], sites[(t // 3) % 2]
+                    size = {"BGRA": w * h * 4, "RGBA": w * h * 4, "NV12": nv12_layout(w, h)[3], "I420": i420_layout(w, h)[4]}.get(ifmt, r4(2 * w) * h)
+                    raw = rng.integers(0, 256, size, dtype=np.uint8).tobytes()
+                    incaps = f"video/x-raw,format={ifmt},width={w},height={h},framerate=1/1"
+                    if ifmt not in ("BGRA", "RGBA"):
+                        incaps += f",colorimetry={col},chroma-site={site}"
+                    out = gst_run(exe, tmp, raw, len(raw), incaps, "videoconvert ! videoscale method=nearest-neighbour",
+                                  f"video/x-raw,format={ofmt},width={ow},height={oh},colorimetry={col},chroma-site={site}")
+                    name = f"nn_{ifmt.lower()}_to_{ofmt.lower()}_{t:03d}_{w}x{h}_to_{ow}x{oh}"
+                    arrays[name + "_in"], arrays[name + "_out"] = np.frombuffer(raw, np.uint8), np.frombuffer(out, np.uint8)
+                    cases.append(dict(name=name, in_format=ifmt, w=w, h=h, colorimetry=col, chroma_site=site, method="nearest", out_format=ofmt,
+                                      ow=ow, oh=oh, in_sha256=hashlib.sha256(raw).hexdigest(), out_sha256=hashlib.sha256(out).hexdigest()))
+                    t += 1
+    arrays["manifest"] = np.frombuffer(json.dumps(cases).encode(), np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "convertscale_gst114_yuvnearest.npz"), **arrays)
+    print("wrote", len(cases), "nearest YUV-output cases")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "yuvnearest":
+    gen_yuv_nearest()
+    sys.exit(0)
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ties":
     gen_ties()
     sys.exit(0)
