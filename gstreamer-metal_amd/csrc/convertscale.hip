@@ -23,7 +23,7 @@ static const int kRgb2Yuv[3][9] = {
 
 struct PlaneCfg {                 // stage-2 set-up of one output plane (gst-exact, 4:2:0 outputs)
   int w = 0, h = 0, ow = 0, oh = 0, n = 1, hmode = 0, vscale_on = 0, vfirst = 0;
-  int step = 1, off = 0, dup_last = 0;      // packed 4:2:2: bytes between samples, offset of the first one, spare-slot rule
+  int step = 1, off = 0;                    // packed 4:2:2: bytes between samples, offset of the first one
   uint32_t hinc = 0;
   int *d_vtab = nullptr, *d_htab = nullptr;
 };
@@ -52,7 +52,7 @@ struct VfHipConvertScale {
   PlaneCfg plane[3];
   int n_out_planes = 0;
   bool need_convert = false, need_scale = false;
-  void *mid = nullptr; size_t mid_bytes = 0;
+  void *mid = nullptr; size_t mid_bytes = 0; int mid_frames = 0;   // mid_bytes: one intermediate frame; mid holds mid_frames of them
   // K_NTAP (method=bicubic): optional conversion at the input size by a private child handle, then the n-tap passes
   VfHipConvertScale *conv = nullptr;
   int2 *d_nt_h = nullptr, *d_nt_v = nullptr; int nt_h = 0, nt_v = 0;
@@ -72,7 +72,7 @@ static void free_tables (VfHipConvertScale *h)
     pc = PlaneCfg ();
   }
   if (h->mid) (void) hipFree (h->mid);
-  h->mid = nullptr; h->mid_bytes = 0;
+  h->mid = nullptr; h->mid_bytes = 0; h->mid_frames = 0;
   if (h->d_nt_h) (void) hipFree (h->d_nt_h);
   if (h->d_nt_v) (void) hipFree (h->d_nt_v);
   if (h->nt_mid0) (void) hipFree (h->nt_mid0);
@@ -395,13 +395,14 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
       if (!rc) rc = setup_plane (h->plane[1], (iw + 1) / 2, ih, (ow + 1) / 2, oh, 1, true, nn);
       if (!rc) rc = setup_plane (h->plane[2], (iw + 1) / 2, ih, (ow + 1) / 2, oh, 1, true, nn);
       if (rc) return rc;
-      h->plane[0].step = 2; h->plane[0].off = yuy2 ? 0 : 1; h->plane[0].dup_last = ow & 1;
+      h->plane[0].step = 2; h->plane[0].off = yuy2 ? 0 : 1;
       h->plane[1].step = 4; h->plane[1].off = yuy2 ? 1 : 0;
       h->plane[2].step = 4; h->plane[2].off = yuy2 ? 3 : 2;
       for (int k = 0; k < 3; k++) h->plane[k].vfirst = !nn && ih > oh + 2;
       if (h->need_convert && h->need_scale) {
         h->mid_bytes = (((size_t) 4 * ((iw + 1) / 2) + 15) / 16 * 16) * ih + 1024;
         VFHIP_CHECK_HIP (hipMalloc (&h->mid, h->mid_bytes));
+        h->mid_frames = 1;
       }
       h->kernel = VfHipConvertScale::K_STAGED; h->kernel_name = "k_cs_staged_422";
       h->configured = true;
@@ -418,6 +419,7 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
       const size_t ys = ((size_t) iw + 15) / 16 * 16, cs = ((size_t) 2 * ((iw + 1) / 2) + 15) / 16 * 16;
       h->mid_bytes = ys * ih + 3 * cs * ((ih + 1) / 2) + 1024;
       VFHIP_CHECK_HIP (hipMalloc (&h->mid, h->mid_bytes));
+      h->mid_frames = 1;
     }
     h->kernel = VfHipConvertScale::K_STAGED; h->kernel_name = "k_cs_staged_420";
     h->configured = true;
@@ -482,58 +484,52 @@ static int validate_frames (VfHipConvertScale *h, const VfHipFrame *in, const Vf
 }
 
 // gst-exact, 4:2:0 output: stage 1 (format change at the input size) + stage 2 (per-plane scale)
-static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame *out, hipStream_t s)
+// gst-exact cells with YUV outputs: videoconvert at the input size (stage 1), then videoscale (stage 2); every kernel
+// takes the whole batch (blockIdx.z = frame)
+static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame *out, size_t in_pitch, size_t out_pitch, int n_frames, hipStream_t s)
 {
   const int iw = h->in.width, ih = h->in.height;
   const bool out_planar = h->out.format == VFHIP_FORMAT_I420;
   const bool out_packed = h->out.format == VFHIP_FORMAT_UYVY || h->out.format == VFHIP_FORMAT_YUY2;
   const bool in_packed = h->in.format == VFHIP_FORMAT_UYVY || h->in.format == VFHIP_FORMAT_YUY2;
+  const unsigned nz = (unsigned) n_frames;
   // where stage 1 writes / stage 2 reads: the output itself (no scaling), the input itself (no conversion), or `mid`
   VfHipFrame mid {};
+  size_t mid_pitch = 0;
   mid.info = h->out; mid.info.width = iw; mid.info.height = ih;
-  if (out_packed) {
-    if (h->need_convert && h->need_scale) { mid.data[0] = h->mid; mid.stride[0] = (int) (((size_t) 4 * ((iw + 1) / 2) + 15) / 16 * 16); }
-    else if (h->need_convert) mid = *out;
-    else mid = *in;
-    if (h->need_convert) {
+  if (h->need_convert && h->need_scale) {
+    if (h->mid_frames < n_frames) {              // intermediate frames of the batch (grown on demand; hipFree waits for the device)
+      if (h->mid) (void) hipFree (h->mid);
+      h->mid = nullptr; h->mid_frames = 0;
+      VFHIP_CHECK_HIP (hipMalloc (&h->mid, h->mid_bytes * (size_t) n_frames));
+      h->mid_frames = n_frames;
+    }
+    mid_pitch = h->mid_bytes;
+    uint8_t *b = (uint8_t *) h->mid;
+    if (out_packed) { mid.data[0] = b; mid.stride[0] = (int) (((size_t) 4 * ((iw + 1) / 2) + 15) / 16 * 16); }
+    else {
+      const size_t ys = ((size_t) iw + 15) / 16 * 16, cs = ((size_t) 2 * ((iw + 1) / 2) + 15) / 16 * 16;
+      mid.data[0] = b; mid.stride[0] = (int) ys;
+      mid.data[1] = b + ys * ih; mid.stride[1] = (int) cs;
+      mid.data[2] = b + ys * ih + cs * ((ih + 1) / 2); mid.stride[2] = (int) cs;
+    }
+  } else if (h->need_convert) { mid = *out; mid_pitch = out_pitch; }
+  else { mid = *in; mid_pitch = in_pitch; }
+  const int cw = (iw + 1) / 2, chh = (ih + 1) / 2;
+  if (h->need_convert) {
+    dim3 grid ((unsigned) ((cw + 63) / 64), (unsigned) (((out_packed ? ih : chh) + 3) / 4), nz);
+    if (out_packed) {
       ToPackedParams p {};
+      p.in_pitch = in_pitch; p.out_pitch = mid_pitch;
       for (int k = 0; k < 3; k++) { p.in[k] = (const uint8_t *) in->data[k]; p.is[k] = in->stride[k]; }
       p.out = (uint8_t *) mid.data[0]; p.os = mid.stride[0];
       p.w = iw; p.h = ih; p.in_fmt = h->in.format; p.out_yuy2 = h->out.format == VFHIP_FORMAT_YUY2;
       p.cosited_in = h->in.chroma_site == VFHIP_CHROMA_SITE_H_COSITED; p.cosited_out = h->out.chroma_site == VFHIP_CHROMA_SITE_H_COSITED;
       for (int k = 0; k < 9; k++) p.c[k] = kRgb2Yuv[h->out.color_matrix][k];
-      dim3 grid ((unsigned) (((iw + 1) / 2 + 63) / 64), (unsigned) ((ih + 3) / 4));
       hipLaunchKernelGGL (k_to_packed422, grid, dim3 (64, 4), 0, s, p);
-      VFHIP_CHECK_HIP (hipGetLastError ());
-    }
-    if (h->need_scale || !h->need_convert) {
-      for (int k = 0; k < 3; k++) {
-        const PlaneCfg &pc = h->plane[k];
-        PlaneScaleParams p {};
-        p.in = (const uint8_t *) mid.data[0] + pc.off; p.is = mid.stride[0];
-        p.out = (uint8_t *) out->data[0] + pc.off; p.os = out->stride[0];
-        p.w = pc.w; p.h = pc.h; p.ow = pc.ow; p.oh = pc.oh; p.n = 1; p.istep = p.ostep = pc.step; p.dup_last = pc.dup_last; p.hmode = pc.hmode;
-        p.vscale_on = pc.vscale_on; p.vfirst = pc.vfirst; p.hinc = pc.hinc; p.vtab = pc.d_vtab; p.htab = pc.d_htab;
-        dim3 grid ((unsigned) ((pc.ow + 63) / 64), (unsigned) ((pc.oh + 3) / 4));
-        hipLaunchKernelGGL (k_scale_plane, grid, dim3 (64, 4), 0, s, p);
-        VFHIP_CHECK_HIP (hipGetLastError ());
-      }
-    }
-    return VFHIP_OK;
-  }
-  if (h->need_convert && h->need_scale) {
-    const size_t ys = ((size_t) iw + 15) / 16 * 16, cs = ((size_t) 2 * ((iw + 1) / 2) + 15) / 16 * 16;
-    uint8_t *b = (uint8_t *) h->mid;
-    mid.data[0] = b; mid.stride[0] = (int) ys;
-    mid.data[1] = b + ys * ih; mid.stride[1] = (int) cs;
-    mid.data[2] = b + ys * ih + cs * ((ih + 1) / 2); mid.stride[2] = (int) cs;
-  } else if (h->need_convert) mid = *out;
-  else mid = *in;
-  const int cw = (iw + 1) / 2, chh = (ih + 1) / 2;
-  if (h->need_convert) {
-    dim3 grid ((unsigned) ((cw + 63) / 64), (unsigned) ((chh + 3) / 4));
-    if (h->in.format == VFHIP_FORMAT_BGRA || h->in.format == VFHIP_FORMAT_RGBA) {
+    } else if (h->in.format == VFHIP_FORMAT_BGRA || h->in.format == VFHIP_FORMAT_RGBA) {
       Rgb2YuvParams p {};
+      p.in_pitch = in_pitch; p.out_pitch = mid_pitch;
       p.in = (const uint8_t *) in->data[0]; p.is = in->stride[0];
       p.y = (uint8_t *) mid.data[0]; p.ys = mid.stride[0];
       p.u = (uint8_t *) mid.data[1]; p.us = mid.stride[1];
@@ -544,6 +540,7 @@ static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
       hipLaunchKernelGGL (k_rgb_to_yuv420, grid, dim3 (64, 4), 0, s, p);
     } else if (in_packed) {
       FromPackedParams p {};
+      p.in_pitch = in_pitch; p.out_pitch = mid_pitch;
       p.in = (const uint8_t *) in->data[0]; p.is = in->stride[0];
       p.y = (uint8_t *) mid.data[0]; p.ys = mid.stride[0];
       p.u = (uint8_t *) mid.data[1]; p.us = mid.stride[1];
@@ -553,6 +550,7 @@ static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
       hipLaunchKernelGGL (k_packed422_to_420, grid, dim3 (64, 4), 0, s, p);
     } else {
       RepackParams p {};
+      p.in_pitch = in_pitch; p.out_pitch = mid_pitch;
       p.iy = (const uint8_t *) in->data[0]; p.iys = in->stride[0];
       p.iu = (const uint8_t *) in->data[1]; p.ius = in->stride[1];
       p.iv = (const uint8_t *) in->data[2]; p.ivs = in->stride[2];
@@ -564,18 +562,35 @@ static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
     }
     VFHIP_CHECK_HIP (hipGetLastError ());
   }
-  if (h->need_scale || !h->need_convert) {
-    for (int k = 0; k < h->n_out_planes; k++) {
-      const PlaneCfg &pc = h->plane[k];
-      PlaneScaleParams p {};
-      p.in = (const uint8_t *) mid.data[k]; p.is = mid.stride[k];
-      p.out = (uint8_t *) out->data[k]; p.os = out->stride[k];
-      p.w = pc.w; p.h = pc.h; p.ow = pc.ow; p.oh = pc.oh; p.n = pc.n; p.istep = p.ostep = pc.n; p.hmode = pc.hmode;
-      p.vscale_on = pc.vscale_on; p.vfirst = pc.vfirst; p.hinc = pc.hinc; p.vtab = pc.d_vtab; p.htab = pc.d_htab;
-      dim3 grid ((unsigned) ((pc.ow + 63) / 64), (unsigned) ((pc.oh + 3) / 4));
-      hipLaunchKernelGGL (k_scale_plane, grid, dim3 (64, 4), 0, s, p);
-      VFHIP_CHECK_HIP (hipGetLastError ());
+  if (!(h->need_scale || !h->need_convert)) return VFHIP_OK;
+  auto fill = [&] (PlaneScaleParams &p, const PlaneCfg &pc) {
+    p.in_pitch = mid_pitch; p.out_pitch = out_pitch;
+    p.w = pc.w; p.h = pc.h; p.ow = pc.ow; p.oh = pc.oh; p.n = pc.n; p.istep = p.ostep = pc.step; p.hmode = pc.hmode;
+    p.vscale_on = pc.vscale_on; p.vfirst = pc.vfirst; p.hinc = pc.hinc; p.vtab = pc.d_vtab; p.htab = pc.d_htab;
+  };
+  if (out_packed) {
+    PackedScaleParams q {};
+    for (int k = 0; k < 3; k++) {
+      fill (q.pl[k], h->plane[k]);
+      q.pl[k].n = 1;
+      q.pl[k].in = (const uint8_t *) mid.data[0] + h->plane[k].off; q.pl[k].is = mid.stride[0];
+      q.pl[k].out = (uint8_t *) out->data[0]; q.pl[k].os = out->stride[0];
     }
+    q.yo = h->plane[0].off; q.uo = h->plane[1].off; q.vo = h->plane[2].off;
+    dim3 grid ((unsigned) ((h->plane[1].ow + 63) / 64), (unsigned) ((h->plane[0].oh + 3) / 4), nz);
+    hipLaunchKernelGGL (k_scale_packed422, grid, dim3 (64, 4), 0, s, q);
+    VFHIP_CHECK_HIP (hipGetLastError ());
+    return VFHIP_OK;
+  }
+  for (int k = 0; k < h->n_out_planes; k++) {
+    const PlaneCfg &pc = h->plane[k];
+    PlaneScaleParams p {};
+    fill (p, pc);
+    p.in = (const uint8_t *) mid.data[k]; p.is = mid.stride[k];
+    p.out = (uint8_t *) out->data[k]; p.os = out->stride[k];
+    dim3 grid ((unsigned) ((pc.n * pc.ow + 255) / 256), (unsigned) ((pc.oh + 3) / 4), nz);
+    hipLaunchKernelGGL (k_scale_plane, grid, dim3 (64, 4), 0, s, p);
+    VFHIP_CHECK_HIP (hipGetLastError ());
   }
   return VFHIP_OK;
 }
@@ -661,18 +676,7 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
     }
     return VFHIP_OK;
   }
-  if (h->kernel == VfHipConvertScale::K_STAGED) {
-    for (int k = 0; k < n_frames; k++) {
-      VfHipFrame fi = *in, fo = *out;
-      for (int p = 0; p < 3; p++) {
-        if (fi.data[p]) fi.data[p] = (uint8_t *) fi.data[p] + (size_t) k * in_pitch;
-        if (fo.data[p]) fo.data[p] = (uint8_t *) fo.data[p] + (size_t) k * out_pitch;
-      }
-      int rc = staged_launch (h, &fi, &fo, s);
-      if (rc) return rc;
-    }
-    return VFHIP_OK;
-  }
+  if (h->kernel == VfHipConvertScale::K_STAGED) return staged_launch (h, in, out, in_pitch, out_pitch, n_frames, s);
   if (h->kernel == VfHipConvertScale::K_METAL)
     return cs_metal_launch (h->in, h->out, h->method, h->add_borders, h->border_color, in, out, in_pitch, out_pitch, n_frames, s);
   CsParams p {};

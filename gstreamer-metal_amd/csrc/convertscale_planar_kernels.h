@@ -17,14 +17,18 @@
 namespace vfhip {
 
 struct Rgb2YuvParams {
+  size_t in_pitch, out_pitch;
   const uint8_t *in; int is;
   uint8_t *y, *u, *v; int ys, us, vs;     // NV12: u = uv plane, v unused
   int w, h, in_rgba, planar, cosited;
   int c[9];
 };
 
-__global__ __launch_bounds__ (256) void k_rgb_to_yuv420 (const Rgb2YuvParams p)
+__global__ __launch_bounds__ (256) void k_rgb_to_yuv420 (const Rgb2YuvParams p0)
 {
+  Rgb2YuvParams p = p0;
+  p.in += (size_t) blockIdx.z * p.in_pitch;
+  p.y += (size_t) blockIdx.z * p.out_pitch; p.u += (size_t) blockIdx.z * p.out_pitch; if (p.v) p.v += (size_t) blockIdx.z * p.out_pitch;
   const int k = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;      // chroma sample (k, j)
   const int cw = (p.w + 1) >> 1, chh = (p.h + 1) >> 1;
   if (k >= cw || j >= chh) return;
@@ -68,13 +72,17 @@ __global__ __launch_bounds__ (256) void k_rgb_to_yuv420 (const Rgb2YuvParams p)
 }
 
 struct RepackParams {
+  size_t in_pitch, out_pitch;
   const uint8_t *iy, *iu, *iv; int iys, ius, ivs;
   uint8_t *oy, *ou, *ov; int oys, ous, ovs;
   int w, h, in_planar, out_planar;
 };
 
-__global__ __launch_bounds__ (256) void k_repack_420 (const RepackParams p)
+__global__ __launch_bounds__ (256) void k_repack_420 (const RepackParams p0)
 {
+  RepackParams p = p0;
+  p.iy += (size_t) blockIdx.z * p.in_pitch; p.iu += (size_t) blockIdx.z * p.in_pitch; if (p.iv) p.iv += (size_t) blockIdx.z * p.in_pitch;
+  p.oy += (size_t) blockIdx.z * p.out_pitch; p.ou += (size_t) blockIdx.z * p.out_pitch; if (p.ov) p.ov += (size_t) blockIdx.z * p.out_pitch;
   const int k = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
   const int cw = (p.w + 1) >> 1, chh = (p.h + 1) >> 1;
   if (k >= cw || j >= chh) return;
@@ -99,7 +107,7 @@ struct PlaneScaleParams {
   int w, h, ow, oh, n;
   int istep, ostep;        // bytes between consecutive samples of this plane (n for a plane of its own; 2 / 4 for the
                            // luma / chroma lines interleaved in a packed 4:2:2 frame); hmode 1 / 2 need istep == 1
-  int dup_last;            // packed luma, odd width: the spare luma slot repeats the last sample (as GStreamer does)
+  size_t in_pitch, out_pitch;   // batch: frame k of the launch at base + k * pitch (blockIdx.z)
   int hmode;               // 0: no horizontal scaling, 1: edge-aligned 16.16 (1 x u8), 2: pair average (1 x u8), 3: table (6-bit taps)
   int vscale_on, vfirst;
   uint32_t hinc;
@@ -124,44 +132,86 @@ __device__ __forceinline__ int plane_htap (const PlaneScaleParams &p, const uint
   }
 }
 
-__global__ __launch_bounds__ (256) void k_scale_plane (const PlaneScaleParams p)
+// one output sample (x, y), component c, of a plane: both passes in GstVideoScaler's order
+__device__ __forceinline__ int plane_sample (const PlaneScaleParams &p, const uint8_t *r0, const uint8_t *r1, int wt, int x, int c)
 {
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-  if (x >= p.ow || y >= p.oh) return;
+  if (!p.vscale_on) return plane_htap (p, r0, x, c);
+  if (p.hmode == 0) { const int a = r0[p.istep * x + c], b = r1[p.istep * x + c]; return a + (((b - a) * wt + 128) >> 8); }
+  if (p.vfirst) {
+    // vertical first: the horizontal taps run on vertically scaled samples -> scale each source column the tap touches
+    switch (p.hmode) {
+      case 1: {
+        const uint32_t t = (uint32_t) x * p.hinc;
+        const int i = min ((int) (t >> 16), p.w - 1), f = (int) ((t >> 8) & 0xff), j1 = min (i + 1, p.w - 1);
+        const int a = r0[i] + (((r1[i] - r0[i]) * wt + 128) >> 8), b = r0[j1] + (((r1[j1] - r0[j1]) * wt + 128) >> 8);
+        return (a * (256 - f) + b * f) >> 8;
+      }
+      case 2: {
+        const int a = r0[2 * x] + (((r1[2 * x] - r0[2 * x]) * wt + 128) >> 8), b = r0[2 * x + 1] + (((r1[2 * x + 1] - r0[2 * x + 1]) * wt + 128) >> 8);
+        return (a + b + 1) >> 1;
+      }
+      default: {
+        const int j0 = p.htab[4 * x], j1 = p.htab[4 * x + 1], t = p.htab[4 * x + 2];
+        const int a0 = r0[p.istep * j0 + c], a1 = r1[p.istep * j0 + c], b0 = r0[p.istep * j1 + c], b1 = r1[p.istep * j1 + c];
+        const int a = a0 + (((a1 - a0) * wt + 128) >> 8), b = b0 + (((b1 - b0) * wt + 128) >> 8);
+        return (a * (64 - t) + b * t + 32) >> 6;
+      }
+    }
+  }
+  const int a = plane_htap (p, r0, x, c), b = plane_htap (p, r1, x, c);
+  return a + (((b - a) * wt + 128) >> 8);
+}
+
+// a plane of its own (n = istep = ostep: 4:2:0 luma / chroma planes).  One lane = FOUR consecutive output bytes of a row
+// (4 samples of a 1 x u8 plane, 2 samples of NV12's 2 x u8 plane), stored as one dword when the address allows: byte
+// stores cost a full store instruction each.  blockIdx.z = frame of the batch.
+__global__ __launch_bounds__ (256) void k_scale_plane (const PlaneScaleParams p0)
+{
+  PlaneScaleParams p = p0;
+  p.in += (size_t) blockIdx.z * p.in_pitch; p.out += (size_t) blockIdx.z * p.out_pitch;
+  const int bx = 4 * (blockIdx.x * 64 + threadIdx.x), y = blockIdx.y * 4 + threadIdx.y, wb = p.n * p.ow;
+  if (bx >= wb || y >= p.oh) return;
   int i0 = y, i1 = y, wt = 0;
   if (p.vscale_on) { i0 = p.vtab[4 * y]; i1 = p.vtab[4 * y + 1]; wt = p.vtab[4 * y + 2]; }
   const uint8_t *r0 = p.in + (size_t) i0 * p.is, *r1 = p.in + (size_t) i1 * p.is;
-  for (int c = 0; c < p.n; c++) {
-    int v;
-    if (!p.vscale_on) v = plane_htap (p, r0, x, c);
-    else if (p.hmode == 0) { const int a = r0[p.istep * x + c], b = r1[p.istep * x + c]; v = a + (((b - a) * wt + 128) >> 8); }
-    else if (p.vfirst) {
-      // vertical first: the horizontal taps run on vertically scaled samples -> scale each source column the tap touches
-      switch (p.hmode) {
-        case 1: {
-          const uint32_t t = (uint32_t) x * p.hinc;
-          const int i = min ((int) (t >> 16), p.w - 1), f = (int) ((t >> 8) & 0xff), j1 = min (i + 1, p.w - 1);
-          const int a = r0[i] + (((r1[i] - r0[i]) * wt + 128) >> 8), b = r0[j1] + (((r1[j1] - r0[j1]) * wt + 128) >> 8);
-          v = (a * (256 - f) + b * f) >> 8; break;
-        }
-        case 2: {
-          const int a = r0[2 * x] + (((r1[2 * x] - r0[2 * x]) * wt + 128) >> 8), b = r0[2 * x + 1] + (((r1[2 * x + 1] - r0[2 * x + 1]) * wt + 128) >> 8);
-          v = (a + b + 1) >> 1; break;
-        }
-        default: {
-          const int j0 = p.htab[4 * x], j1 = p.htab[4 * x + 1], t = p.htab[4 * x + 2];
-          const int a0 = r0[p.istep * j0 + c], a1 = r1[p.istep * j0 + c], b0 = r0[p.istep * j1 + c], b1 = r1[p.istep * j1 + c];
-          const int a = a0 + (((a1 - a0) * wt + 128) >> 8), b = b0 + (((b1 - b0) * wt + 128) >> 8);
-          v = (a * (64 - t) + b * t + 32) >> 6; break;
-        }
-      }
-    } else {
-      const int a = plane_htap (p, r0, x, c), b = plane_htap (p, r1, x, c);
-      v = a + (((b - a) * wt + 128) >> 8);
-    }
-    p.out[(size_t) y * p.os + p.ostep * x + c] = (uint8_t) v;
-    if (p.dup_last && x == p.ow - 1) p.out[(size_t) y * p.os + p.ostep * (x + 1) + c] = (uint8_t) v;
+  uint32_t v = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int b = min (bx + k, wb - 1);
+    const int x = p.n == 2 ? b >> 1 : b, c = p.n == 2 ? b & 1 : 0;
+    v |= (uint32_t) plane_sample (p, r0, r1, wt, x, c) << (8 * k);
   }
+  uint8_t *d = p.out + (size_t) y * p.os + bx;
+  if (bx + 3 < wb && ((uintptr_t) d & 3) == 0) *reinterpret_cast<uint32_t *> (d) = v;
+  else for (int k = 0; k < 4 && bx + k < wb; k++) d[k] = (uint8_t) (v >> (8 * k));
+}
+
+// videoscale on a packed 4:2:2 frame: one lane = one output macro-pixel (Y0 U Y1 V in the frame's byte order), the three
+// interleaved lines each with their own tables; pl[0] = luma (step 2), pl[1] = U, pl[2] = V (step 4)
+struct PackedScaleParams { PlaneScaleParams pl[3]; int yo, uo, vo; };
+
+__global__ __launch_bounds__ (256) void k_scale_packed422 (const PackedScaleParams q)
+{
+  const PlaneScaleParams &py = q.pl[0];
+  const int k = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (k >= q.pl[1].ow || y >= py.oh) return;
+  int i0 = y, i1 = y, wt = 0;
+  if (py.vscale_on) { i0 = py.vtab[4 * y]; i1 = py.vtab[4 * y + 1]; wt = py.vtab[4 * y + 2]; }
+  const size_t fin = (size_t) blockIdx.z * py.in_pitch, fout = (size_t) blockIdx.z * py.out_pitch;
+  uint32_t b[4];
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    const PlaneScaleParams &p = q.pl[t];
+    const uint8_t *r0 = p.in + fin + (size_t) i0 * p.is, *r1 = p.in + fin + (size_t) i1 * p.is;
+    if (t == 0) {
+      b[q.yo] = (uint32_t) plane_sample (p, r0, r1, wt, 2 * k, 0);
+      b[q.yo + 2] = 2 * k + 1 < p.ow ? (uint32_t) plane_sample (p, r0, r1, wt, 2 * k + 1, 0) : b[q.yo];   // spare slot of an odd width
+    } else b[t == 1 ? q.uo : q.vo] = (uint32_t) plane_sample (p, r0, r1, wt, k, 0);
+  }
+  uint8_t *d = py.out + fout + (size_t) y * py.os + 4 * k;
+  const uint32_t v = b[0] | b[1] << 8 | b[2] << 16 | b[3] << 24;
+  if (((uintptr_t) d & 3) == 0) *reinterpret_cast<uint32_t *> (d) = v;
+  else { d[0] = (uint8_t) b[0]; d[1] = (uint8_t) b[1]; d[2] = (uint8_t) b[2]; d[3] = (uint8_t) b[3]; }
 }
 
 // ---- packed 4:2:2 (UYVY / YUY2) outputs and packed -> 4:2:0: videoconvert's conversions at the input size ------------
@@ -191,6 +241,7 @@ __device__ __forceinline__ int chroma_down (const int s[3], int cosited)
 }
 
 struct ToPackedParams {
+  size_t in_pitch, out_pitch;
   const uint8_t *in[3]; int is[3];
   uint8_t *out; int os;
   int w, h, in_fmt, out_yuy2, cosited_in, cosited_out;
@@ -198,8 +249,11 @@ struct ToPackedParams {
 };
 
 // one lane = one macro-pixel (two luma samples + U + V) of the packed output
-__global__ __launch_bounds__ (256) void k_to_packed422 (const ToPackedParams p)
+__global__ __launch_bounds__ (256) void k_to_packed422 (const ToPackedParams p0)
 {
+  ToPackedParams p = p0;
+  for (int t = 0; t < 3; t++) if (p.in[t]) p.in[t] += (size_t) blockIdx.z * p.in_pitch;
+  p.out += (size_t) blockIdx.z * p.out_pitch;
   const int k = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
   const int cw = (p.w + 1) >> 1;
   if (k >= cw || y >= p.h) return;
@@ -259,14 +313,18 @@ __global__ __launch_bounds__ (256) void k_to_packed422 (const ToPackedParams p)
 }
 
 struct FromPackedParams {
+  size_t in_pitch, out_pitch;
   const uint8_t *in; int is;
   uint8_t *y, *u, *v; int ys, us, vs;     // NV12: u = uv plane, v unused
   int w, h, in_yuy2, planar, cosited_in, cosited_out;
 };
 
 // one lane = one 4:2:0 chroma sample (and the 2x2 luma block under it)
-__global__ __launch_bounds__ (256) void k_packed422_to_420 (const FromPackedParams p)
+__global__ __launch_bounds__ (256) void k_packed422_to_420 (const FromPackedParams p0)
 {
+  FromPackedParams p = p0;
+  p.in += (size_t) blockIdx.z * p.in_pitch;
+  p.y += (size_t) blockIdx.z * p.out_pitch; p.u += (size_t) blockIdx.z * p.out_pitch; if (p.v) p.v += (size_t) blockIdx.z * p.out_pitch;
   const int k = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
   const int cw = (p.w + 1) >> 1, chh = (p.h + 1) >> 1;
   if (k >= cw || j >= chh) return;

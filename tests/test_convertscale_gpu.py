@@ -403,3 +403,30 @@ def test_golden_gstreamer_vectors_nearest_yuv_outputs(vfhip, case):
     assert kname.startswith("k_cs_staged")
     a, b = meaningful(c["out_format"], c["ow"], c["oh"], got), meaningful(c["out_format"], c["ow"], c["oh"], ZN[c["name"] + "_out"])
     assert np.array_equal(a, b), f"max diff {np.abs(a.astype(int) - b.astype(int)).max()}"
+
+
+@pytest.mark.parametrize("ifmt,ofmt,w,h,ow,oh,method", [("NV12", "NV12", 200, 120, 96, 50, "bilinear"), ("BGRA", "I420", 121, 77, 64, 90, "bilinear"),
+                                                        ("I420", "UYVY", 100, 60, 171, 33, "bilinear"), ("YUY2", "NV12", 90, 45, 91, 20, "nearest"),
+                                                        ("UYVY", "YUY2", 64, 64, 64, 64, "bilinear"), ("RGBA", "NV12", 64, 36, 64, 36, "bilinear")])
+def test_staged_cells_batched(vfhip, oracle, ifmt, ofmt, w, h, ow, oh, method):
+    """the YUV-output cells take a whole batch per kernel (frame k at base + k * pitch, intermediate frames included): every
+    frame of a 5-frame batch equals the oracle, and a second, larger batch re-grows the intermediate buffer"""
+    import torch
+    isz, osz = vfhip.plane_layout(ifmt, w, h)[1], vfhip.plane_layout(ofmt, ow, oh)[1]
+    ip, op = (isz + 255) // 256 * 256, (osz + 255) // 256 * 256 + 256
+    cs = vfhip.ConvertScale(0)
+    cs.configure(ifmt, w, h, ofmt, ow, oh, method=method, colorimetry="bt709", chroma_site="mpeg2")
+    assert cs.kernel_name.startswith("k_cs_staged")
+    s = torch.cuda.Stream()
+    for n in (5, 9):
+        g = torch.Generator(device="cpu").manual_seed(100 + n)
+        host = torch.randint(0, 256, (n, ip), dtype=torch.uint8, generator=g)
+        dev_in, dev_out = host.cuda(), torch.zeros((n, op), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        cs.process_device(dev_in.data_ptr(), dev_out.data_ptr(), stream=s.cuda_stream, n_frames=n, in_pitch=ip, out_pitch=op)
+        s.synchronize()
+        out = dev_out.cpu().numpy()
+        for k in range(n):
+            want = oracle.convertscale(ifmt, w, h, host[k, :isz].numpy(), "bt709", "mpeg2", method, ofmt, ow, oh)
+            assert np.array_equal(meaningful(ofmt, ow, oh, out[k, :osz]), meaningful(ofmt, ow, oh, want)), f"batch {n} frame {k}"
+    cs.close()

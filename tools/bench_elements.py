@@ -167,6 +167,28 @@ def main():
     cs.close()
 
 
+def staged():
+    """kernel-only throughput of the gst-exact cells with YUV outputs (k_cs_staged_420 / _422), batched device frames"""
+    s = torch.cuda.Stream()
+    for (ifmt, w, h, ofmt, ow, oh, method) in [("NV12", 3840, 2160, "NV12", 1920, 1080, "bilinear"), ("NV12", 1920, 1080, "NV12", 1280, 720, "bilinear"),
+                                               ("I420", 1920, 1080, "I420", 1280, 720, "bilinear"), ("BGRA", 1920, 1080, "NV12", 1920, 1080, "bilinear"),
+                                               ("BGRA", 1920, 1080, "I420", 1280, 720, "bilinear"), ("NV12", 1920, 1080, "UYVY", 1920, 1080, "bilinear"),
+                                               ("UYVY", 1920, 1080, "NV12", 1920, 1080, "bilinear"), ("UYVY", 1920, 1080, "UYVY", 1280, 720, "bilinear"),
+                                               ("NV12", 3840, 2160, "NV12", 1920, 1080, "nearest")]:
+        isz, osz = vfhip.plane_layout(ifmt, w, h)[1], vfhip.plane_layout(ofmt, ow, oh)[1]
+        N = max(16, int(1.2e9 // (isz + osz)))                     # > 1 GB per launch: several times the 256 MB infinity cache
+        ip, op = (isz + 255) // 256 * 256, (osz + 255) // 256 * 256
+        fin, fout = ring(N, isz, 70), ring(N, osz, 71)
+        cs = vfhip.ConvertScale(0)
+        cs.configure(ifmt, w, h, ofmt, ow, oh, method=method, colorimetry="bt709", chroma_site="mpeg2")
+
+        def go():
+            cs.process_device(fin.data_ptr(), fout.data_ptr(), stream=s.cuda_stream, n_frames=N, in_pitch=ip, out_pitch=op)
+        report(f"{ifmt} {w}x{h} -> {ofmt} {ow}x{oh} {method} (gst-exact)", cs.kernel_name, timed(go, s, 5), N, isz + osz)
+        cs.close()
+        del fin, fout
+
+
 def e2e():
     """element-level (PCIe-inclusive) rate of vfhip_convertscale_process on C2: pageable vs pinned host buffers"""
     import ctypes as C
@@ -254,6 +276,8 @@ def e2e_chain():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "main":
         main()
+    elif len(sys.argv) > 1 and sys.argv[1] == "staged":
+        staged()
     elif len(sys.argv) > 1 and sys.argv[1] == "e2e":
         e2e()
         e2e_chain()
