@@ -526,6 +526,8 @@ static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
       p.w = iw; p.h = ih; p.in_fmt = h->in.format; p.out_yuy2 = h->out.format == VFHIP_FORMAT_YUY2;
       p.cosited_in = h->in.chroma_site == VFHIP_CHROMA_SITE_H_COSITED; p.cosited_out = h->out.chroma_site == VFHIP_CHROMA_SITE_H_COSITED;
       for (int k = 0; k < 9; k++) p.c[k] = kRgb2Yuv[h->out.color_matrix][k];
+      p.vec = h->in.format == VFHIP_FORMAT_NV12 && getenv ("VFHIP_PLANE_SCALAR") == nullptr &&
+              (((uintptr_t) p.in[0] | (uintptr_t) p.in[1] | (uintptr_t) p.is[0] | (uintptr_t) p.is[1] | (uintptr_t) in_pitch) & 1) == 0;
       hipLaunchKernelGGL (k_to_packed422, grid, dim3 (64, 4), 0, s, p);
     } else if (h->in.format == VFHIP_FORMAT_BGRA || h->in.format == VFHIP_FORMAT_RGBA) {
       Rgb2YuvParams p {};
@@ -537,6 +539,20 @@ static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
       p.w = iw; p.h = ih; p.in_rgba = h->in.format == VFHIP_FORMAT_RGBA; p.planar = out_planar;
       p.cosited = h->out.chroma_site == VFHIP_CHROMA_SITE_H_COSITED;
       for (int k = 0; k < 9; k++) p.c[k] = kRgb2Yuv[h->out.color_matrix][k];
+      if ((((uintptr_t) p.in | (uintptr_t) p.is | (uintptr_t) in_pitch) & 3) == 0 && getenv ("VFHIP_RGB2YUV_SCALAR") == nullptr) {
+        // dword pixel loads + v_dot4: coefficients packed in the input's byte order, positive and negative parts apart
+        Rgb2YuvFastParams q {};
+        q.b = p;
+        auto pack = [&] (int r, int g, int b, bool neg) {
+          auto part = [&] (int c) { return (uint32_t) (neg ? (c < 0 ? -c : 0) : (c > 0 ? c : 0)); };
+          const uint32_t lo = p.in_rgba ? part (r) : part (b), hi = p.in_rgba ? part (b) : part (r);
+          return lo | part (g) << 8 | hi << 16;
+        };
+        q.cy = pack (p.c[0], p.c[1], p.c[2], false);
+        q.cup = pack (p.c[3], p.c[4], p.c[5], false); q.cun = pack (p.c[3], p.c[4], p.c[5], true);
+        q.cvp = pack (p.c[6], p.c[7], p.c[8], false); q.cvn = pack (p.c[6], p.c[7], p.c[8], true);
+        hipLaunchKernelGGL (k_rgb_to_yuv420_fast, grid, dim3 (64, 4), 0, s, q);
+      } else
       hipLaunchKernelGGL (k_rgb_to_yuv420, grid, dim3 (64, 4), 0, s, p);
     } else if (in_packed) {
       FromPackedParams p {};
@@ -547,6 +563,7 @@ static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
       p.v = (uint8_t *) mid.data[2]; p.vs = mid.stride[2];
       p.w = iw; p.h = ih; p.in_yuy2 = h->in.format == VFHIP_FORMAT_YUY2; p.planar = out_planar;
       p.cosited_in = h->in.chroma_site == VFHIP_CHROMA_SITE_H_COSITED; p.cosited_out = h->out.chroma_site == VFHIP_CHROMA_SITE_H_COSITED;
+      p.vec = (((uintptr_t) p.in | (uintptr_t) p.is | (uintptr_t) in_pitch) & 3) == 0 && getenv ("VFHIP_PLANE_SCALAR") == nullptr;
       hipLaunchKernelGGL (k_packed422_to_420, grid, dim3 (64, 4), 0, s, p);
     } else {
       RepackParams p {};
@@ -588,6 +605,7 @@ static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
     fill (p, pc);
     p.in = (const uint8_t *) mid.data[k]; p.is = mid.stride[k];
     p.out = (uint8_t *) out->data[k]; p.os = out->stride[k];
+    p.vec = (((uintptr_t) p.in | (uintptr_t) p.is | (uintptr_t) mid_pitch) & 3) == 0 && getenv ("VFHIP_PLANE_SCALAR") == nullptr;
     dim3 grid ((unsigned) ((pc.n * pc.ow + 255) / 256), (unsigned) ((pc.oh + 3) / 4), nz);
     hipLaunchKernelGGL (k_scale_plane, grid, dim3 (64, 4), 0, s, p);
     VFHIP_CHECK_HIP (hipGetLastError ());

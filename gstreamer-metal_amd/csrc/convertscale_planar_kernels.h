@@ -71,6 +71,67 @@ __global__ __launch_bounds__ (256) void k_rgb_to_yuv420 (const Rgb2YuvParams p0)
     }
 }
 
+// Fast variant for 4-byte-aligned RGB rows: every pixel is ONE dword load and every matrix row one or two `v_dot4_u32_u8`
+// (coefficients packed per byte lane on the host, positive and negative parts apart: the dot product is the same exact
+// integer as the three multiply-adds of k_rgb_to_yuv420, so the bytes are identical).  Same lane = chroma sample mapping.
+struct Rgb2YuvFastParams {
+  Rgb2YuvParams b;
+  uint32_t cy, cup, cun, cvp, cvn;     // packed coefficients in the input's byte order (alpha lane 0)
+};
+
+__device__ __forceinline__ void rgb_chroma (const Rgb2YuvFastParams &q, uint32_t px, int &u, int &v)
+{
+  u = (((int) __builtin_amdgcn_udot4 (px, q.cup, 0u, false) - (int) __builtin_amdgcn_udot4 (px, q.cun, 0u, false)) >> 8) + 128;
+  v = (((int) __builtin_amdgcn_udot4 (px, q.cvp, 0u, false) - (int) __builtin_amdgcn_udot4 (px, q.cvn, 0u, false)) >> 8) + 128;
+}
+
+__global__ __launch_bounds__ (256) void k_rgb_to_yuv420_fast (const Rgb2YuvFastParams q)
+{
+  Rgb2YuvParams p = q.b;
+  p.in += (size_t) blockIdx.z * p.in_pitch;
+  p.y += (size_t) blockIdx.z * p.out_pitch; p.u += (size_t) blockIdx.z * p.out_pitch; if (p.v) p.v += (size_t) blockIdx.z * p.out_pitch;
+  const int k = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+  const int cw = (p.w + 1) >> 1, chh = (p.h + 1) >> 1;
+  if (k >= cw || j >= chh) return;
+  const int x = 2 * k, xr = min (x + 1, p.w - 1), xl = max (x - 1, 0);
+  const int y0 = 2 * j, y1 = min (2 * j + 1, p.h - 1);
+  const uint32_t *r0 = reinterpret_cast<const uint32_t *> (p.in + (size_t) y0 * p.is), *r1 = reinterpret_cast<const uint32_t *> (p.in + (size_t) y1 * p.is);
+  const uint32_t c0 = r0[x], c1 = r1[x], e0 = r0[xr], e1 = r1[xr];
+  int u0, v0, u1, v1;
+  // vertical pair averages of the converted chroma at the centre and right columns (and left, co-sited)
+  rgb_chroma (q, c0, u0, v0); rgb_chroma (q, c1, u1, v1);
+  const int cu = (u0 + u1 + 1) >> 1, cv = (v0 + v1 + 1) >> 1;
+  rgb_chroma (q, e0, u0, v0); rgb_chroma (q, e1, u1, v1);
+  int ru = (u0 + u1 + 1) >> 1, rv = (v0 + v1 + 1) >> 1;
+  int U, V;
+  if (p.cosited) {
+    if (k == cw - 1 && k > 0) { ru = cu; rv = cv; }        // the last sample ignores its right neighbour, unless it is also the first
+    int lu = cu, lv = cv;
+    if (x > 0) {
+      rgb_chroma (q, r0[xl], u0, v0); rgb_chroma (q, r1[xl], u1, v1);
+      lu = (u0 + u1 + 1) >> 1; lv = (v0 + v1 + 1) >> 1;
+    }
+    U = (lu + 2 * cu + ru + 2) >> 2; V = (lv + 2 * cv + rv + 2) >> 2;
+  } else { U = (cu + ru + 1) >> 1; V = (cv + rv + 1) >> 1; }
+  if (p.planar) { p.u[(size_t) j * p.us + k] = (uint8_t) U; p.v[(size_t) j * p.vs + k] = (uint8_t) V; }
+  else {
+    uint8_t *d = p.u + (size_t) j * p.us + 2 * k;
+    if (((uintptr_t) d & 1) == 0) *reinterpret_cast<uint16_t *> (d) = (uint16_t) (U | (V << 8));
+    else { d[0] = (uint8_t) U; d[1] = (uint8_t) V; }
+  }
+  // luma of the 2x2 block: the pair of a row goes out as one 2-byte store when it can
+  const uint32_t ya = (__builtin_amdgcn_udot4 (c0, q.cy, 0u, false) >> 8) + 16, yb = (__builtin_amdgcn_udot4 (e0, q.cy, 0u, false) >> 8) + 16;
+  const uint32_t yc = (__builtin_amdgcn_udot4 (c1, q.cy, 0u, false) >> 8) + 16, yd = (__builtin_amdgcn_udot4 (e1, q.cy, 0u, false) >> 8) + 16;
+  uint8_t *d0 = p.y + (size_t) y0 * p.ys + x, *d1 = p.y + (size_t) (2 * j + 1) * p.ys + x;
+  const bool two = x + 1 < p.w;
+  if (two && ((uintptr_t) d0 & 1) == 0) *reinterpret_cast<uint16_t *> (d0) = (uint16_t) (ya | (yb << 8));
+  else { d0[0] = (uint8_t) ya; if (two) d0[1] = (uint8_t) yb; }
+  if (2 * j + 1 < p.h) {
+    if (two && ((uintptr_t) d1 & 1) == 0) *reinterpret_cast<uint16_t *> (d1) = (uint16_t) (yc | (yd << 8));
+    else { d1[0] = (uint8_t) yc; if (two) d1[1] = (uint8_t) yd; }
+  }
+}
+
 struct RepackParams {
   size_t in_pitch, out_pitch;
   const uint8_t *iy, *iu, *iv; int iys, ius, ivs;
@@ -108,6 +169,7 @@ struct PlaneScaleParams {
   int istep, ostep;        // bytes between consecutive samples of this plane (n for a plane of its own; 2 / 4 for the
                            // luma / chroma lines interleaved in a packed 4:2:2 frame); hmode 1 / 2 need istep == 1
   size_t in_pitch, out_pitch;   // batch: frame k of the launch at base + k * pitch (blockIdx.z)
+  int vec;                 // source rows are 4-byte aligned: hmode 0 / 2 read dwords
   int hmode;               // 0: no horizontal scaling, 1: edge-aligned 16.16 (1 x u8), 2: pair average (1 x u8), 3: table (6-bit taps)
   int vscale_on, vfirst;
   uint32_t hinc;
@@ -175,11 +237,41 @@ __global__ __launch_bounds__ (256) void k_scale_plane (const PlaneScaleParams p0
   if (p.vscale_on) { i0 = p.vtab[4 * y]; i1 = p.vtab[4 * y + 1]; wt = p.vtab[4 * y + 2]; }
   const uint8_t *r0 = p.in + (size_t) i0 * p.is, *r1 = p.in + (size_t) i1 * p.is;
   uint32_t v = 0;
+  if (p.vec && bx + 3 < wb && p.hmode == 0) {
+    // no horizontal pass: four consecutive bytes of each source row are one dword
+    const uint32_t a4 = *reinterpret_cast<const uint32_t *> (r0 + bx);
+    if (!p.vscale_on) v = a4;
+    else {
+      const uint32_t b4 = *reinterpret_cast<const uint32_t *> (r1 + bx);
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int b = min (bx + k, wb - 1);
-    const int x = p.n == 2 ? b >> 1 : b, c = p.n == 2 ? b & 1 : 0;
-    v |= (uint32_t) plane_sample (p, r0, r1, wt, x, c) << (8 * k);
+      for (int k = 0; k < 4; k++) {
+        const int a = (a4 >> (8 * k)) & 0xff, b = (b4 >> (8 * k)) & 0xff;
+        v |= (uint32_t) (a + (((b - a) * wt + 128) >> 8)) << (8 * k);
+      }
+    }
+  } else if (p.vec && bx + 3 < wb && p.hmode == 2) {
+    // exactly halved 1 x u8 plane: eight consecutive source bytes per row = two dwords
+    const uint32_t *s0 = reinterpret_cast<const uint32_t *> (r0 + 2 * bx), *s1 = reinterpret_cast<const uint32_t *> (r1 + 2 * bx);
+    const uint32_t a8[2] = { s0[0], s0[1] };
+    uint32_t b8[2] = { a8[0], a8[1] };
+    if (p.vscale_on) { b8[0] = s1[0]; b8[1] = s1[1]; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int sh = 16 * (k & 1);
+      const int a0 = (a8[k >> 1] >> sh) & 0xff, a1 = (a8[k >> 1] >> (sh + 8)) & 0xff, b0 = (b8[k >> 1] >> sh) & 0xff, b1 = (b8[k >> 1] >> (sh + 8)) & 0xff;
+      int r;
+      if (!p.vscale_on) r = (a0 + a1 + 1) >> 1;
+      else if (p.vfirst) { const int l = a0 + (((b0 - a0) * wt + 128) >> 8), m = a1 + (((b1 - a1) * wt + 128) >> 8); r = (l + m + 1) >> 1; }
+      else { const int l = (a0 + a1 + 1) >> 1, m = (b0 + b1 + 1) >> 1; r = l + (((m - l) * wt + 128) >> 8); }
+      v |= (uint32_t) r << (8 * k);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int b = min (bx + k, wb - 1);
+      const int x = p.n == 2 ? b >> 1 : b, c = p.n == 2 ? b & 1 : 0;
+      v |= (uint32_t) plane_sample (p, r0, r1, wt, x, c) << (8 * k);
+    }
   }
   uint8_t *d = p.out + (size_t) y * p.os + bx;
   if (bx + 3 < wb && ((uintptr_t) d & 3) == 0) *reinterpret_cast<uint32_t *> (d) = v;
@@ -240,11 +332,29 @@ __device__ __forceinline__ int chroma_down (const int s[3], int cosited)
   return cosited ? (s[0] + 2 * s[1] + s[2] + 2) >> 2 : (s[1] + s[2] + 1) >> 1;
 }
 
+// Full-resolution chroma at columns x-1, x, x+1 (x = 2k) from the three samples cm, c0, cp of one row (already clamped at
+// the row ends): the same values chroma_up_h gives, without re-reading the row
+__device__ __forceinline__ void chroma_up3 (int cm, int c0, int cp, int cosited, int &L, int &C, int &R)
+{
+  if (cosited) { C = c0; R = (c0 + cp + 1) >> 1; L = (cm + c0 + 1) >> 1; }
+  else { C = (3 * c0 + cm + 2) >> 2; R = (3 * c0 + cp + 2) >> 2; L = (3 * cm + c0 + 2) >> 2; }
+}
+// horizontal 2:1 down-sampling of chroma sample k from the columns L (x-1), C (x), R (x+1), with chroma_down_cols' edge rules
+__device__ __forceinline__ int chroma_down3 (int L, int C, int R, int k, int cw, int w, int cosited)
+{
+  if (2 * k + 1 > w - 1) R = C;                        // odd width: the last column pairs with itself
+  if (!cosited) return (C + R + 1) >> 1;
+  if (k == cw - 1 && k > 0) R = C;                     // the last sample ignores its right neighbour, unless it is also the first
+  if (k == 0) L = C;
+  return (L + 2 * C + R + 2) >> 2;
+}
+
 struct ToPackedParams {
   size_t in_pitch, out_pitch;
   const uint8_t *in[3]; int is[3];
   uint8_t *out; int os;
   int w, h, in_fmt, out_yuy2, cosited_in, cosited_out;
+  int vec;                 // NV12 rows are 2-byte aligned: a U/V (or luma) pair is one 16-bit load
   int c[9];                // RGB -> YUV matrix (RGB inputs)
 };
 
@@ -287,6 +397,25 @@ __global__ __launch_bounds__ (256) void k_to_packed422 (const ToPackedParams p0)
     case VFHIP_FORMAT_NV12: {          // generic path: up h (input siting), up v (3:1 with the nearer row), down h (output siting)
       const int chh = (p.h + 1) >> 1, j = y >> 1, jn = (y & 1) ? min (j + 1, chh - 1) : max (j - 1, 0);
       const uint8_t *r0 = p.in[1] + (size_t) j * p.is[1], *r1 = p.in[1] + (size_t) jn * p.is[1];
+      if (p.vec) {
+        // three U/V pairs per chroma row, each one 16-bit load; the full-resolution columns x-1, x, x+1 come from them
+        const int km = max (k - 1, 0), kp = min (k + 1, cw - 1);
+        const uint16_t *q0 = reinterpret_cast<const uint16_t *> (r0), *q1 = reinterpret_cast<const uint16_t *> (r1);
+        const uint32_t a[3] = { q0[km], q0[k], q0[kp] }, b[3] = { q1[km], q1[k], q1[kp] };
+        int s[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+          int L0, C0, R0, L1, C1, R1;
+          chroma_up3 ((a[0] >> (8 * c)) & 0xff, (a[1] >> (8 * c)) & 0xff, (a[2] >> (8 * c)) & 0xff, p.cosited_in, L0, C0, R0);
+          chroma_up3 ((b[0] >> (8 * c)) & 0xff, (b[1] >> (8 * c)) & 0xff, (b[2] >> (8 * c)) & 0xff, p.cosited_in, L1, C1, R1);
+          s[c] = chroma_down3 ((3 * L0 + L1 + 2) >> 2, (3 * C0 + C1 + 2) >> 2, (3 * R0 + R1 + 2) >> 2, k, cw, p.w, p.cosited_out);
+        }
+        U = s[0]; V = s[1];
+        const uint8_t *yr = p.in[0] + (size_t) y * p.is[0] + x;
+        if (x + 1 < p.w) { const uint32_t yy = *reinterpret_cast<const uint16_t *> (yr); Y0 = yy & 0xff; Y1 = yy >> 8; }
+        else Y0 = Y1 = yr[0];
+        break;
+      }
       int xs[3], su[3], sv[3];
       chroma_down_cols (k, cw, p.w, p.cosited_out, xs);
 #pragma unroll
@@ -317,6 +446,7 @@ struct FromPackedParams {
   const uint8_t *in; int is;
   uint8_t *y, *u, *v; int ys, us, vs;     // NV12: u = uv plane, v unused
   int w, h, in_yuy2, planar, cosited_in, cosited_out;
+  int vec;                 // packed rows are 4-byte aligned: a macro-pixel is one dword load
 };
 
 // one lane = one 4:2:0 chroma sample (and the 2x2 luma block under it)
@@ -334,6 +464,35 @@ __global__ __launch_bounds__ (256) void k_packed422_to_420 (const FromPackedPara
   if (p.planar) {                      // fast path: vertical pair average, no horizontal step
     U = (r0[4 * k + uo] + r1[4 * k + uo] + 1) >> 1; V = (r0[4 * k + vo] + r1[4 * k + vo] + 1) >> 1;
     p.u[(size_t) j * p.us + k] = (uint8_t) U; p.v[(size_t) j * p.vs + k] = (uint8_t) V;
+  } else if (p.vec) {                  // generic path on whole macro-pixels: three dword loads per row give U, V and the luma block
+    const int km = max (k - 1, 0), kp = min (k + 1, cw - 1);
+    const uint32_t *q0 = reinterpret_cast<const uint32_t *> (r0), *q1 = reinterpret_cast<const uint32_t *> (r1);
+    const uint32_t a[3] = { q0[km], q0[k], q0[kp] }, b[3] = { q1[km], q1[k], q1[kp] };
+    int s[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const int sh = 8 * (c ? vo : uo);
+      int L0, C0, R0, L1, C1, R1;
+      chroma_up3 ((a[0] >> sh) & 0xff, (a[1] >> sh) & 0xff, (a[2] >> sh) & 0xff, p.cosited_in, L0, C0, R0);
+      chroma_up3 ((b[0] >> sh) & 0xff, (b[1] >> sh) & 0xff, (b[2] >> sh) & 0xff, p.cosited_in, L1, C1, R1);
+      s[c] = chroma_down3 ((L0 + L1 + 1) >> 1, (C0 + C1 + 1) >> 1, (R0 + R1 + 1) >> 1, k, cw, p.w, p.cosited_out);
+    }
+    uint8_t *d = p.u + (size_t) j * p.us + 2 * k;
+    if (((uintptr_t) d & 1) == 0) *reinterpret_cast<uint16_t *> (d) = (uint16_t) (s[0] | (s[1] << 8));
+    else { d[0] = (uint8_t) s[0]; d[1] = (uint8_t) s[1]; }
+    // luma: the two samples of each row from the macro-pixels already loaded, one 2-byte store per row when it can
+    const bool two = 2 * k + 1 < p.w;
+#pragma unroll
+    for (int dd = 0; dd < 2; dd++) {
+      const int yy = 2 * j + dd;
+      if (yy >= p.h) break;
+      const uint32_t m = dd ? b[1] : a[1];
+      const uint32_t l0 = (m >> (8 * yo)) & 0xff, l1 = (m >> (8 * yo + 16)) & 0xff;
+      uint8_t *o = p.y + (size_t) yy * p.ys + 2 * k;
+      if (two && ((uintptr_t) o & 1) == 0) *reinterpret_cast<uint16_t *> (o) = (uint16_t) (l0 | (l1 << 8));
+      else { o[0] = (uint8_t) l0; if (two) o[1] = (uint8_t) l1; }
+    }
+    return;
   } else {                             // generic path: up h (input siting), vertical pair average, down h (output siting)
     int xs[3], su[3], sv[3];
     chroma_down_cols (k, cw, p.w, p.cosited_out, xs);

@@ -430,3 +430,18 @@ def test_staged_cells_batched(vfhip, oracle, ifmt, ofmt, w, h, ow, oh, method):
             want = oracle.convertscale(ifmt, w, h, host[k, :isz].numpy(), "bt709", "mpeg2", method, ofmt, ow, oh)
             assert np.array_equal(meaningful(ofmt, ow, oh, out[k, :osz]), meaningful(ofmt, ow, oh, want)), f"batch {n} frame {k}"
     cs.close()
+
+
+def test_staged_scalar_fallbacks_match(vfhip, oracle, monkeypatch):
+    """the byte-wise kernels that take over when rows are not 4-byte aligned (forced here with the tuning knobs) produce the
+    same frames as the dword / v_dot4 variants"""
+    monkeypatch.setenv("VFHIP_RGB2YUV_SCALAR", "1")
+    monkeypatch.setenv("VFHIP_PLANE_SCALAR", "1")
+    rng = np.random.default_rng(77)
+    for (ifmt, ofmt, w, h, ow, oh) in [("BGRA", "NV12", 64, 36, 64, 36), ("RGBA", "I420", 67, 41, 33, 20), ("NV12", "NV12", 128, 72, 64, 36),
+                                       ("I420", "I420", 128, 72, 64, 72), ("NV12", "I420", 96, 54, 96, 27), ("NV12", "UYVY", 67, 41, 67, 41),
+                                       ("NV12", "YUY2", 64, 36, 50, 20), ("YUY2", "NV12", 67, 41, 67, 41), ("UYVY", "NV12", 64, 36, 90, 50)]:
+        raw = rng.integers(0, 256, oracle_lib.raw_layout(ifmt, w, h)[1], dtype=np.uint8)
+        got, _ = run(vfhip, ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", ofmt, ow, oh)
+        want = oracle.convertscale(ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", ofmt, ow, oh)
+        assert np.array_equal(meaningful(ofmt, ow, oh, got), meaningful(ofmt, ow, oh, want)), (ifmt, ofmt, w, h, ow, oh)
