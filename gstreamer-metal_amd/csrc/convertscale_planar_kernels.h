@@ -265,6 +265,41 @@ __global__ __launch_bounds__ (256) void k_scale_plane (const PlaneScaleParams p0
       else { const int l = (a0 + a1 + 1) >> 1, m = (b0 + b1 + 1) >> 1; r = l + (((m - l) * wt + 128) >> 8); }
       v |= (uint32_t) r << (8 * k);
     }
+  } else if (p.vec && bx + 3 < wb && p.hmode == 3 && p.n == 2) {
+    // NV12 chroma with table taps: a U/V pair is one 16-bit load, a table entry one 16-byte load
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int4 e = reinterpret_cast<const int4 *> (p.htab)[(bx >> 1) + k];
+      const uint16_t *q0 = reinterpret_cast<const uint16_t *> (r0), *q1 = reinterpret_cast<const uint16_t *> (r1);
+      const uint32_t a0 = q0[e.x], a1 = q0[e.y];
+      uint32_t b0 = a0, b1 = a1;
+      if (p.vscale_on) { b0 = q1[e.x]; b1 = q1[e.y]; }
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        const int l0 = (a0 >> (8 * c)) & 0xff, l1 = (a1 >> (8 * c)) & 0xff, m0 = (b0 >> (8 * c)) & 0xff, m1 = (b1 >> (8 * c)) & 0xff;
+        int r;
+        if (!p.vscale_on) r = (l0 * (64 - e.z) + l1 * e.z + 32) >> 6;
+        else if (p.vfirst) { const int l = l0 + (((m0 - l0) * wt + 128) >> 8), m = l1 + (((m1 - l1) * wt + 128) >> 8); r = (l * (64 - e.z) + m * e.z + 32) >> 6; }
+        else { const int l = (l0 * (64 - e.z) + l1 * e.z + 32) >> 6, m = (m0 * (64 - e.z) + m1 * e.z + 32) >> 6; r = l + (((m - l) * wt + 128) >> 8); }
+        v |= (uint32_t) r << (16 * k + 8 * c);
+      }
+    }
+  } else if (p.vec && bx + 3 < wb && p.hmode == 1) {
+    // edge-aligned 16.16 taps on a 1 x u8 plane: the two taps are neighbouring bytes -> one (unaligned) 16-bit load per row
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t t = (uint32_t) (bx + k) * p.hinc;
+      const int i = min ((int) (t >> 16), p.w - 1), f = (int) ((t >> 8) & 0xff);
+      uint16_t pa, pb;
+      if (i + 1 < p.w) { __builtin_memcpy (&pa, r0 + i, 2); __builtin_memcpy (&pb, r1 + i, 2); }
+      else { pa = (uint16_t) (r0[i] * 0x101u); pb = (uint16_t) (r1[i] * 0x101u); }
+      const int a0 = pa & 0xff, a1 = pa >> 8, b0 = pb & 0xff, b1 = pb >> 8;
+      int r;
+      if (!p.vscale_on) r = (a0 * (256 - f) + a1 * f) >> 8;
+      else if (p.vfirst) { const int l = a0 + (((b0 - a0) * wt + 128) >> 8), m = a1 + (((b1 - a1) * wt + 128) >> 8); r = (l * (256 - f) + m * f) >> 8; }
+      else { const int l = (a0 * (256 - f) + a1 * f) >> 8, m = (b0 * (256 - f) + b1 * f) >> 8; r = l + (((m - l) * wt + 128) >> 8); }
+      v |= (uint32_t) r << (8 * k);
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
