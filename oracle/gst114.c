@@ -255,20 +255,34 @@ static int cubic_n_taps (int in, int out)
   return (int) __builtin_ceil (2.0 * 2.0 / fx);
 }
 
-/* pinned domain: the line is at least as long as the filter (n_taps <= in) and n_taps <= 64; GstVideoResampler's handling
- * of shorter lines (it truncates the filter) is not restated */
-int gst114_cubic_taps (int in, int out, int *idx, int *taps, int max_entries)
+/* n_taps of the LINEAR method without a tap limit (what videoscale's catrom leaves the chroma planes of a planar frame
+ * with): envelope 1 -> ceil (2 / fx) */
+static int linear_n_taps (int in, int out)
 {
-  const int n = cubic_n_taps (in, out);
+  const double scale = (double) in / (double) out;
+  const double fx = scale > 1.0 ? 1.0 / scale : 1.0;
+  return (int) __builtin_ceil (2.0 * 1.0 / fx);
+}
+
+/* pinned domain: the line is at least as long as the filter (n_taps <= in) and n_taps <= 64; GstVideoResampler's handling
+ * of shorter lines (it truncates the filter) is not restated.  kernel: 0 = cubic (catrom), 1 = linear (1 - |a|). */
+static int resampler_taps (int kernel, int in, int out, int *idx, int *taps, int max_entries)
+{
+  const int n = kernel ? linear_n_taps (in, out) : cubic_n_taps (in, out);
   if (n > 64 || n > in || (long) n * out > max_entries) return -1;
-  const double fx = 2.0 * 2.0 / n;
+  const double fx = (kernel ? 2.0 * 1.0 : 2.0 * 2.0) / n;
   for (int j = 0; j < out; j++) {
     double x = ((j + 0.5) / out) * in - 0.5;        /* this order: the quotient first (it decides which way exact .5 ties fall) */
     x = x < 0.0 ? 0.0 : (x > in - 1.0 ? in - 1.0 : x);
     const int xi = (int) __builtin_floor (x) - (n - 1) / 2;
     double w[64], sum = 0.0, m[64];
     int pos[64], cnt = 0;
-    for (int l = 0; l < n; l++) { w[l] = cubic_k ((x - (xi + l)) * fx); sum += w[l]; }
+    for (int l = 0; l < n; l++) {
+      const double a = (x - (xi + l)) * fx;
+      if (kernel) { const double aa = a < 0 ? -a : a; w[l] = aa < 1.0 ? 1.0 - aa : 0.0; }
+      else w[l] = cubic_k (a);
+      sum += w[l];
+    }
     for (int l = 0; l < n; l++) {                    /* merge clamped taps (in tap order: left edge first) */
       const int k = clampi (xi + l, 0, in - 1);
       if (cnt > 0 && pos[cnt - 1] == k) m[cnt - 1] += w[l] / sum;
@@ -290,6 +304,9 @@ int gst114_cubic_taps (int in, int out, int *idx, int *taps, int max_entries)
   }
   return n;
 }
+
+int gst114_cubic_taps (int in, int out, int *idx, int *taps, int max_entries) { return resampler_taps (0, in, out, idx, taps, max_entries); }
+int gst114_linear_ntaps (int in, int out, int *idx, int *taps, int max_entries) { return resampler_taps (1, in, out, idx, taps, max_entries); }
 
 static int cubic_pass (const uint8_t *in, int is, int w, int h, uint8_t *out, int os, int on, int vertical)
 {
@@ -732,4 +749,84 @@ int gst114_scale_packed422_nearest (const uint8_t *in, int is, int yuy2, int w, 
     }
   }
   return 0;
+}
+
+/* ---- videoscale method=catrom on YUV frames (pinned by 48 real-pipeline vectors, tests/golden/convertscale_gst114_yuvcubic.npz):
+ *   the luma plane and all three interleaved lines of a packed frame take the catrom n-tap passes of the 4 x u8 case;
+ *   the CHROMA planes of a planar frame (I420 U / V, NV12 UV) do not: GstVideoConverter scales them with its LINEAR
+ *   method without videoscale's 2-tap limit, n_taps = ceil (2 * max (1, in / out)).  Each pass picks its line function by
+ *   its own tap count: 2 taps -> the pinned 2-tap functions (vertical 8-bit; horizontal edge-aligned 16.16 for 1 x u8,
+ *   centre-aligned 6-bit for 2 x u8), more -> the generic n-tap function (6-bit taps, clamp ((sum + 32) >> 6));
+ *   vertical pass first iff in_h > out_h + n_taps_v.  Same domain: every scaled line is at least as long as its filter. */
+static int ntap_line_pass (int kernel, const uint8_t *in, int is, int istep, int w, int h, int n, uint8_t *out, int os, int ostep, int on, int vertical)
+{
+  const int len = vertical ? h : w;
+  const int nt = kernel ? linear_n_taps (len, on) : cubic_n_taps (len, on);
+  if (kernel && nt == 2) {                            /* the special 2-tap line functions (n = istep = ostep here) */
+    if (vertical) vscale_plane (in, is, n * w, h, out, os, on);
+    else hscale_plane (in, is, w, h, n, out, os, on, 0);
+    return 0;
+  }
+  int *idx = malloc (sizeof (int) * (size_t) nt * on), *tp = malloc (sizeof (int) * (size_t) nt * on);
+  if (!idx || !tp || resampler_taps (kernel, len, on, idx, tp, nt * on) < 0) { free (idx); free (tp); return -3; }
+  const int oh_ = vertical ? on : h, ow_ = vertical ? w : on;
+  for (int y = 0; y < oh_; y++)
+    for (int x = 0; x < ow_; x++)
+      for (int c = 0; c < n; c++) {
+        int acc = 0;
+        for (int l = 0; l < nt; l++)
+          acc += (vertical ? in[(size_t) idx[y * nt + l] * is + istep * x + c] : in[(size_t) y * is + istep * idx[x * nt + l] + c]) * (vertical ? tp[y * nt + l] : tp[x * nt + l]);
+        out[(size_t) y * os + ostep * x + c] = (uint8_t) clampi ((acc + 32) >> 6, 0, 255);
+      }
+  free (idx); free (tp);
+  return 0;
+}
+
+static int ntap_ok (int kernel, int in, int out) { const int n = kernel ? linear_n_taps (in, out) : cubic_n_taps (in, out); return in == out || (n <= in && n <= 64); }
+
+/* one line set: n components per sample, samples istep / ostep bytes apart (the linear kernel is only used on planes of
+ * their own: istep = ostep = n) */
+static int scale_line_ntap (int kernel, const uint8_t *in, int is, int istep, int w, int h, int n, uint8_t *out, int os, int ostep, int ow, int oh)
+{
+  if (!ntap_ok (kernel, w, ow) || !ntap_ok (kernel, h, oh)) return -3;
+  if (ow == w && oh == h) {
+    for (int y = 0; y < h; y++) for (int x = 0; x < w; x++) for (int c = 0; c < n; c++) out[(size_t) y * os + ostep * x + c] = in[(size_t) y * is + istep * x + c];
+    return 0;
+  }
+  if (ow == w) return ntap_line_pass (kernel, in, is, istep, w, h, n, out, os, ostep, oh, 1);
+  if (oh == h) return ntap_line_pass (kernel, in, is, istep, w, h, n, out, os, ostep, ow, 0);
+  int rc;
+  const int nv = kernel ? linear_n_taps (h, oh) : cubic_n_taps (h, oh);
+  if (h > oh + nv) {
+    uint8_t *tmp = malloc ((size_t) oh * w * n); if (!tmp) return -2;
+    rc = ntap_line_pass (kernel, in, is, istep, w, h, n, tmp, w * n, n, oh, 1);
+    if (!rc) rc = ntap_line_pass (kernel, tmp, w * n, n, w, oh, n, out, os, ostep, ow, 0);
+    free (tmp);
+  } else {
+    uint8_t *tmp = malloc ((size_t) h * ow * n); if (!tmp) return -2;
+    rc = ntap_line_pass (kernel, in, is, istep, w, h, n, tmp, ow * n, n, ow, 0);
+    if (!rc) rc = ntap_line_pass (kernel, tmp, ow * n, n, ow, h, n, out, os, ostep, oh, 1);
+    free (tmp);
+  }
+  return rc;
+}
+#define scale_line_cubic(in, is, istep, w, h, n, out, os, ostep, ow, oh) scale_line_ntap (0, in, is, istep, w, h, n, out, os, ostep, ow, oh)
+
+/* `chroma`: a chroma plane of a planar frame (linear kernel); otherwise the luma plane (catrom) */
+int gst114_scale_plane_cubic (const uint8_t *in, int is, int w, int h, int n, uint8_t *out, int os, int ow, int oh, int chroma)
+{
+  if (w <= 0 || h <= 0 || ow <= 0 || oh <= 0 || (n != 1 && n != 2)) return -1;
+  return scale_line_ntap (chroma ? 1 : 0, in, is, n, w, h, n, out, os, n, ow, oh);
+}
+
+int gst114_scale_packed422_cubic (const uint8_t *in, int is, int yuy2, int w, int h, uint8_t *out, int os, int ow, int oh)
+{
+  if (w <= 0 || h <= 0 || ow <= 0 || oh <= 0) return -1;
+  int yo, uo, vo; pk_offsets (yuy2, &yo, &uo, &vo);
+  const int cw = (w + 1) / 2, cow = (ow + 1) / 2;
+  int rc = scale_line_cubic (in + yo, is, 2, w, h, 1, out + yo, os, 2, ow, oh);
+  if (!rc) rc = scale_line_cubic (in + uo, is, 4, cw, h, 1, out + uo, os, 4, cow, oh);
+  if (!rc) rc = scale_line_cubic (in + vo, is, 4, cw, h, 1, out + vo, os, 4, cow, oh);
+  if (!rc && (ow & 1)) for (int y = 0; y < oh; y++) out[(size_t) y * os + 2 * ow + yo] = out[(size_t) y * os + 2 * (ow - 1) + yo];
+  return rc;
 }

@@ -34,6 +34,9 @@ int gst114_packed422_swizzle (const uint8_t *in, int is, int in_yuy2, int w, int
 int gst114_packed422_to_yuv420 (const uint8_t *in, int is, int yuy2, int w, int h, int cosited_in, int cosited_out, int planar,
     uint8_t *yp, int ys, uint8_t *up, int us, uint8_t *vp, int vs);
 int gst114_scale_packed422 (const uint8_t *in, int is, int yuy2, int w, int h, uint8_t *out, int os, int ow, int oh);
+int gst114_scale_plane_cubic (const uint8_t *in, int is, int w, int h, int n, uint8_t *out, int os, int ow, int oh, int chroma);
+int gst114_linear_ntaps (int in, int out, int *idx, int *taps, int max_entries);
+int gst114_scale_packed422_cubic (const uint8_t *in, int is, int yuy2, int w, int h, uint8_t *out, int os, int ow, int oh);
 int gst114_scale_plane_nearest (const uint8_t *in, int is, int w, int h, int n, uint8_t *out, int os, int ow, int oh);
 int gst114_scale_packed422_nearest (const uint8_t *in, int is, int yuy2, int w, int h, uint8_t *out, int os, int ow, int oh);
 int gst114_default_matrix (int height);

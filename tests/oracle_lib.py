@@ -92,8 +92,8 @@ class Oracle:
             if rc != 0:
                 raise RuntimeError(f"oracle rc={rc}")
             return out
-        assert method in ("bilinear", "nearest"), "planar / packed bicubic scaling is not restated"
         near = method == "nearest"
+        sfx = {"bilinear": "", "nearest": "_nearest", "bicubic": "_cubic"}[method]
         if out_format in ("UYVY", "YUY2"):
             # videoconvert at the input size -> packed frame of the output format, then videoscale on the packed frame
             ms, yuy2 = r4(2 * w), int(out_format == "YUY2")
@@ -111,7 +111,9 @@ class Oracle:
             assert rc == 0
             os_ = r4(2 * ow)
             out = np.zeros(os_ * oh, np.uint8)
-            assert (L.gst114_scale_packed422_nearest if near else L.gst114_scale_packed422)(self._p(mid), ms, yuy2, w, h, self._p(out), os_, ow, oh) == 0
+            rc = getattr(L, "gst114_scale_packed422" + sfx)(self._p(mid), ms, yuy2, w, h, self._p(out), os_, ow, oh)
+            if rc != 0:
+                raise RuntimeError(f"oracle rc={rc}")
             return out
         # stage 1: videoconvert at the input size -> planes of the output format
         cw, ch = (w + 1) // 2, (h + 1) // 2
@@ -152,16 +154,19 @@ class Oracle:
         lay, size = raw_layout(out_format, ow, oh)
         out = np.zeros(size, np.uint8)
 
-        def scale(src, sw, sh, n, off, stride, dw, dh):
+        def scale(src, sw, sh, n, off, stride, dw, dh, chroma=False):
             src = np.ascontiguousarray(src)
-            rc = (L.gst114_scale_plane_nearest if near else L.gst114_scale_plane)(self._p(src), src.strides[0], sw, sh, n, self._p(out, off), stride, dw, dh)
-            assert rc == 0
+            args = (self._p(src), src.strides[0], sw, sh, n, self._p(out, off), stride, dw, dh)
+            # videoscale method=catrom: catrom on the luma plane, GstVideoConverter's un-limited LINEAR taps on the chroma planes
+            rc = L.gst114_scale_plane_cubic(*args, int(chroma)) if method == "bicubic" else getattr(L, "gst114_scale_plane" + sfx)(*args)
+            if rc != 0:
+                raise RuntimeError(f"oracle rc={rc}")
         scale(Y, w, h, 1, lay[0][0], lay[0][1], ow, oh)
         if out_format == "NV12":
-            scale(C[0], cw, ch, 2, lay[1][0], lay[1][1], ocw, och)
+            scale(C[0], cw, ch, 2, lay[1][0], lay[1][1], ocw, och, chroma=True)
         else:
-            scale(C[0], cw, ch, 1, lay[1][0], lay[1][1], ocw, och)
-            scale(C[1], cw, ch, 1, lay[2][0], lay[2][1], ocw, och)
+            scale(C[0], cw, ch, 1, lay[1][0], lay[1][1], ocw, och, chroma=True)
+            scale(C[1], cw, ch, 1, lay[2][0], lay[2][1], ocw, och, chroma=True)
         return out
 
 

@@ -95,17 +95,29 @@ def gst_undefined_packed(oracle, c, frames):
     w, h, ow, oh = c["w"], c["h"], c["ow"], c["oh"]
     if w == 2 and ow != w:
         return None
-    if not (h > oh + 2 and ow != w and oh != h and (w & 1)):
+    import math
+    cubic = c["method"] == "bicubic"
+    nv = math.ceil(4 * max(1.0, h / oh)) if cubic else 2          # taps of the vertical pass: it runs first iff h > oh + nv
+    if c["method"] == "nearest" or not (h > oh + nv and ow != w and oh != h and (w & 1)):
         return frames
     cw, cow, stride = (w + 1) // 2, (ow + 1) // 2, oracle_lib.r4(2 * ow)
     vo = 3 if c["out_format"] == "YUY2" else 2
     out = [np.array(f[: stride * oh]).reshape(oh, stride) for f in frames]
-    for k in range(cow):
-        i0, i1, t0, t1 = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-        oracle.lib.gst114_linear_taps(cw, cow, k, 6, C.byref(i0), C.byref(i1), C.byref(t0), C.byref(t1))
-        if cw - 1 in (i0.value, i1.value):
-            for f in out:
-                f[:, 4 * k + vo] = 0
+    if cubic:
+        n = math.ceil(4 * max(1.0, cw / cow))
+        idx, taps = (C.c_int * (n * cow))(), (C.c_int * (n * cow))()
+        assert oracle.lib.gst114_cubic_taps(cw, cow, idx, taps, n * cow) == n
+        touched = [k for k in range(cow) if cw - 1 in idx[k * n:(k + 1) * n]]
+    else:
+        touched = []
+        for k in range(cow):
+            i0, i1, t0, t1 = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            oracle.lib.gst114_linear_taps(cw, cow, k, 6, C.byref(i0), C.byref(i1), C.byref(t0), C.byref(t1))
+            if cw - 1 in (i0.value, i1.value):
+                touched.append(k)
+    for k in touched:
+        for f in out:
+            f[:, 4 * k + vo] = 0
     return [f.reshape(-1) for f in out]
 
 
@@ -149,6 +161,19 @@ def test_oracle_matches_gstreamer_nearest_yuv_outputs(oracle, case):
     got = oracle.convertscale(c["in_format"], c["w"], c["h"], ZN[c["name"] + "_in"], c["colorimetry"], c["chroma_site"],
                               c["method"], c["out_format"], c["ow"], c["oh"])
     assert np.array_equal(meaningful(c["out_format"], c["ow"], c["oh"], got), meaningful(c["out_format"], c["ow"], c["oh"], ZN[c["name"] + "_out"]))
+
+
+# ---- method=bicubic with YUV outputs (48 vectors from the real elements) -------------------------------------------------
+MANIFEST_C, ZC = oracle_lib.load_golden("convertscale_gst114_yuvcubic.npz")
+
+
+@pytest.mark.parametrize("case", MANIFEST_C, ids=[c["name"] for c in MANIFEST_C])
+def test_oracle_matches_gstreamer_bicubic_yuv_outputs(oracle, case):
+    c = case
+    got = oracle.convertscale(c["in_format"], c["w"], c["h"], ZC[c["name"] + "_in"], c["colorimetry"], c["chroma_site"],
+                              c["method"], c["out_format"], c["ow"], c["oh"])
+    got, want = gst_undefined_packed(oracle, c, [got, ZC[c["name"] + "_out"]])
+    assert np.array_equal(meaningful(c["out_format"], c["ow"], c["oh"], got), meaningful(c["out_format"], c["ow"], c["oh"], want))
 
 
 # ---- bicubic (videoscale method=catrom): 76 vectors from the real elements ------------------------------------------

@@ -335,6 +335,40 @@ def gen_yuv_nearest():
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "yuvnearest":
     gen_yuv_nearest()
     sys.exit(0)
+def gen_yuv_cubic():
+    """`videoscale method=catrom` with YUV outputs (4:2:0 and packed 4:2:2) -> tests/golden/convertscale_gst114_yuvcubic.npz"""
+    cases, arrays = [], {}
+    rng = np.random.default_rng(20261010)
+    cols, sites = ["bt601", "bt709", "bt2020"], ["jpeg", "mpeg2"]
+    fixed = [(64, 36, 32, 18), (64, 36, 100, 50), (66, 34, 33, 17), (34, 18, 80, 42), (48, 40, 20, 38), (62, 60, 62, 24), (50, 20, 125, 20), (70, 58, 36, 16),
+             (33, 17, 16, 9), (35, 29, 18, 8), (31, 30, 13, 12), (128, 72, 40, 24)]
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = build_helper(tmp)
+        t = 0
+        for ifmt in ["BGRA", "NV12", "I420", "UYVY", "YUY2", "RGBA"]:
+            for ofmt in ["NV12", "I420", "UYVY", "YUY2"]:
+                for (w, h, ow, oh) in [fixed[t % 12], tuple(int(v) for v in rng.integers(24, 100, 4))]:
+                    col, site = cols[t % 3], sites[(t // 3) % 2]
+                    size = {"BGRA": w * h * 4, "RGBA": w * h * 4, "NV12": nv12_layout(w, h)[3], "I420": i420_layout(w, h)[4]}.get(ifmt, r4(2 * w) * h)
+                    raw = rng.integers(0, 256, size, dtype=np.uint8).tobytes()
+                    incaps = f"video/x-raw,format={ifmt},width={w},height={h},framerate=1/1"
+                    if ifmt not in ("BGRA", "RGBA"):
+                        incaps += f",colorimetry={col},chroma-site={site}"
+                    out = gst_run(exe, tmp, raw, len(raw), incaps, "videoconvert ! videoscale method=catrom",
+                                  f"video/x-raw,format={ofmt},width={ow},height={oh},colorimetry={col},chroma-site={site}")
+                    name = f"cub_{ifmt.lower()}_to_{ofmt.lower()}_{t:03d}_{w}x{h}_to_{ow}x{oh}"
+                    arrays[name + "_in"], arrays[name + "_out"] = np.frombuffer(raw, np.uint8), np.frombuffer(out, np.uint8)
+                    cases.append(dict(name=name, in_format=ifmt, w=w, h=h, colorimetry=col, chroma_site=site, method="bicubic", out_format=ofmt,
+                                      ow=ow, oh=oh, in_sha256=hashlib.sha256(raw).hexdigest(), out_sha256=hashlib.sha256(out).hexdigest()))
+                    t += 1
+    arrays["manifest"] = np.frombuffer(json.dumps(cases).encode(), np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "convertscale_gst114_yuvcubic.npz"), **arrays)
+    print("wrote", len(cases), "bicubic YUV-output cases")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "yuvcubic":
+    gen_yuv_cubic()
+    sys.exit(0)
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ties":
     gen_ties()
     sys.exit(0)
