@@ -22,10 +22,11 @@ static const int kRgb2Yuv[3][9] = {
 };
 
 struct PlaneCfg {                 // stage-2 set-up of one output plane (gst-exact, 4:2:0 outputs)
-  int w = 0, h = 0, ow = 0, oh = 0, n = 1, hmode = 0, vscale_on = 0, vfirst = 0;
+  int w = 0, h = 0, ow = 0, oh = 0, n = 1, hmode = 0, vmode = 0, vfirst = 0, nh = 0, nv = 0;
   int step = 1, off = 0;                    // packed 4:2:2: bytes between samples, offset of the first one
   uint32_t hinc = 0;
   int *d_vtab = nullptr, *d_htab = nullptr;
+  int2 *d_hnt = nullptr, *d_vnt = nullptr;   // n-tap tables (method=bicubic)
 };
 
 static const int kOrcCoef[3][5] = {
@@ -69,6 +70,8 @@ static void free_tables (VfHipConvertScale *h)
   for (auto &pc : h->plane) {
     if (pc.d_vtab) (void) hipFree (pc.d_vtab);
     if (pc.d_htab) (void) hipFree (pc.d_htab);
+    if (pc.d_hnt) (void) hipFree (pc.d_hnt);
+    if (pc.d_vnt) (void) hipFree (pc.d_vnt);
     pc = PlaneCfg ();
   }
   if (h->mid) (void) hipFree (h->mid);
@@ -136,10 +139,19 @@ static int cubic_n_taps (int in, int out)
 
 static bool cubic_in_domain (int in, int out) { const int n = cubic_n_taps (in, out); return in == out || (n <= in && n <= 64); }
 
-static int cubic_table (int in, int out, std::vector<int2> &tab)
+// un-limited LINEAR method (what videoscale's catrom leaves the chroma planes of a planar frame with): envelope 1
+static int linear_n_taps (int in, int out)
 {
-  const int n = cubic_n_taps (in, out);
-  const double fx = 2.0 * 2.0 / n;
+  const double scale = (double) in / (double) out;
+  const double fx = scale > 1.0 ? 1.0 / scale : 1.0;
+  return (int) std::ceil (2.0 * 1.0 / fx);
+}
+
+// kernel: 0 = cubic (catrom), 1 = linear (1 - |a|)
+static int ntap_table (int kernel, int in, int out, std::vector<int2> &tab)
+{
+  const int n = kernel ? linear_n_taps (in, out) : cubic_n_taps (in, out);
+  const double fx = (kernel ? 2.0 : 4.0) / n;
   tab.assign ((size_t) n * out, make_int2 (0, 0));
   for (int j = 0; j < out; j++) {
     double x = ((j + 0.5) / out) * in - 0.5;        // this order: the quotient first (it decides which way exact .5 ties fall)
@@ -147,7 +159,11 @@ static int cubic_table (int in, int out, std::vector<int2> &tab)
     const int xi = (int) std::floor (x) - (n - 1) / 2;
     double w[64], sum = 0.0, m[64];
     int pos[64], cnt = 0;
-    for (int l = 0; l < n; l++) { w[l] = cubic_k ((x - (xi + l)) * fx); sum += w[l]; }
+    for (int l = 0; l < n; l++) {
+      const double a = (x - (xi + l)) * fx;
+      w[l] = kernel ? (std::fabs (a) < 1.0 ? 1.0 - std::fabs (a) : 0.0) : cubic_k (a);
+      sum += w[l];
+    }
     for (int l = 0; l < n; l++) {                    // taps outside the line are added to the edge tap, in double
       const int k = xi + l < 0 ? 0 : (xi + l > in - 1 ? in - 1 : xi + l);
       if (cnt > 0 && pos[cnt - 1] == k) m[cnt - 1] += w[l] / sum;
@@ -159,6 +175,8 @@ static int cubic_table (int in, int out, std::vector<int2> &tab)
   }
   return n;
 }
+
+static int cubic_table (int in, int out, std::vector<int2> &tab) { return ntap_table (0, in, out, tab); }
 
 static int upload_int2 (const std::vector<int2> &v, int2 **dst)
 {
@@ -191,13 +209,35 @@ static void vertical_taps (int in_h, int out_h, std::vector<int> &vt)
 static int nearest_index (int in, int out, int j);
 
 // `nearest`: every tap table holds the nearest source index with a zero second tap (the 2-tap formulas then return the sample)
-static int setup_plane (PlaneCfg &pc, int w, int h, int ow, int oh, int n, bool table = false, bool nearest = false)
+// `kernel`: -1 = videoscale's bilinear (2 taps), 0 = catrom, 1 = GstVideoConverter's un-limited LINEAR (planar chroma under
+// catrom); with 0 / 1 each pass picks its line function by its own tap count (2 -> the 2-tap modes, more -> n-tap tables)
+static int setup_plane (PlaneCfg &pc, int w, int h, int ow, int oh, int n, bool table = false, bool nearest = false, int kernel = -1)
 {
   pc = PlaneCfg ();
   pc.w = w; pc.h = h; pc.ow = ow; pc.oh = oh; pc.n = n; pc.step = n;
-  pc.vscale_on = oh != h; pc.vfirst = h > oh + 2;
+  pc.vmode = oh != h ? 1 : 0; pc.vfirst = h > oh + 2;
   std::vector<int> vt, ht;
   vertical_taps (h, oh, vt);
+  bool h2tap = true;
+  if (kernel >= 0) {
+    auto taps = [kernel] (int in, int out) { return kernel ? linear_n_taps (in, out) : cubic_n_taps (in, out); };
+    for (int d = 0; d < 2; d++) {
+      const int in = d ? h : w, out = d ? oh : ow;
+      if (in != out && (taps (in, out) > in || taps (in, out) > 64))
+        return set_error (VFHIP_ERR_UNSUPPORTED, "method=bicubic: a %d -> %d line is shorter than its %d-tap filter (or it has more than 64 taps)", in, out, taps (in, out));
+    }
+    if (oh != h && !(kernel == 1 && taps (h, oh) == 2)) {
+      std::vector<int2> tv;
+      pc.nv = ntap_table (kernel, h, oh, tv); pc.vmode = 2;
+      int rc = upload_int2 (tv, &pc.d_vnt); if (rc) return rc;
+    }
+    pc.vfirst = h > oh + (oh != h ? taps (h, oh) : 2);
+    if (ow != w && !(kernel == 1 && taps (w, ow) == 2)) {
+      std::vector<int2> th;
+      pc.nh = ntap_table (kernel, w, ow, th); pc.hmode = 4; h2tap = false;
+      int rc = upload_int2 (th, &pc.d_hnt); if (rc) return rc;
+    }
+  }
   if (nearest) {
     for (int y = 0; y < oh; y++) { vt[4 * y] = vt[4 * y + 1] = nearest_index (h, oh, y); vt[4 * y + 2] = 0; }
     pc.vfirst = 0;
@@ -206,9 +246,9 @@ static int setup_plane (PlaneCfg &pc, int w, int h, int ow, int oh, int n, bool 
       ht.assign ((size_t) ow * 4, 0);
       for (int x = 0; x < ow; x++) ht[4 * x] = ht[4 * x + 1] = nearest_index (w, ow, x);
     }
-  } else
-  if (ow == w) pc.hmode = 0;
-  else if (n == 1 && !table && w == 2 * ow && (oh == h || h == 2 * oh)) pc.hmode = 2;
+  } else if (!h2tap) { /* n-tap table set above */ }
+  else if (ow == w) pc.hmode = 0;
+  else if (n == 1 && !table && kernel < 0 && w == 2 * ow && (oh == h || h == 2 * oh)) pc.hmode = 2;
   else if (n == 1 && !table) { pc.hmode = 1; pc.hinc = (ow > 1 && w > 1) ? (uint32_t) ((((uint64_t) (w - 1)) << 16) / (uint64_t) (ow - 1)) - 1 : 0; }   // a one-sample line is replicated
   else {
     pc.hmode = 3;
@@ -336,14 +376,14 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
   // packed frame scaled horizontally (GStreamer 1.14 emits out-of-line garbage for it) -> metal arithmetic
   const bool out_packed = out->format == VFHIP_FORMAT_UYVY || out->format == VFHIP_FORMAT_YUY2;
   const bool any_yuv_in = in_yuv || in_packed;
-  const bool staged = numerics == VFHIP_NUMERICS_GST_EXACT && (method == VFHIP_SCALE_BILINEAR || method == VFHIP_SCALE_NEAREST) && !h->add_borders &&
+  const bool staged = numerics == VFHIP_NUMERICS_GST_EXACT && !h->add_borders &&
                       ((in_420_or_rgb && out_420) || out_packed || (in_packed && out_420)) &&
                       !(out_packed && in->width == 2 && out->width != 2) &&
                       (!any_yuv_in || (in->color_matrix == out->color_matrix && in->chroma_site == out->chroma_site));
-  if (method == VFHIP_SCALE_BICUBIC) {
+  if (method == VFHIP_SCALE_BICUBIC && !staged) {
     const int iw = in->width, ih = in->height, ow = out->width, oh = out->height;
     if (numerics != VFHIP_NUMERICS_GST_EXACT || !(in_420_or_rgb || in_packed) || !out_rgb || h->add_borders)
-      return set_error (VFHIP_ERR_UNSUPPORTED, "method=bicubic needs numerics=gst-exact, a BGRA / RGBA output and no borders");
+      return set_error (VFHIP_ERR_UNSUPPORTED, "method=bicubic needs numerics=gst-exact and no borders (YUV -> YUV: the same matrix and chroma siting on both sides)");
     if (!cubic_in_domain (iw, ow) || !cubic_in_domain (ih, oh))
       return set_error (VFHIP_ERR_UNSUPPORTED, "method=bicubic: %dx%d -> %dx%d has a line shorter than its filter (or more than 64 taps)", iw, ih, ow, oh);
     std::vector<int2> th_, tv_;
@@ -391,14 +431,15 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
       // NV12's chroma plane (6-bit table taps), vertical pass over every byte
       const int yuy2 = out->format == VFHIP_FORMAT_YUY2;
       const bool nn = method == VFHIP_SCALE_NEAREST;
-      int rc = setup_plane (h->plane[0], iw, ih, ow, oh, 1, true, nn);
-      if (!rc) rc = setup_plane (h->plane[1], (iw + 1) / 2, ih, (ow + 1) / 2, oh, 1, true, nn);
-      if (!rc) rc = setup_plane (h->plane[2], (iw + 1) / 2, ih, (ow + 1) / 2, oh, 1, true, nn);
+      const int kern = method == VFHIP_SCALE_BICUBIC ? 0 : -1;          // catrom runs on all three interleaved lines
+      int rc = setup_plane (h->plane[0], iw, ih, ow, oh, 1, true, nn, kern);
+      if (!rc) rc = setup_plane (h->plane[1], (iw + 1) / 2, ih, (ow + 1) / 2, oh, 1, true, nn, kern);
+      if (!rc) rc = setup_plane (h->plane[2], (iw + 1) / 2, ih, (ow + 1) / 2, oh, 1, true, nn, kern);
       if (rc) return rc;
       h->plane[0].step = 2; h->plane[0].off = yuy2 ? 0 : 1;
       h->plane[1].step = 4; h->plane[1].off = yuy2 ? 1 : 0;
       h->plane[2].step = 4; h->plane[2].off = yuy2 ? 3 : 2;
-      for (int k = 0; k < 3; k++) h->plane[k].vfirst = !nn && ih > oh + 2;
+      if (kern < 0) for (int k = 0; k < 3; k++) h->plane[k].vfirst = !nn && ih > oh + 2;
       if (h->need_convert && h->need_scale) {
         h->mid_bytes = (((size_t) 4 * ((iw + 1) / 2) + 15) / 16 * 16) * ih + 1024;
         VFHIP_CHECK_HIP (hipMalloc (&h->mid, h->mid_bytes));
@@ -409,11 +450,13 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
       return VFHIP_OK;
     }
     const bool nn = method == VFHIP_SCALE_NEAREST;
-    int rc = setup_plane (h->plane[0], iw, ih, ow, oh, 1, nn, nn);
+    // method=bicubic: catrom on the luma plane; the chroma planes get GstVideoConverter's un-limited LINEAR taps (oracle/gst114.c)
+    const int ky = method == VFHIP_SCALE_BICUBIC ? 0 : -1, kc = method == VFHIP_SCALE_BICUBIC ? 1 : -1;
+    int rc = setup_plane (h->plane[0], iw, ih, ow, oh, 1, nn, nn, ky);
     if (rc) return rc;
-    if (out->format == VFHIP_FORMAT_NV12) rc = setup_plane (h->plane[1], (iw + 1) / 2, (ih + 1) / 2, (ow + 1) / 2, (oh + 1) / 2, 2, nn, nn);
-    else { rc = setup_plane (h->plane[1], (iw + 1) / 2, (ih + 1) / 2, (ow + 1) / 2, (oh + 1) / 2, 1, nn, nn);
-           if (!rc) rc = setup_plane (h->plane[2], (iw + 1) / 2, (ih + 1) / 2, (ow + 1) / 2, (oh + 1) / 2, 1, nn, nn); }
+    if (out->format == VFHIP_FORMAT_NV12) rc = setup_plane (h->plane[1], (iw + 1) / 2, (ih + 1) / 2, (ow + 1) / 2, (oh + 1) / 2, 2, nn, nn, kc);
+    else { rc = setup_plane (h->plane[1], (iw + 1) / 2, (ih + 1) / 2, (ow + 1) / 2, (oh + 1) / 2, 1, nn, nn, kc);
+           if (!rc) rc = setup_plane (h->plane[2], (iw + 1) / 2, (ih + 1) / 2, (ow + 1) / 2, (oh + 1) / 2, 1, nn, nn, kc); }
     if (rc) return rc;
     if (h->need_convert && h->need_scale) {        // intermediate frame: output format at the input size
       const size_t ys = ((size_t) iw + 15) / 16 * 16, cs = ((size_t) 2 * ((iw + 1) / 2) + 15) / 16 * 16;
@@ -583,7 +626,8 @@ static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
   auto fill = [&] (PlaneScaleParams &p, const PlaneCfg &pc) {
     p.in_pitch = mid_pitch; p.out_pitch = out_pitch;
     p.w = pc.w; p.h = pc.h; p.ow = pc.ow; p.oh = pc.oh; p.n = pc.n; p.istep = p.ostep = pc.step; p.hmode = pc.hmode;
-    p.vscale_on = pc.vscale_on; p.vfirst = pc.vfirst; p.hinc = pc.hinc; p.vtab = pc.d_vtab; p.htab = pc.d_htab;
+    p.vmode = pc.vmode; p.vfirst = pc.vfirst; p.hinc = pc.hinc; p.vtab = pc.d_vtab; p.htab = pc.d_htab;
+    p.hnt = pc.d_hnt; p.vnt = pc.d_vnt; p.nh = pc.nh; p.nv = pc.nv;
   };
   if (out_packed) {
     PackedScaleParams q {};

@@ -170,58 +170,67 @@ struct PlaneScaleParams {
                            // luma / chroma lines interleaved in a packed 4:2:2 frame); hmode 1 / 2 need istep == 1
   size_t in_pitch, out_pitch;   // batch: frame k of the launch at base + k * pitch (blockIdx.z)
   int vec;                 // source rows are 4-byte aligned: hmode 0 / 2 read dwords
-  int hmode;               // 0: no horizontal scaling, 1: edge-aligned 16.16 (1 x u8), 2: pair average (1 x u8), 3: table (6-bit taps)
-  int vscale_on, vfirst;
+  int hmode;               // 0: no horizontal scaling, 1: edge-aligned 16.16 (1 x u8), 2: pair average (1 x u8), 3: 2-tap table (6-bit), 4: n-tap table
+  int vmode;               // 0: no vertical scaling, 1: 2-tap 8-bit (vtab), 2: n-tap 6-bit (vnt)
+  int vfirst;
   uint32_t hinc;
-  const int *vtab;         // oh * {i0, i1, w, 0}
+  const int *vtab;         // vmode 1: oh * {i0, i1, w, 0}
   const int *htab;         // hmode 3: ow * {i0, i1, t, 0}
+  const int2 *hnt, *vnt;   // hmode 4 / vmode 2: out * n * {source index, 6-bit tap}
+  int nh, nv;
 };
 
-__device__ __forceinline__ int plane_htap (const PlaneScaleParams &p, const uint8_t *row, int x, int c)
+// One pass each, written over an accessor so that they compose in either order (GstVideoScaler runs the vertical pass
+// first iff in_h > out_h + n_taps_v, and every pass rounds to 8 bits):
+//   hpass (p, x, at): output column x from at (i) = the sample of source column i (raw, or already vertically scaled)
+//   vpass (p, y, at): output row y from at (r) = the sample of source row r (raw, or already horizontally scaled)
+template <class At>
+__device__ __forceinline__ int hpass (const PlaneScaleParams &p, int x, At at)
 {
   switch (p.hmode) {
-    case 0: return row[p.istep * x + c];
-    case 1: {
+    case 0: return at (x);
+    case 1: {                                        // 2-tap, edge-aligned 16.16 increment (1 x u8)
       const uint32_t t = (uint32_t) x * p.hinc;
       const int i = min ((int) (t >> 16), p.w - 1), f = (int) ((t >> 8) & 0xff), i1 = min (i + 1, p.w - 1);
-      return (row[i] * (256 - f) + row[i1] * f) >> 8;
+      return (at (i) * (256 - f) + at (i1) * f) >> 8;
     }
-    case 2: return (row[2 * x] + row[2 * x + 1] + 1) >> 1;
-    default: {
+    case 2: return (at (2 * x) + at (2 * x + 1) + 1) >> 1;      // exactly halved (1 x u8)
+    case 3: {                                        // 2-tap, centre-aligned 6-bit table (also nearest: second tap 0)
       const int i0 = p.htab[4 * x], i1 = p.htab[4 * x + 1], t = p.htab[4 * x + 2];
-      return (row[p.istep * i0 + c] * (64 - t) + row[p.istep * i1 + c] * t + 32) >> 6;
+      return (at (i0) * (64 - t) + at (i1) * t + 32) >> 6;
+    }
+    default: {                                       // n taps, 6-bit (catrom; un-limited linear)
+      int acc = 32;
+      for (int l = 0; l < p.nh; l++) { const int2 e = p.hnt[x * p.nh + l]; acc += at (e.x) * e.y; }
+      return min (max (acc >> 6, 0), 255);
     }
   }
 }
 
-// one output sample (x, y), component c, of a plane: both passes in GstVideoScaler's order
-__device__ __forceinline__ int plane_sample (const PlaneScaleParams &p, const uint8_t *r0, const uint8_t *r1, int wt, int x, int c)
+template <class At>
+__device__ __forceinline__ int vpass (const PlaneScaleParams &p, int y, At at)
 {
-  if (!p.vscale_on) return plane_htap (p, r0, x, c);
-  if (p.hmode == 0) { const int a = r0[p.istep * x + c], b = r1[p.istep * x + c]; return a + (((b - a) * wt + 128) >> 8); }
-  if (p.vfirst) {
-    // vertical first: the horizontal taps run on vertically scaled samples -> scale each source column the tap touches
-    switch (p.hmode) {
-      case 1: {
-        const uint32_t t = (uint32_t) x * p.hinc;
-        const int i = min ((int) (t >> 16), p.w - 1), f = (int) ((t >> 8) & 0xff), j1 = min (i + 1, p.w - 1);
-        const int a = r0[i] + (((r1[i] - r0[i]) * wt + 128) >> 8), b = r0[j1] + (((r1[j1] - r0[j1]) * wt + 128) >> 8);
-        return (a * (256 - f) + b * f) >> 8;
-      }
-      case 2: {
-        const int a = r0[2 * x] + (((r1[2 * x] - r0[2 * x]) * wt + 128) >> 8), b = r0[2 * x + 1] + (((r1[2 * x + 1] - r0[2 * x + 1]) * wt + 128) >> 8);
-        return (a + b + 1) >> 1;
-      }
-      default: {
-        const int j0 = p.htab[4 * x], j1 = p.htab[4 * x + 1], t = p.htab[4 * x + 2];
-        const int a0 = r0[p.istep * j0 + c], a1 = r1[p.istep * j0 + c], b0 = r0[p.istep * j1 + c], b1 = r1[p.istep * j1 + c];
-        const int a = a0 + (((a1 - a0) * wt + 128) >> 8), b = b0 + (((b1 - b0) * wt + 128) >> 8);
-        return (a * (64 - t) + b * t + 32) >> 6;
-      }
+  switch (p.vmode) {
+    case 0: return at (y);
+    case 1: {                                        // 2-tap, 8-bit: only the second tap is used
+      const int i0 = p.vtab[4 * y], i1 = p.vtab[4 * y + 1], wt = p.vtab[4 * y + 2];
+      const int a = at (i0), b = at (i1);
+      return a + (((b - a) * wt + 128) >> 8);
+    }
+    default: {
+      int acc = 32;
+      for (int l = 0; l < p.nv; l++) { const int2 e = p.vnt[y * p.nv + l]; acc += at (e.x) * e.y; }
+      return min (max (acc >> 6, 0), 255);
     }
   }
-  const int a = plane_htap (p, r0, x, c), b = plane_htap (p, r1, x, c);
-  return a + (((b - a) * wt + 128) >> 8);
+}
+
+// one output sample (x, y), component c, of a plane whose first sample is at `base`
+__device__ __forceinline__ int plane_sample (const PlaneScaleParams &p, const uint8_t *base, int x, int y, int c)
+{
+  auto raw = [&] (int r, int i) { return (int) base[(size_t) r * p.is + p.istep * i + c]; };
+  if (p.vfirst) return hpass (p, x, [&] (int i) { return vpass (p, y, [&] (int r) { return raw (r, i); }); });
+  return vpass (p, y, [&] (int r) { return hpass (p, x, [&] (int i) { return raw (r, i); }); });
 }
 
 // a plane of its own (n = istep = ostep: 4:2:0 luma / chroma planes).  One lane = FOUR consecutive output bytes of a row
@@ -234,13 +243,14 @@ __global__ __launch_bounds__ (256) void k_scale_plane (const PlaneScaleParams p0
   const int bx = 4 * (blockIdx.x * 64 + threadIdx.x), y = blockIdx.y * 4 + threadIdx.y, wb = p.n * p.ow;
   if (bx >= wb || y >= p.oh) return;
   int i0 = y, i1 = y, wt = 0;
-  if (p.vscale_on) { i0 = p.vtab[4 * y]; i1 = p.vtab[4 * y + 1]; wt = p.vtab[4 * y + 2]; }
+  const bool v2 = p.vmode == 1, fast = p.vec && p.vmode != 2 && bx + 3 < wb;      // the dword / 16-bit paths cover the 2-tap modes
+  if (v2) { i0 = p.vtab[4 * y]; i1 = p.vtab[4 * y + 1]; wt = p.vtab[4 * y + 2]; }
   const uint8_t *r0 = p.in + (size_t) i0 * p.is, *r1 = p.in + (size_t) i1 * p.is;
   uint32_t v = 0;
-  if (p.vec && bx + 3 < wb && p.hmode == 0) {
+  if (fast && p.hmode == 0) {
     // no horizontal pass: four consecutive bytes of each source row are one dword
     const uint32_t a4 = *reinterpret_cast<const uint32_t *> (r0 + bx);
-    if (!p.vscale_on) v = a4;
+    if (!v2) v = a4;
     else {
       const uint32_t b4 = *reinterpret_cast<const uint32_t *> (r1 + bx);
 #pragma unroll
@@ -249,23 +259,23 @@ __global__ __launch_bounds__ (256) void k_scale_plane (const PlaneScaleParams p0
         v |= (uint32_t) (a + (((b - a) * wt + 128) >> 8)) << (8 * k);
       }
     }
-  } else if (p.vec && bx + 3 < wb && p.hmode == 2) {
+  } else if (fast && p.hmode == 2) {
     // exactly halved 1 x u8 plane: eight consecutive source bytes per row = two dwords
     const uint32_t *s0 = reinterpret_cast<const uint32_t *> (r0 + 2 * bx), *s1 = reinterpret_cast<const uint32_t *> (r1 + 2 * bx);
     const uint32_t a8[2] = { s0[0], s0[1] };
     uint32_t b8[2] = { a8[0], a8[1] };
-    if (p.vscale_on) { b8[0] = s1[0]; b8[1] = s1[1]; }
+    if (v2) { b8[0] = s1[0]; b8[1] = s1[1]; }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int sh = 16 * (k & 1);
       const int a0 = (a8[k >> 1] >> sh) & 0xff, a1 = (a8[k >> 1] >> (sh + 8)) & 0xff, b0 = (b8[k >> 1] >> sh) & 0xff, b1 = (b8[k >> 1] >> (sh + 8)) & 0xff;
       int r;
-      if (!p.vscale_on) r = (a0 + a1 + 1) >> 1;
+      if (!v2) r = (a0 + a1 + 1) >> 1;
       else if (p.vfirst) { const int l = a0 + (((b0 - a0) * wt + 128) >> 8), m = a1 + (((b1 - a1) * wt + 128) >> 8); r = (l + m + 1) >> 1; }
       else { const int l = (a0 + a1 + 1) >> 1, m = (b0 + b1 + 1) >> 1; r = l + (((m - l) * wt + 128) >> 8); }
       v |= (uint32_t) r << (8 * k);
     }
-  } else if (p.vec && bx + 3 < wb && p.hmode == 3 && p.n == 2) {
+  } else if (fast && p.hmode == 3 && p.n == 2) {
     // NV12 chroma with table taps: a U/V pair is one 16-bit load, a table entry one 16-byte load
 #pragma unroll
     for (int k = 0; k < 2; k++) {
@@ -273,18 +283,18 @@ __global__ __launch_bounds__ (256) void k_scale_plane (const PlaneScaleParams p0
       const uint16_t *q0 = reinterpret_cast<const uint16_t *> (r0), *q1 = reinterpret_cast<const uint16_t *> (r1);
       const uint32_t a0 = q0[e.x], a1 = q0[e.y];
       uint32_t b0 = a0, b1 = a1;
-      if (p.vscale_on) { b0 = q1[e.x]; b1 = q1[e.y]; }
+      if (v2) { b0 = q1[e.x]; b1 = q1[e.y]; }
 #pragma unroll
       for (int c = 0; c < 2; c++) {
         const int l0 = (a0 >> (8 * c)) & 0xff, l1 = (a1 >> (8 * c)) & 0xff, m0 = (b0 >> (8 * c)) & 0xff, m1 = (b1 >> (8 * c)) & 0xff;
         int r;
-        if (!p.vscale_on) r = (l0 * (64 - e.z) + l1 * e.z + 32) >> 6;
+        if (!v2) r = (l0 * (64 - e.z) + l1 * e.z + 32) >> 6;
         else if (p.vfirst) { const int l = l0 + (((m0 - l0) * wt + 128) >> 8), m = l1 + (((m1 - l1) * wt + 128) >> 8); r = (l * (64 - e.z) + m * e.z + 32) >> 6; }
         else { const int l = (l0 * (64 - e.z) + l1 * e.z + 32) >> 6, m = (m0 * (64 - e.z) + m1 * e.z + 32) >> 6; r = l + (((m - l) * wt + 128) >> 8); }
         v |= (uint32_t) r << (16 * k + 8 * c);
       }
     }
-  } else if (p.vec && bx + 3 < wb && p.hmode == 1) {
+  } else if (fast && p.hmode == 1) {
     // edge-aligned 16.16 taps on a 1 x u8 plane: the two taps are neighbouring bytes -> one (unaligned) 16-bit load per row
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -295,7 +305,7 @@ __global__ __launch_bounds__ (256) void k_scale_plane (const PlaneScaleParams p0
       else { pa = (uint16_t) (r0[i] * 0x101u); pb = (uint16_t) (r1[i] * 0x101u); }
       const int a0 = pa & 0xff, a1 = pa >> 8, b0 = pb & 0xff, b1 = pb >> 8;
       int r;
-      if (!p.vscale_on) r = (a0 * (256 - f) + a1 * f) >> 8;
+      if (!v2) r = (a0 * (256 - f) + a1 * f) >> 8;
       else if (p.vfirst) { const int l = a0 + (((b0 - a0) * wt + 128) >> 8), m = a1 + (((b1 - a1) * wt + 128) >> 8); r = (l * (256 - f) + m * f) >> 8; }
       else { const int l = (a0 * (256 - f) + a1 * f) >> 8, m = (b0 * (256 - f) + b1 * f) >> 8; r = l + (((m - l) * wt + 128) >> 8); }
       v |= (uint32_t) r << (8 * k);
@@ -305,7 +315,7 @@ __global__ __launch_bounds__ (256) void k_scale_plane (const PlaneScaleParams p0
     for (int k = 0; k < 4; k++) {
       const int b = min (bx + k, wb - 1);
       const int x = p.n == 2 ? b >> 1 : b, c = p.n == 2 ? b & 1 : 0;
-      v |= (uint32_t) plane_sample (p, r0, r1, wt, x, c) << (8 * k);
+      v |= (uint32_t) plane_sample (p, p.in, x, y, c) << (8 * k);
     }
   }
   uint8_t *d = p.out + (size_t) y * p.os + bx;
@@ -322,18 +332,16 @@ __global__ __launch_bounds__ (256) void k_scale_packed422 (const PackedScalePara
   const PlaneScaleParams &py = q.pl[0];
   const int k = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
   if (k >= q.pl[1].ow || y >= py.oh) return;
-  int i0 = y, i1 = y, wt = 0;
-  if (py.vscale_on) { i0 = py.vtab[4 * y]; i1 = py.vtab[4 * y + 1]; wt = py.vtab[4 * y + 2]; }
   const size_t fin = (size_t) blockIdx.z * py.in_pitch, fout = (size_t) blockIdx.z * py.out_pitch;
   uint32_t b[4];
 #pragma unroll
   for (int t = 0; t < 3; t++) {
     const PlaneScaleParams &p = q.pl[t];
-    const uint8_t *r0 = p.in + fin + (size_t) i0 * p.is, *r1 = p.in + fin + (size_t) i1 * p.is;
+    const uint8_t *base = p.in + fin;
     if (t == 0) {
-      b[q.yo] = (uint32_t) plane_sample (p, r0, r1, wt, 2 * k, 0);
-      b[q.yo + 2] = 2 * k + 1 < p.ow ? (uint32_t) plane_sample (p, r0, r1, wt, 2 * k + 1, 0) : b[q.yo];   // spare slot of an odd width
-    } else b[t == 1 ? q.uo : q.vo] = (uint32_t) plane_sample (p, r0, r1, wt, k, 0);
+      b[q.yo] = (uint32_t) plane_sample (p, base, 2 * k, y, 0);
+      b[q.yo + 2] = 2 * k + 1 < p.ow ? (uint32_t) plane_sample (p, base, 2 * k + 1, y, 0) : b[q.yo];   // spare slot of an odd width
+    } else b[t == 1 ? q.uo : q.vo] = (uint32_t) plane_sample (p, base, k, y, 0);
   }
   uint8_t *d = py.out + fout + (size_t) y * py.os + 4 * k;
   const uint32_t v = b[0] | b[1] << 8 | b[2] << 16 | b[3] << 24;

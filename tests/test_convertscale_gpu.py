@@ -239,7 +239,8 @@ def test_golden_gstreamer_vectors_bicubic(vfhip, case, tile, monkeypatch):
 
 def test_bicubic_outside_the_pinned_domain_is_refused(vfhip):
     cs = vfhip.ConvertScale(0)
-    for (w, h, ow, oh, ofmt, kw) in [(3, 3, 7, 5, "BGRA", {}), (16, 16, 1, 1, "BGRA", {}), (64, 36, 32, 18, "NV12", {}), (64, 36, 32, 18, "BGRA", dict(numerics="metal")),
+    for (w, h, ow, oh, ofmt, kw) in [(3, 3, 7, 5, "BGRA", {}), (16, 16, 1, 1, "BGRA", {}), (6, 36, 3, 18, "NV12", {}), (64, 36, 32, 18, "NV12", dict(add_borders=True)),
+                                     (64, 36, 32, 18, "BGRA", dict(numerics="metal")),
                                      (64, 36, 32, 18, "BGRA", dict(add_borders=True))]:
         with pytest.raises(vfhip.VfHipError) as e:
             cs.configure("NV12", w, h, ofmt, ow, oh, method="bicubic", **kw)
@@ -353,7 +354,7 @@ def test_one_sample_lines_are_replicated(vfhip, oracle, ifmt, ofmt, w, h, ow, oh
 
 
 # ---- packed 4:2:2 outputs, packed -> 4:2:0, and the tap-quantiser ties ----------------------------------------------
-from test_oracle_golden import MANIFEST_PO, ZPO, MANIFEST_T, ZT, MANIFEST_N, ZN, gst_undefined_packed  # noqa: E402
+from test_oracle_golden import MANIFEST_PO, ZPO, MANIFEST_T, ZT, MANIFEST_N, ZN, MANIFEST_C, ZC, gst_undefined_packed  # noqa: E402
 
 
 @pytest.mark.parametrize("case", MANIFEST_PO, ids=[c["name"] for c in MANIFEST_PO])
@@ -445,3 +446,25 @@ def test_staged_scalar_fallbacks_match(vfhip, oracle, monkeypatch):
         got, _ = run(vfhip, ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", ofmt, ow, oh)
         want = oracle.convertscale(ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", ofmt, ow, oh)
         assert np.array_equal(meaningful(ofmt, ow, oh, got), meaningful(ofmt, ow, oh, want)), (ifmt, ofmt, w, h, ow, oh)
+
+
+@pytest.mark.parametrize("case", MANIFEST_C, ids=[c["name"] for c in MANIFEST_C])
+def test_golden_gstreamer_vectors_bicubic_yuv_outputs(vfhip, oracle, case):
+    """videoscale method=catrom with YUV outputs: catrom on the luma plane / the lines of a packed frame, un-limited LINEAR taps
+    on the chroma planes of a planar frame"""
+    c = case
+    got, kname = run(vfhip, c["in_format"], c["w"], c["h"], ZC[c["name"] + "_in"], c["colorimetry"], c["chroma_site"],
+                     c["method"], c["out_format"], c["ow"], c["oh"])
+    assert kname.startswith("k_cs_staged")
+    a, b = (meaningful(c["out_format"], c["ow"], c["oh"], f) for f in gst_undefined_packed(oracle, c, [got, ZC[c["name"] + "_out"]]))
+    assert np.array_equal(a, b), f"max diff {np.abs(a.astype(int) - b.astype(int)).max()}"
+
+
+def test_bicubic_yuv_outputs_hd_vs_oracle(vfhip, oracle):
+    rng = np.random.default_rng(23)
+    for (ifmt, ofmt, w, h, ow, oh) in [("NV12", "NV12", 1920, 1080, 1280, 720), ("BGRA", "I420", 1280, 720, 1920, 1080), ("UYVY", "UYVY", 1280, 720, 640, 360),
+                                       ("I420", "YUY2", 1279, 719, 641, 355)]:
+        raw = rng.integers(0, 256, oracle_lib.raw_layout(ifmt, w, h)[1], dtype=np.uint8)
+        got, _ = run(vfhip, ifmt, w, h, raw, "bt709", "mpeg2", "bicubic", ofmt, ow, oh)
+        want = oracle.convertscale(ifmt, w, h, raw, "bt709", "mpeg2", "bicubic", ofmt, ow, oh)
+        assert np.array_equal(meaningful(ofmt, ow, oh, got), meaningful(ofmt, ow, oh, want)), (ifmt, ofmt)

@@ -390,3 +390,17 @@ def test_pixel_parity_yuv_outputs_with_cpu_elements(tmp_path, ifmt, iw, ih, ofmt
     x, y = np.fromfile(a, np.uint8), np.fromfile(b, np.uint8)
     assert x.size == y.size and x.size > 0
     assert np.array_equal(x, y), f"max diff {np.abs(x.astype(int) - y.astype(int)).max()}, {(x != y).sum()} bytes differ"
+
+
+@pytest.mark.parametrize("ifmt,iw,ih,ofmt,ow,oh,method,gst", [("NV12", 1280, 720, "NV12", 854, 480, "bicubic", "catrom"), ("I420", 640, 360, "UYVY", 1280, 720, "bicubic", "catrom"),
+                                                              ("BGRA", 1280, 720, "I420", 640, 480, "bicubic", "catrom"), ("NV12", 1280, 720, "YUY2", 640, 360, "nearest", "nearest-neighbour")])
+def test_pixel_parity_yuv_outputs_other_methods(tmp_path, ifmt, iw, ih, ofmt, ow, oh, method, gst):
+    """method=bicubic / nearest with YUV outputs, as real pipelines against the CPU elements"""
+    a, b = tmp_path / "cpu.raw", tmp_path / "hip.raw"
+    r = gst_env.launch(f"videotestsrc num-buffers=2 ! {caps(ifmt, iw, ih)} ! tee name=t "
+                       f"t. ! queue ! videoconvert ! videoscale method={gst} ! {caps(ofmt, ow, oh)} ! filesink location={a} "
+                       f"t. ! queue ! vfhipconvertscale method={method} ! {caps(ofmt, ow, oh)} ! filesink location={b}", timeout=300)
+    assert r.returncode == 0, r.stderr
+    x, y = np.fromfile(a, np.uint8), np.fromfile(b, np.uint8)
+    assert x.size == y.size and x.size > 0
+    assert np.array_equal(x, y), f"max diff {np.abs(x.astype(int) - y.astype(int)).max()}, {(x != y).sum()} bytes differ"
