@@ -329,24 +329,18 @@ struct PackedScaleParams { PlaneScaleParams pl[3]; int yo, uo, vo; };
 
 __global__ __launch_bounds__ (256) void k_scale_packed422 (const PackedScaleParams q)
 {
-  const PlaneScaleParams &py = q.pl[0];
   const int k = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-  if (k >= q.pl[1].ow || y >= py.oh) return;
-  const size_t fin = (size_t) blockIdx.z * py.in_pitch, fout = (size_t) blockIdx.z * py.out_pitch;
-  uint32_t b[4];
-#pragma unroll
-  for (int t = 0; t < 3; t++) {
-    const PlaneScaleParams &p = q.pl[t];
-    const uint8_t *base = p.in + fin;
-    if (t == 0) {
-      b[q.yo] = (uint32_t) plane_sample (p, base, 2 * k, y, 0);
-      b[q.yo + 2] = 2 * k + 1 < p.ow ? (uint32_t) plane_sample (p, base, 2 * k + 1, y, 0) : b[q.yo];   // spare slot of an odd width
-    } else b[t == 1 ? q.uo : q.vo] = (uint32_t) plane_sample (p, base, k, y, 0);
-  }
-  uint8_t *d = py.out + fout + (size_t) y * py.os + 4 * k;
-  const uint32_t v = b[0] | b[1] << 8 | b[2] << 16 | b[3] << 24;
+  if (k >= q.pl[1].ow || y >= q.pl[0].oh) return;
+  const size_t fin = (size_t) blockIdx.z * q.pl[0].in_pitch, fout = (size_t) blockIdx.z * q.pl[0].out_pitch;
+  // (constant indices only: a dynamically indexed parameter struct or byte array ends up in scratch memory)
+  const uint32_t Y0 = (uint32_t) plane_sample (q.pl[0], q.pl[0].in + fin, 2 * k, y, 0);
+  const uint32_t Y1 = 2 * k + 1 < q.pl[0].ow ? (uint32_t) plane_sample (q.pl[0], q.pl[0].in + fin, 2 * k + 1, y, 0) : Y0;   // spare slot of an odd width
+  const uint32_t U = (uint32_t) plane_sample (q.pl[1], q.pl[1].in + fin, k, y, 0);
+  const uint32_t V = (uint32_t) plane_sample (q.pl[2], q.pl[2].in + fin, k, y, 0);
+  uint8_t *d = q.pl[0].out + fout + (size_t) y * q.pl[0].os + 4 * k;
+  const uint32_t v = q.yo == 0 ? (Y0 | U << 8 | Y1 << 16 | V << 24) : (U | Y0 << 8 | V << 16 | Y1 << 24);
   if (((uintptr_t) d & 3) == 0) *reinterpret_cast<uint32_t *> (d) = v;
-  else { d[0] = (uint8_t) b[0]; d[1] = (uint8_t) b[1]; d[2] = (uint8_t) b[2]; d[3] = (uint8_t) b[3]; }
+  else { d[0] = (uint8_t) v; d[1] = (uint8_t) (v >> 8); d[2] = (uint8_t) (v >> 16); d[3] = (uint8_t) (v >> 24); }
 }
 
 // ---- packed 4:2:2 (UYVY / YUY2) outputs and packed -> 4:2:0: videoconvert's conversions at the input size ------------
