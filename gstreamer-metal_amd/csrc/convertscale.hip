@@ -258,6 +258,11 @@ static int setup_plane (PlaneCfg &pc, int w, int h, int ow, int oh, int n, bool 
       linear_taps (w, ow, x, 6, &ht[4 * x], &ht[4 * x + 1], &t0, &ht[4 * x + 2]);
       if (t0 + ht[4 * x + 2] != 64) return set_error (VFHIP_ERR_UNSUPPORTED, "6-bit taps of column %d (%d -> %d) do not sum to 64", x, w, ow);
     }
+    if (n == 2 && w == 2 * ow) {                    // exactly halved: every entry is (2k, 2k+1, 32) -> the kernel's dword path
+      bool half = true;
+      for (int x = 0; x < ow && half; x++) half = ht[4 * x] == 2 * x && ht[4 * x + 1] == 2 * x + 1 && ht[4 * x + 2] == 32;
+      if (half) pc.hmode = 5;
+    }
   }
   int rc = upload_ints (vt, &pc.d_vtab);
   if (rc) return rc;
@@ -650,8 +655,18 @@ static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
     p.in = (const uint8_t *) mid.data[k]; p.is = mid.stride[k];
     p.out = (uint8_t *) out->data[k]; p.os = out->stride[k];
     p.vec = (((uintptr_t) p.in | (uintptr_t) p.is | (uintptr_t) mid_pitch) & 3) == 0 && getenv ("VFHIP_PLANE_SCALAR") == nullptr;
-    dim3 grid ((unsigned) ((pc.n * pc.ow + 255) / 256), (unsigned) ((pc.oh + 3) / 4), nz);
-    hipLaunchKernelGGL (k_scale_plane, grid, dim3 (64, 4), 0, s, p);
+    // contiguous source bytes (no horizontal pass, or an exact half): 8 output bytes per lane; 2-tap gathers and n-tap tables:
+    // 4 bytes per lane, each family in its own small kernel
+    const bool twotap = p.vec && pc.vmode != 2;
+    if (twotap && (pc.hmode == 0 || pc.hmode == 2 || pc.hmode == 5) && getenv ("VFHIP_PLANE_G1") == nullptr) {
+      dim3 grid ((unsigned) ((pc.n * pc.ow + 511) / 512), (unsigned) ((pc.oh + 3) / 4), nz);
+      hipLaunchKernelGGL ((k_scale_plane<2, 0>), grid, dim3 (64, 4), 0, s, p);
+    } else {
+      dim3 grid ((unsigned) ((pc.n * pc.ow + 255) / 256), (unsigned) ((pc.oh + 3) / 4), nz);
+      if (twotap && (pc.hmode == 0 || pc.hmode == 2 || pc.hmode == 5)) hipLaunchKernelGGL ((k_scale_plane<1, 0>), grid, dim3 (64, 4), 0, s, p);
+      else if (twotap && (pc.hmode == 1 || pc.hmode == 3)) hipLaunchKernelGGL ((k_scale_plane<1, 1>), grid, dim3 (64, 4), 0, s, p);
+      else hipLaunchKernelGGL ((k_scale_plane<1, 2>), grid, dim3 (64, 4), 0, s, p);
+    }
     VFHIP_CHECK_HIP (hipGetLastError ());
   }
   return VFHIP_OK;

@@ -170,7 +170,7 @@ struct PlaneScaleParams {
                            // luma / chroma lines interleaved in a packed 4:2:2 frame); hmode 1 / 2 need istep == 1
   size_t in_pitch, out_pitch;   // batch: frame k of the launch at base + k * pitch (blockIdx.z)
   int vec;                 // source rows are 4-byte aligned: hmode 0 / 2 read dwords
-  int hmode;               // 0: no horizontal scaling, 1: edge-aligned 16.16 (1 x u8), 2: pair average (1 x u8), 3: 2-tap table (6-bit), 4: n-tap table
+  int hmode;               // 0: no horizontal scaling, 1: edge-aligned 16.16 (1 x u8), 2: pair average (1 x u8), 3: 2-tap table (6-bit), 4: n-tap table, 5: like 3 with the exact-half table (2k, 2k+1, 32)
   int vmode;               // 0: no vertical scaling, 1: 2-tap 8-bit (vtab), 2: n-tap 6-bit (vnt)
   int vfirst;
   uint32_t hinc;
@@ -195,7 +195,7 @@ __device__ __forceinline__ int hpass (const PlaneScaleParams &p, int x, At at)
       return (at (i) * (256 - f) + at (i1) * f) >> 8;
     }
     case 2: return (at (2 * x) + at (2 * x + 1) + 1) >> 1;      // exactly halved (1 x u8)
-    case 3: {                                        // 2-tap, centre-aligned 6-bit table (also nearest: second tap 0)
+    case 3: case 5: {                                // 2-tap, centre-aligned 6-bit table (also nearest: second tap 0); 5 = the table is (2k, 2k+1, 32)
       const int i0 = p.htab[4 * x], i1 = p.htab[4 * x + 1], t = p.htab[4 * x + 2];
       return (at (i0) * (64 - t) + at (i1) * t + 32) >> 6;
     }
@@ -233,21 +233,17 @@ __device__ __forceinline__ int plane_sample (const PlaneScaleParams &p, const ui
   return vpass (p, y, [&] (int r) { return hpass (p, x, [&] (int i) { return raw (r, i); }); });
 }
 
-// a plane of its own (n = istep = ostep: 4:2:0 luma / chroma planes).  One lane = FOUR consecutive output bytes of a row
-// (4 samples of a 1 x u8 plane, 2 samples of NV12's 2 x u8 plane), stored as one dword when the address allows: byte
-// stores cost a full store instruction each.  blockIdx.z = frame of the batch.
-__global__ __launch_bounds__ (256) void k_scale_plane (const PlaneScaleParams p0)
+// a plane of its own (n = istep = ostep: 4:2:0 luma / chroma planes).  One lane = G groups of FOUR consecutive output bytes
+// of a row (4 samples of a 1 x u8 plane, 2 samples of NV12's 2 x u8 plane), stored as dwords when the address allows:
+// byte stores cost a full store instruction each.  blockIdx.z = frame of the batch.
+// F = which fast paths this instantiation carries (each kernel stays small: the gather paths are latency-bound and live on
+// occupancy): 0 = contiguous source bytes (hmode 0 / 2 / 5), 1 = 2-tap gathers (hmode 1 / 3), 2 = none (n-tap tables)
+template <int F>
+__device__ __forceinline__ uint32_t plane_group (const PlaneScaleParams &p, const uint8_t *r0, const uint8_t *r1, int wt, bool v2, bool vecok, int bx, int wb, int y)
 {
-  PlaneScaleParams p = p0;
-  p.in += (size_t) blockIdx.z * p.in_pitch; p.out += (size_t) blockIdx.z * p.out_pitch;
-  const int bx = 4 * (blockIdx.x * 64 + threadIdx.x), y = blockIdx.y * 4 + threadIdx.y, wb = p.n * p.ow;
-  if (bx >= wb || y >= p.oh) return;
-  int i0 = y, i1 = y, wt = 0;
-  const bool v2 = p.vmode == 1, fast = p.vec && p.vmode != 2 && bx + 3 < wb;      // the dword / 16-bit paths cover the 2-tap modes
-  if (v2) { i0 = p.vtab[4 * y]; i1 = p.vtab[4 * y + 1]; wt = p.vtab[4 * y + 2]; }
-  const uint8_t *r0 = p.in + (size_t) i0 * p.is, *r1 = p.in + (size_t) i1 * p.is;
+  const bool fast = vecok && bx + 3 < wb;
   uint32_t v = 0;
-  if (fast && p.hmode == 0) {
+  if (F == 0 && fast && p.hmode == 0) {
     // no horizontal pass: four consecutive bytes of each source row are one dword
     const uint32_t a4 = *reinterpret_cast<const uint32_t *> (r0 + bx);
     if (!v2) v = a4;
@@ -259,7 +255,7 @@ __global__ __launch_bounds__ (256) void k_scale_plane (const PlaneScaleParams p0
         v |= (uint32_t) (a + (((b - a) * wt + 128) >> 8)) << (8 * k);
       }
     }
-  } else if (fast && p.hmode == 2) {
+  } else if (F == 0 && fast && p.hmode == 2) {
     // exactly halved 1 x u8 plane: eight consecutive source bytes per row = two dwords
     const uint32_t *s0 = reinterpret_cast<const uint32_t *> (r0 + 2 * bx), *s1 = reinterpret_cast<const uint32_t *> (r1 + 2 * bx);
     const uint32_t a8[2] = { s0[0], s0[1] };
@@ -275,7 +271,24 @@ __global__ __launch_bounds__ (256) void k_scale_plane (const PlaneScaleParams p0
       else { const int l = (a0 + a1 + 1) >> 1, m = (b0 + b1 + 1) >> 1; r = l + (((m - l) * wt + 128) >> 8); }
       v |= (uint32_t) r << (8 * k);
     }
-  } else if (fast && p.hmode == 3 && p.n == 2) {
+  } else if (F == 0 && fast && p.hmode == 5) {
+    // exactly halved 2 x u8 plane (NV12 chroma): the table is (2k, 2k+1, 32) for every k, so the two source pairs of an
+    // output pair are one dword and the taps are constants
+    const uint32_t *s0 = reinterpret_cast<const uint32_t *> (r0 + 2 * bx), *s1 = reinterpret_cast<const uint32_t *> (r1 + 2 * bx);
+    const uint32_t a8[2] = { s0[0], s0[1] };
+    uint32_t b8[2] = { a8[0], a8[1] };
+    if (v2) { b8[0] = s1[0]; b8[1] = s1[1]; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int sh = 8 * (k & 1);
+      const int a0 = (a8[k >> 1] >> sh) & 0xff, a1 = (a8[k >> 1] >> (sh + 16)) & 0xff, b0 = (b8[k >> 1] >> sh) & 0xff, b1 = (b8[k >> 1] >> (sh + 16)) & 0xff;
+      int r;
+      if (!v2) r = (a0 * 32 + a1 * 32 + 32) >> 6;
+      else if (p.vfirst) { const int l = a0 + (((b0 - a0) * wt + 128) >> 8), m = a1 + (((b1 - a1) * wt + 128) >> 8); r = (l * 32 + m * 32 + 32) >> 6; }
+      else { const int l = (a0 * 32 + a1 * 32 + 32) >> 6, m = (b0 * 32 + b1 * 32 + 32) >> 6; r = l + (((m - l) * wt + 128) >> 8); }
+      v |= (uint32_t) r << (8 * k);
+    }
+  } else if (F == 1 && fast && p.hmode == 3 && p.n == 2) {
     // NV12 chroma with table taps: a U/V pair is one 16-bit load, a table entry one 16-byte load
 #pragma unroll
     for (int k = 0; k < 2; k++) {
@@ -294,7 +307,7 @@ __global__ __launch_bounds__ (256) void k_scale_plane (const PlaneScaleParams p0
         v |= (uint32_t) r << (16 * k + 8 * c);
       }
     }
-  } else if (fast && p.hmode == 1) {
+  } else if (F == 1 && fast && p.hmode == 1) {
     // edge-aligned 16.16 taps on a 1 x u8 plane: the two taps are neighbouring bytes -> one (unaligned) 16-bit load per row
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -311,16 +324,39 @@ __global__ __launch_bounds__ (256) void k_scale_plane (const PlaneScaleParams p0
       v |= (uint32_t) r << (8 * k);
     }
   } else {
-#pragma unroll
+#pragma unroll 1                                   // (rolled: unrolled it sets the register count of every instantiation)
     for (int k = 0; k < 4; k++) {
       const int b = min (bx + k, wb - 1);
       const int x = p.n == 2 ? b >> 1 : b, c = p.n == 2 ? b & 1 : 0;
       v |= (uint32_t) plane_sample (p, p.in, x, y, c) << (8 * k);
     }
   }
-  uint8_t *d = p.out + (size_t) y * p.os + bx;
-  if (bx + 3 < wb && ((uintptr_t) d & 3) == 0) *reinterpret_cast<uint32_t *> (d) = v;
-  else for (int k = 0; k < 4 && bx + k < wb; k++) d[k] = (uint8_t) (v >> (8 * k));
+  return v;
+}
+
+template <int G, int F>
+__global__ __launch_bounds__ (256) void k_scale_plane (const PlaneScaleParams p0)
+{
+  PlaneScaleParams p = p0;
+  p.in += (size_t) blockIdx.z * p.in_pitch; p.out += (size_t) blockIdx.z * p.out_pitch;
+  const int bx0 = 4 * G * (blockIdx.x * 64 + threadIdx.x), y = blockIdx.y * 4 + threadIdx.y, wb = p.n * p.ow;
+  if (bx0 >= wb || y >= p.oh) return;
+  int i0 = y, i1 = y, wt = 0;
+  const bool v2 = p.vmode == 1, vecok = p.vec && p.vmode != 2;      // the dword / 16-bit paths cover the 2-tap modes
+  if (v2) { i0 = p.vtab[4 * y]; i1 = p.vtab[4 * y + 1]; wt = p.vtab[4 * y + 2]; }
+  const uint8_t *r0 = p.in + (size_t) i0 * p.is, *r1 = p.in + (size_t) i1 * p.is;
+  uint32_t v[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) v[g] = bx0 + 4 * g < wb ? plane_group<F> (p, r0, r1, wt, v2, vecok, bx0 + 4 * g, wb, y) : 0u;
+  uint8_t *d = p.out + (size_t) y * p.os + bx0;
+  if (G == 2 && bx0 + 7 < wb && ((uintptr_t) d & 7) == 0) { *reinterpret_cast<uint2 *> (d) = make_uint2 (v[0], v[G - 1]); return; }
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    const int bx = bx0 + 4 * g;
+    if (bx >= wb) break;
+    if (bx + 3 < wb && ((uintptr_t) (d + 4 * g) & 3) == 0) *reinterpret_cast<uint32_t *> (d + 4 * g) = v[g];
+    else for (int k = 0; k < 4 && bx + k < wb; k++) d[4 * g + k] = (uint8_t) (v[g] >> (8 * k));
+  }
 }
 
 // videoscale on a packed 4:2:2 frame: one lane = one output macro-pixel (Y0 U Y1 V in the frame's byte order), the three
