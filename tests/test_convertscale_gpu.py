@@ -468,3 +468,55 @@ def test_bicubic_yuv_outputs_hd_vs_oracle(vfhip, oracle):
         got, _ = run(vfhip, ifmt, w, h, raw, "bt709", "mpeg2", "bicubic", ofmt, ow, oh)
         want = oracle.convertscale(ifmt, w, h, raw, "bt709", "mpeg2", "bicubic", ofmt, ow, oh)
         assert np.array_equal(meaningful(ofmt, ow, oh, got), meaningful(ofmt, ow, oh, want)), (ifmt, ofmt)
+
+
+def _custom_layout(vfhip, fmt, w, h, pad, base):
+    """plane list [(offset, stride, rows)] with every stride padded by `pad` bytes and the first plane at byte `base`"""
+    pl, _ = vfhip.plane_layout(fmt, w, h)
+    out, off = [], base
+    for (_, stride, rows) in pl:
+        out.append((off, stride + pad, rows))
+        off += (stride + pad) * rows + 5                      # planes need not follow each other directly
+    return out, off
+
+
+def _repack(buf, layout_from, layout_to, size_to):
+    """copy plane rows between two layouts of the same format and size (the narrower stride bounds the copy)"""
+    out = np.zeros(size_to, np.uint8)
+    for (fo, fs, rows), (to, ts, _) in zip(layout_from, layout_to):
+        n = min(fs, ts)
+        for r in range(rows):
+            out[to + r * ts: to + r * ts + n] = buf[fo + r * fs: fo + r * fs + n]
+    return out
+
+
+@pytest.mark.parametrize("pad,base", [(16, 0), (3, 0), (16, 1), (5, 3), (64, 8)])
+@pytest.mark.parametrize("ifmt,ofmt,w,h,ow,oh,method", [("NV12", "BGRA", 128, 72, 64, 36, "bilinear"), ("I420", "RGBA", 128, 72, 64, 36, "bilinear"), ("NV12", "BGRA", 96, 54, 50, 31, "bilinear"),
+                                                        ("NV12", "RGBA", 80, 46, 100, 60, "nearest"), ("NV12", "BGRA", 96, 54, 40, 30, "bicubic"), ("BGRA", "NV12", 64, 36, 64, 36, "bilinear"),
+                                                        ("RGBA", "I420", 66, 38, 33, 19, "bilinear"), ("NV12", "NV12", 128, 72, 64, 36, "bilinear"), ("I420", "NV12", 90, 50, 60, 40, "bilinear"),
+                                                        ("NV12", "UYVY", 64, 36, 64, 36, "bilinear"), ("YUY2", "NV12", 64, 36, 48, 30, "bilinear"), ("UYVY", "YUY2", 70, 40, 35, 20, "bicubic"),
+                                                        ("BGRA", "BGRA", 64, 36, 100, 50, "bilinear"), ("UYVY", "BGRA", 64, 36, 32, 18, "bilinear")])
+def test_padded_strides_and_misaligned_planes(vfhip, oracle, ifmt, ofmt, w, h, ow, oh, method, pad, base):
+    """frames as decoders and pools hand them over: padded strides, gaps between planes, odd strides and base addresses (which
+    take the byte-wise kernel variants) - the same bytes as the default layout in every case"""
+    import torch
+    (ipl, isz), (opl, osz) = _custom_layout(vfhip, ifmt, w, h, pad, base), _custom_layout(vfhip, ofmt, ow, oh, pad, base)
+    dpl_in, dsz_in = vfhip.plane_layout(ifmt, w, h)
+    dpl_out, dsz_out = vfhip.plane_layout(ofmt, ow, oh)
+    raw = np.random.default_rng(w * 7 + pad).integers(0, 256, dsz_in, dtype=np.uint8)
+    padded = _repack(raw, dpl_in, ipl, isz + 64)
+    din = torch.from_numpy(padded).cuda()
+    dout = torch.zeros(osz + 64, dtype=torch.uint8, device="cuda")
+    cs = vfhip.ConvertScale(0)
+    cs.configure(ifmt, w, h, ofmt, ow, oh, method=method, colorimetry="bt709", chroma_site="mpeg2")
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    cs.process_device(din.data_ptr(), dout.data_ptr(), stream=s.cuda_stream, in_layout=(ipl, isz), out_layout=(opl, osz))
+    s.synchronize()
+    cs.close()
+    got = _repack(dout.cpu().numpy(), opl, dpl_out, dsz_out)
+    want = np.asarray(oracle.convertscale(ifmt, w, h, raw, "bt709", "mpeg2", method, ofmt, ow, oh)).reshape(-1)
+    if ofmt in ("BGRA", "RGBA"):
+        assert np.array_equal(got, want)
+    else:
+        assert np.array_equal(meaningful(ofmt, ow, oh, got), meaningful(ofmt, ow, oh, want))
