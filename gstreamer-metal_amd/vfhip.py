@@ -306,10 +306,11 @@ class Deinterlace(_Element):
         check(lib.vfhip_deinterlace_process(self.h, C.byref(fi), C.byref(fo), C.byref(prm)))
         return out
 
-    def process_device(self, in_ptr, out_ptr, method="bob", tff=True, threshold=0.1, stream=None, n_frames=1, in_pitch=0, out_pitch=0):
+    def process_device(self, in_ptr, out_ptr, method="bob", tff=True, threshold=0.1, stream=None, n_frames=1, in_pitch=0, out_pitch=0,
+                       in_layout=None, out_layout=None):
         """n_frames > 1: consecutive frames of one stream, frame k at ptr + k * pitch (history of k = frame k-1)"""
-        fi = frame_from_base(self.info, self.fmt, self.w, self.hh, in_ptr)
-        fo = frame_from_base(self.info, self.fmt, self.w, self.hh, out_ptr)
+        fi = frame_from_base(self.info, self.fmt, self.w, self.hh, in_ptr, layout=in_layout)
+        fo = frame_from_base(self.info, self.fmt, self.w, self.hh, out_ptr, layout=out_layout)
         prm = DeinterlaceParams(DEINTERLACE_METHODS[method], int(tff), threshold, 0)
         check(lib.vfhip_deinterlace_process_device_batch(self.h, C.byref(fi), C.byref(fo), in_pitch, out_pitch, n_frames, C.byref(prm), stream))
 
@@ -342,10 +343,10 @@ class VideoFilter(_Element):
         check(lib.vfhip_videofilter_process(self.h, C.byref(fi), C.byref(fo), C.byref(params)))
         return out
 
-    def process_device(self, in_ptr, out_ptr, params, stream=None, n_frames=1, in_pitch=0, out_pitch=0):
+    def process_device(self, in_ptr, out_ptr, params, stream=None, n_frames=1, in_pitch=0, out_pitch=0, in_layout=None, out_layout=None):
         """n_frames > 1: frame k at ptr + k * pitch, filtered with frame_index + k"""
-        fi = frame_from_base(self.in_info, self.in_fmt, self.w, self.hh, in_ptr)
-        fo = frame_from_base(self.out_info, self.out_fmt, self.w, self.hh, out_ptr)
+        fi = frame_from_base(self.in_info, self.in_fmt, self.w, self.hh, in_ptr, layout=in_layout)
+        fo = frame_from_base(self.out_info, self.out_fmt, self.w, self.hh, out_ptr, layout=out_layout)
         check(lib.vfhip_videofilter_process_device_batch(self.h, C.byref(fi), C.byref(fo), in_pitch, out_pitch, n_frames, C.byref(params), stream))
 
     def load_lut(self, path):
@@ -381,9 +382,9 @@ class Compositor(_Element):
         return self
 
     @staticmethod
-    def pad(fmt, w, h, base_ptr, xpos, ypos, width, height, alpha=1.0, blend="over", colorimetry="bt601"):
+    def pad(fmt, w, h, base_ptr, xpos, ypos, width, height, alpha=1.0, blend="over", colorimetry="bt601", layout=None):
         p = PadInput()
-        p.frame = frame_from_base(make_info(fmt, w, h, colorimetry), fmt, w, h, base_ptr)
+        p.frame = frame_from_base(make_info(fmt, w, h, colorimetry), fmt, w, h, base_ptr, layout=layout)
         p.xpos, p.ypos, p.width, p.height, p.alpha, p.blend_mode = xpos, ypos, width, height, alpha, BLEND_MODES[blend]
         return p
 
@@ -399,10 +400,10 @@ class Compositor(_Element):
         check(lib.vfhip_compositor_composite(self.h, arr, len(pads), BACKGROUNDS[background], C.byref(fo)))
         return out
 
-    def composite_device(self, pad_structs, out_ptr, background="checker", stream=None, n_frames=1, pad_pitches=None, out_pitch=0):
+    def composite_device(self, pad_structs, out_ptr, background="checker", stream=None, n_frames=1, pad_pitches=None, out_pitch=0, out_layout=None):
         """n_frames > 1: pad i's frame k at its base + k * pad_pitches[i], output frame k at out_ptr + k * out_pitch"""
         arr = (PadInput * max(len(pad_structs), 1))(*pad_structs)
-        fo = frame_from_base(self.info, self.fmt, self.w, self.hh, out_ptr)
+        fo = frame_from_base(self.info, self.fmt, self.w, self.hh, out_ptr, layout=out_layout)
         if n_frames == 1 and pad_pitches is None:
             check(lib.vfhip_compositor_composite_device(self.h, arr, len(pad_structs), BACKGROUNDS[background], C.byref(fo), stream))
             return
@@ -441,9 +442,10 @@ class Transform(_Element):
         check(lib.vfhip_transform_process(self.h, C.byref(fi), C.byref(fo), C.byref(prm)))
         return out
 
-    def process_device(self, in_ptr, out_ptr, method="none", crop=(0, 0, 0, 0), stream=None, n_frames=1, in_pitch=0, out_pitch=0):
-        fi = frame_from_base(self.in_info, self.in_fmt, self.w, self.hh, in_ptr)
-        fo = frame_from_base(self.out_info, self.out_fmt, self.w, self.hh, out_ptr)
+    def process_device(self, in_ptr, out_ptr, method="none", crop=(0, 0, 0, 0), stream=None, n_frames=1, in_pitch=0, out_pitch=0,
+                       in_layout=None, out_layout=None):
+        fi = frame_from_base(self.in_info, self.in_fmt, self.w, self.hh, in_ptr, layout=in_layout)
+        fo = frame_from_base(self.out_info, self.out_fmt, self.w, self.hh, out_ptr, layout=out_layout)
         prm = TransformParams(TRANSFORM_METHODS[method], *crop)
         check(lib.vfhip_transform_process_device_batch(self.h, C.byref(fi), C.byref(fo), in_pitch, out_pitch, n_frames, C.byref(prm), stream))
 
@@ -489,8 +491,9 @@ class Overlay(_Element):
         check(lib.vfhip_overlay_process(self.h, C.byref(fi), C.byref(fo), C.byref(prm)))
         return out
 
-    def process_device(self, in_ptr, out_ptr, x=0.0, y=0.0, width=0.0, height=0.0, alpha=1.0, stream=None, n_frames=1, in_pitch=0, out_pitch=0):
-        fi = frame_from_base(self.in_info, self.in_fmt, self.w, self.hh, in_ptr)
-        fo = frame_from_base(self.out_info, self.out_fmt, self.w, self.hh, out_ptr)
+    def process_device(self, in_ptr, out_ptr, x=0.0, y=0.0, width=0.0, height=0.0, alpha=1.0, stream=None, n_frames=1, in_pitch=0, out_pitch=0,
+                       in_layout=None, out_layout=None):
+        fi = frame_from_base(self.in_info, self.in_fmt, self.w, self.hh, in_ptr, layout=in_layout)
+        fo = frame_from_base(self.out_info, self.out_fmt, self.w, self.hh, out_ptr, layout=out_layout)
         prm = OverlayParams(x, y, width, height, alpha)
         check(lib.vfhip_overlay_process_device_batch(self.h, C.byref(fi), C.byref(fo), in_pitch, out_pitch, n_frames, C.byref(prm), stream))

@@ -236,3 +236,87 @@ def test_many_handles_from_many_threads(vfhip, oracle, metalref):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+# ---- padded strides / plane gaps / misaligned bases through every element's device-frame entry point ------------------
+def _custom_layout(vfhip, fmt, w, h, pad, base):
+    pl, _ = vfhip.plane_layout(fmt, w, h)
+    out, off = [], base
+    for (_, stride, rows) in pl:
+        out.append((off, stride + pad, rows))
+        off += (stride + pad) * rows + 5
+    return out, off
+
+
+def _repack(buf, layout_from, layout_to, size_to):
+    out = np.zeros(size_to, np.uint8)
+    for (fo, fs, rows), (to, ts, _) in zip(layout_from, layout_to):
+        n = min(fs, ts)
+        for r in range(rows):
+            out[to + r * ts: to + r * ts + n] = buf[fo + r * fs: fo + r * fs + n]
+    return out
+
+
+def _meaningful(vfhip, fmt, w, h, raw):
+    out = []
+    for i, (off, stride, rows) in enumerate(vfhip.plane_layout(fmt, w, h)[0]):
+        r = h if i == 0 else (h + 1) // 2
+        wb = {"BGRA": 4 * w, "RGBA": 4 * w}.get(fmt, w if i == 0 else (w + 1) // 2 * (2 if fmt == "NV12" else 1))
+        out.append(np.asarray(raw[off: off + r * stride]).reshape(r, stride)[:, :wb].reshape(-1))
+    return np.concatenate(out)
+
+
+@pytest.mark.parametrize("pad,base", [(16, 0), (3, 0), (16, 1), (5, 3)])
+@pytest.mark.parametrize("ifmt,ofmt", [("BGRA", "BGRA"), ("NV12", "NV12"), ("I420", "BGRA"), ("RGBA", "I420")])
+def test_elements_take_padded_and_misaligned_frames(vfhip, ifmt, ofmt, pad, base):
+    """videofilter, deinterlace, transform, overlay and compositor on frames with padded / odd strides, gaps between planes and
+    misaligned bases give the bytes they give on the default layout (the vector loads and stores all have byte-wise twins)"""
+    import torch
+    w, h = 70, 38
+    rng = np.random.default_rng(pad * 10 + base)
+    s = torch.cuda.Stream()
+
+    def run(make, call, fin, fout, in_fmt=ifmt, out_fmt=ofmt):
+        """call(elem, in_ptr, out_ptr, in_layout, out_layout) once on the default layout, once on the custom one"""
+        res = []
+        dpl_i, dsz_i = vfhip.plane_layout(in_fmt, w, h)
+        dpl_o, dsz_o = vfhip.plane_layout(out_fmt, w, h)
+        for custom in (False, True):
+            (ipl, isz) = _custom_layout(vfhip, in_fmt, w, h, pad, base) if custom else (dpl_i, dsz_i)
+            (opl, osz) = _custom_layout(vfhip, out_fmt, w, h, pad, base) if custom else (dpl_o, dsz_o)
+            elem = make()
+            outs = []
+            for raw in fin:
+                din = torch.from_numpy(_repack(raw, dpl_i, ipl, isz + 64)).cuda()
+                dout = torch.zeros(osz + 64, dtype=torch.uint8, device="cuda")
+                torch.cuda.synchronize()
+                call(elem, din.data_ptr(), dout.data_ptr(), (ipl, isz), (opl, osz))
+                s.synchronize()
+                outs.append(_meaningful(vfhip, out_fmt, w, h, _repack(dout.cpu().numpy(), opl, dpl_o, dsz_o)))
+            elem.close()
+            res.append(outs)
+        for a, b in zip(*res):
+            assert np.array_equal(a, b), fout
+    frames = [rng.integers(0, 256, vfhip.plane_layout(ifmt, w, h)[1], dtype=np.uint8) for _ in range(2)]
+
+    prm = vfhip.filter_params(brightness=0.1, contrast=1.2, saturation=0.8, sharpness=0.5, vignette=0.3)
+    run(lambda: vfhip.VideoFilter(0).configure(ifmt, w, h, ofmt, colorimetry="bt709"),
+        lambda e, i, o, il, ol: e.process_device(i, o, prm, stream=s.cuda_stream, in_layout=il, out_layout=ol), frames, "videofilter")
+    run(lambda: vfhip.Transform(0).configure(ifmt, w, h, ofmt, colorimetry="bt709"),
+        lambda e, i, o, il, ol: e.process_device(i, o, method="rotate-180", crop=(2, 3, 4, 5), stream=s.cuda_stream, in_layout=il, out_layout=ol), frames, "transform")
+    logo = rng.integers(0, 256, (9, 13, 4), dtype=np.uint8)
+
+    def make_overlay():
+        ov = vfhip.Overlay(0).configure(ifmt, w, h, ofmt, colorimetry="bt709")
+        ov.set_image(logo)
+        return ov
+    run(make_overlay, lambda e, i, o, il, ol: e.process_device(i, o, x=5.0, y=7.0, alpha=0.6, stream=s.cuda_stream, in_layout=il, out_layout=ol), frames, "overlay")
+    if ifmt == ofmt:
+        run(lambda: vfhip.Deinterlace(0).configure(ifmt, w, h, colorimetry="bt709"),
+            lambda e, i, o, il, ol: e.process_device(i, o, method="greedyh", tff=True, threshold=0.08, stream=s.cuda_stream, in_layout=il, out_layout=ol),
+            frames, "deinterlace")
+
+    def comp(e, i, o, il, ol):
+        pads = [vfhip.Compositor.pad(ifmt, w, h, i, 3, 2, w, h, 0.8, "over", "bt709", layout=il), vfhip.Compositor.pad(ifmt, w, h, i, -11, 9, 40, 25, 0.5, "add", "bt709", layout=il)]
+        e.composite_device(pads, o, background="checker", stream=s.cuda_stream, out_layout=ol)
+    run(lambda: vfhip.Compositor(0).configure(ofmt, w, h, colorimetry="bt709"), comp, frames[:1], "compositor")
