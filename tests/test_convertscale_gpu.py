@@ -520,3 +520,32 @@ def test_padded_strides_and_misaligned_planes(vfhip, oracle, ifmt, ofmt, w, h, o
         assert np.array_equal(got, want)
     else:
         assert np.array_equal(meaningful(ofmt, ow, oh, got), meaningful(ofmt, ow, oh, want))
+
+
+@pytest.mark.parametrize("pad,base", [(16, 0), (3, 1)])
+@pytest.mark.parametrize("ifmt,ofmt,w,h,ow,oh", [("NV12", "BGRA", 128, 72, 64, 36), ("I420", "NV12", 90, 50, 60, 40), ("BGRA", "UYVY", 64, 36, 33, 20)])
+def test_host_frames_with_padded_strides(vfhip, oracle, ifmt, ofmt, w, h, ow, oh, pad, base):
+    """the host-frame entry point (staging upload / download) honours per-plane strides and offsets too"""
+    import ctypes as C
+    (ipl, isz), (opl, osz) = _custom_layout(vfhip, ifmt, w, h, pad, base), _custom_layout(vfhip, ofmt, ow, oh, pad, base)
+    dpl_in, dsz_in = vfhip.plane_layout(ifmt, w, h)
+    dpl_out, dsz_out = vfhip.plane_layout(ofmt, ow, oh)
+    raw = np.random.default_rng(w + pad).integers(0, 256, dsz_in, dtype=np.uint8)
+    hin, hout = _repack(raw, dpl_in, ipl, isz + 64), np.full(osz + 64, 0xAB, np.uint8)
+    cs = vfhip.ConvertScale(0)
+    cs.configure(ifmt, w, h, ofmt, ow, oh, colorimetry="bt709", chroma_site="mpeg2")
+    fi = vfhip.frame_from_base(cs.in_info, ifmt, w, h, hin.ctypes.data, layout=(ipl, isz))
+    fo = vfhip.frame_from_base(cs.out_info, ofmt, ow, oh, hout.ctypes.data, layout=(opl, osz))
+    vfhip.check(vfhip.lib.vfhip_convertscale_process(cs.h, C.byref(fi), C.byref(fo)))
+    cs.close()
+    got = _repack(hout, opl, dpl_out, dsz_out)
+    want = np.asarray(oracle.convertscale(ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", ofmt, ow, oh)).reshape(-1)
+    if ofmt in ("BGRA", "RGBA"):
+        assert np.array_equal(got, want)
+    else:
+        assert np.array_equal(meaningful(ofmt, ow, oh, got), meaningful(ofmt, ow, oh, want))
+    # bytes outside the planes' rows are not the library's to write: the gaps between planes keep the fill pattern
+    for k in range(len(opl) - 1):
+        end = opl[k][0] + opl[k][1] * (opl[k][2] if k else oh)
+        assert (hout[opl[k + 1][0] - 5: opl[k + 1][0]] == 0xAB).all() or end > opl[k + 1][0] - 5
+    assert (hout[-32:] == 0xAB).all()
