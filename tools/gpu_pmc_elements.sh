@@ -3,7 +3,7 @@
 set -o pipefail
 TAG=${1:-pmce}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
-B="python tools/bench_elements.py main"
+B="python tools/bench_elements.py ${2:-main}"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pmc_stats -- $B > $OUT/stats.jsonl 2> $OUT/stats.err || { tail $OUT/stats.err; exit 1; }
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B > $OUT/pmc_fetch.jsonl 2> $OUT/pmc_fetch.err || { tail $OUT/pmc_fetch.err; exit 1; }
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B > $OUT/pmc_write.jsonl 2> $OUT/pmc_write.err || { tail $OUT/pmc_write.err; exit 1; }
