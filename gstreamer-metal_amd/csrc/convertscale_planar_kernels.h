@@ -2,14 +2,19 @@
 // 4:2:2 (UYVY / YUY2).
 //
 // GStreamer's `videoconvert ! videoscale` does these in two steps and so do we (bit-exact, oracle/gst114.c
-// gst114_rgb_to_yuv420 / gst114_scale_plane; rules pinned by probing the real 1.14 elements):
-//   stage 1  videoconvert at the INPUT size: BGRA/RGBA -> NV12/I420 (8-bit integer matrix, chroma averaged vertically
-//            then horizontally), or NV12 <-> I420 re-packing;
+// gst114_rgb_to_yuv420 / gst114_*_packed422 / gst114_scale_plane*; rules pinned by probing the real 1.14 elements):
+//   stage 1  videoconvert at the INPUT size: BGRA/RGBA -> NV12/I420/UYVY/YUY2 (8-bit integer matrix, chroma averaged
+//            vertically then horizontally), NV12 <-> I420 re-packing, 4:2:0 <-> packed 4:2:2 (GStreamer's fast paths
+//            for I420, the generic up / down-sampling path for NV12), UYVY <-> YUY2 swizzle;
 //   stage 2  videoscale plane by plane: luma / I420 chroma as 1 x u8 (edge-aligned 16.16 horizontal taps, or pair
 //            averaging when exactly halved), NV12 chroma as 2 x u8 (centre-aligned, 6-bit taps), vertical 8-bit
-//            centre-aligned taps, pass order per plane.
-// Replaces reference rgbaToNV12 / rgbaToI420 (common/vfmetalshaders.m:90-168) for numerics=gst-exact.
-// These kernels are correct-first (one sample per lane); the headline path is k_cs_nv12_half.
+//            centre-aligned taps, pass order per plane; a packed frame as three interleaved lines; method=nearest
+//            through the same tables with a zero second tap; method=bicubic through n-tap tables (catrom on luma and
+//            packed lines, un-limited LINEAR taps on planar chroma).
+// Replaces reference rgbaToNV12 / rgbaToI420 (common/vfmetalshaders.m:90-168) and rgbaToUYVY / rgbaToYUY2
+// (convertscale/metalconvertscale_shaders.h:202-269) for numerics=gst-exact.
+// Every kernel takes a batch (blockIdx.z = frame).  Access width is what these byte kernels live on: dword / 16-bit loads
+// and dword stores wherever rows are aligned, byte-wise twins otherwise (DESIGN.md section 5.2 has the measurements).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
