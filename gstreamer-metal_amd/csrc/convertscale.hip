@@ -241,8 +241,9 @@ static int setup_plane (PlaneCfg &pc, int w, int h, int ow, int oh, int n, bool 
   if (nearest) {
     for (int y = 0; y < oh; y++) { vt[4 * y] = vt[4 * y + 1] = nearest_index (h, oh, y); vt[4 * y + 2] = 0; }
     pc.vfirst = 0;
+    if (oh != h) pc.vmode = 3;
     if (ow != w) {
-      pc.hmode = 3;
+      pc.hmode = 6;
       ht.assign ((size_t) ow * 4, 0);
       for (int x = 0; x < ow; x++) ht[4 * x] = ht[4 * x + 1] = nearest_index (w, ow, x);
     }
@@ -657,7 +658,7 @@ static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
     p.vec = (((uintptr_t) p.in | (uintptr_t) p.is | (uintptr_t) mid_pitch) & 3) == 0 && getenv ("VFHIP_PLANE_SCALAR") == nullptr;
     // contiguous source bytes (no horizontal pass, or an exact half): 8 output bytes per lane; 2-tap gathers and n-tap tables:
     // 4 bytes per lane, each family in its own small kernel
-    const bool twotap = p.vec && pc.vmode != 2;
+    const bool twotap = p.vec && pc.vmode <= 1;
     if (twotap && (pc.hmode == 0 || pc.hmode == 2 || pc.hmode == 5) && getenv ("VFHIP_PLANE_G1") == nullptr) {
       dim3 grid ((unsigned) ((pc.n * pc.ow + 511) / 512), (unsigned) ((pc.oh + 3) / 4), nz);
       hipLaunchKernelGGL ((k_scale_plane<2, 0>), grid, dim3 (64, 4), 0, s, p);

@@ -175,8 +175,8 @@ struct PlaneScaleParams {
                            // luma / chroma lines interleaved in a packed 4:2:2 frame); hmode 1 / 2 need istep == 1
   size_t in_pitch, out_pitch;   // batch: frame k of the launch at base + k * pitch (blockIdx.z)
   int vec;                 // source rows are 4-byte aligned: hmode 0 / 2 read dwords
-  int hmode;               // 0: no horizontal scaling, 1: edge-aligned 16.16 (1 x u8), 2: pair average (1 x u8), 3: 2-tap table (6-bit), 4: n-tap table, 5: like 3 with the exact-half table (2k, 2k+1, 32)
-  int vmode;               // 0: no vertical scaling, 1: 2-tap 8-bit (vtab), 2: n-tap 6-bit (vnt)
+  int hmode;               // 0: no horizontal scaling, 1: edge-aligned 16.16 (1 x u8), 2: pair average (1 x u8), 3: 2-tap table (6-bit), 4: n-tap table, 5: like 3 with the exact-half table (2k, 2k+1, 32), 6: nearest (htab)
+  int vmode;               // 0: no vertical scaling, 1: 2-tap 8-bit (vtab), 2: n-tap 6-bit (vnt), 3: nearest (vtab)
   int vfirst;
   uint32_t hinc;
   const int *vtab;         // vmode 1: oh * {i0, i1, w, 0}
@@ -204,6 +204,7 @@ __device__ __forceinline__ int hpass (const PlaneScaleParams &p, int x, At at)
       const int i0 = p.htab[4 * x], i1 = p.htab[4 * x + 1], t = p.htab[4 * x + 2];
       return (at (i0) * (64 - t) + at (i1) * t + 32) >> 6;
     }
+    case 6: return at (p.htab[4 * x]);               // nearest: one source column
     default: {                                       // n taps, 6-bit (catrom; un-limited linear)
       int acc = 32;
       for (int l = 0; l < p.nh; l++) { const int2 e = p.hnt[x * p.nh + l]; acc += at (e.x) * e.y; }
@@ -222,6 +223,7 @@ __device__ __forceinline__ int vpass (const PlaneScaleParams &p, int y, At at)
       const int a = at (i0), b = at (i1);
       return a + (((b - a) * wt + 128) >> 8);
     }
+    case 3: return at (p.vtab[4 * y]);               // nearest: one source row
     default: {
       int acc = 32;
       for (int l = 0; l < p.nv; l++) { const int2 e = p.vnt[y * p.nv + l]; acc += at (e.x) * e.y; }
@@ -347,7 +349,7 @@ __global__ __launch_bounds__ (256) void k_scale_plane (const PlaneScaleParams p0
   const int bx0 = 4 * G * (blockIdx.x * 64 + threadIdx.x), y = blockIdx.y * 4 + threadIdx.y, wb = p.n * p.ow;
   if (bx0 >= wb || y >= p.oh) return;
   int i0 = y, i1 = y, wt = 0;
-  const bool v2 = p.vmode == 1, vecok = p.vec && p.vmode != 2;      // the dword / 16-bit paths cover the 2-tap modes
+  const bool v2 = p.vmode == 1, vecok = p.vec && p.vmode <= 1;      // the dword / 16-bit paths cover the 2-tap modes
   if (v2) { i0 = p.vtab[4 * y]; i1 = p.vtab[4 * y + 1]; wt = p.vtab[4 * y + 2]; }
   const uint8_t *r0 = p.in + (size_t) i0 * p.is, *r1 = p.in + (size_t) i1 * p.is;
   uint32_t v[G];
