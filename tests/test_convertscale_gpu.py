@@ -549,3 +549,33 @@ def test_host_frames_with_padded_strides(vfhip, oracle, ifmt, ofmt, w, h, ow, oh
         end = opl[k][0] + opl[k][1] * (opl[k][2] if k else oh)
         assert (hout[opl[k + 1][0] - 5: opl[k + 1][0]] == 0xAB).all() or end > opl[k + 1][0] - 5
     assert (hout[-32:] == 0xAB).all()
+
+
+@pytest.mark.parametrize("ifmt,ofmt,w,h,ow,oh,method", [("NV12", "BGRA", 64, 36, 48, 48, "bilinear"), ("I420", "RGBA", 36, 64, 50, 40, "bilinear"), ("BGRA", "BGRA", 40, 30, 64, 64, "nearest"),
+                                                        ("UYVY", "RGBA", 64, 16, 33, 31, "bilinear"), ("NV12", "BGRA", 128, 72, 64, 36, "bilinear")])
+def test_gst_exact_letterbox(vfhip, oracle, ifmt, ofmt, w, h, ow, oh, method):
+    """add-borders with gst-exact numerics and an RGB output: the reference's centred aspect-preserving rectangle
+    (metalconvertscalerenderer.m:137-166) holds exactly what `videoconvert ! videoscale` gives at the rectangle's size, the
+    rest is the border colour in the output's byte order"""
+    import math
+    raw = np.random.default_rng(ow).integers(0, 256, vfhip.plane_layout(ifmt, w, h)[1], dtype=np.uint8)
+    cs = vfhip.ConvertScale(0)
+    cs.configure(ifmt, w, h, ofmt, ow, oh, method=method, add_borders=True, border_color=0x80FF2010, colorimetry="bt709", chroma_site="mpeg2")
+    assert cs.kernel_name != "k_cs_metal"
+    got = cs.process(raw).reshape(oh, ow, 4)
+    cs.close()
+    src, dst = np.float32(w) / np.float32(h), np.float32(ow) / np.float32(oh)
+    rw, rh = ow, oh
+    if src > dst:
+        rh = int(math.floor(float(oh) * float(np.float32(dst / src)) + 0.5))
+    else:
+        rw = int(math.floor(float(ow) * float(np.float32(src / dst)) + 0.5))
+    rw, rh = min(max(rw, 1), ow), min(max(rh, 1), oh)
+    rx, ry = (ow - rw) // 2, (oh - rh) // 2
+    inner = oracle.convertscale(ifmt, w, h, raw, "bt709", "mpeg2", method, ofmt, rw, rh)
+    assert np.array_equal(got[ry:ry + rh, rx:rx + rw], inner)
+    a, r, g, b = 0x80, 0xFF, 0x20, 0x10
+    colour = np.array([r, g, b, a] if ofmt == "RGBA" else [b, g, r, a], np.uint8)
+    mask = np.ones((oh, ow), bool)
+    mask[ry:ry + rh, rx:rx + rw] = False
+    assert (got[mask] == colour).all() and (rw < ow or rh < oh or not mask.any())
