@@ -156,6 +156,7 @@ struct VfHipCompositor {
   bool configured = false;
   VfHipVideoInfo out {};
   uint32_t *scratch[2] = { nullptr, nullptr };   // only for > COMP_MAX_LAYERS pads
+  Flights fl;                                    // _submit / _wait: flight k owns staging slots k * COMP_FLIGHT_SLOTS ...
 };
 
 static int comp_launch (VfHipCompositor *h, const VfHipPadInput *pads, int count, int background, VfHipFrame *out, hipStream_t s,
@@ -261,6 +262,7 @@ int vfhip_compositor_composite (VfHipCompositor *h, const VfHipPadInput *pads, i
   int rc = comp_check (h, pads, count, background, out);
   if (rc) return rc;
   std::lock_guard<std::mutex> lk (h->mu);
+  if (h->fl.count) return set_error (VFHIP_ERR_INVALID, "frames submitted with vfhip_compositor_submit are still in flight");
   VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
   std::vector<VfHipPadInput> dpads (pads, pads + count);
   for (int k = 0; k < count; k++)                     // slot k + 1 per pad (slot-indexed like the reference's texture cache)
@@ -273,11 +275,60 @@ int vfhip_compositor_composite (VfHipCompositor *h, const VfHipPadInput *pads, i
   return download_frame (h->st, 0, &dout, out);
 }
 
+// pipelined host path: flight k uses staging slot k * COMP_FLIGHT_SLOTS for the output and the next `count` for the pads
+// (the synchronous entry point uses flight 0's slots: it refuses to run while frames are in flight)
+enum { COMP_FLIGHT_SLOTS = 65 };
+
+int vfhip_compositor_submit (VfHipCompositor *h, const VfHipPadInput *pads, int count, int background, VfHipFrame *out)
+{
+  int rc = comp_check (h, pads, count, background, out);
+  if (rc) return rc;
+  if (count >= COMP_FLIGHT_SLOTS) return set_error (VFHIP_ERR_UNSUPPORTED, "at most %d pads per pipelined composite", COMP_FLIGHT_SLOTS - 1);
+  std::lock_guard<std::mutex> lk (h->mu);
+  VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
+  Flights &fl = h->fl;
+  if (fl.count >= 2) return set_error (VFHIP_ERR_INVALID, "two frames are already in flight: call vfhip_compositor_wait first");
+  const int k = (fl.head + fl.count) & 1;
+  const size_t base = (size_t) k * COMP_FLIGHT_SLOTS;
+  std::vector<VfHipPadInput> dpads (pads, pads + count);
+  for (int i = 0; i < count; i++)
+    if ((rc = upload_frame (h->st, base + 1 + (size_t) i, &pads[i].frame, &dpads[i].frame))) return rc;
+  VfHipFrame dout;
+  if ((rc = output_frame (h->st, base, &h->out, out, &dout))) return rc;
+  if (count > 0) VFHIP_CHECK_HIP (hipStreamWaitEvent (h->st.s_compute, h->st.ev_h2d, 0));
+  if ((rc = comp_launch (h, dpads.data (), count, background, &dout, h->st.s_compute))) return rc;
+  VFHIP_CHECK_HIP (hipEventRecord (h->st.ev_compute, h->st.s_compute));
+  fl.f[k].out = *out;
+  if ((rc = download_begin (h->st, base, &fl.f[k].out, fl.f[k].staged, h->st.ev_done[k]))) return rc;
+  fl.count++;
+  return VFHIP_OK;
+}
+
+int vfhip_compositor_wait (VfHipCompositor *h)
+{
+  if (!h) return set_error (VFHIP_ERR_INVALID, "null handle");
+  std::lock_guard<std::mutex> lk (h->mu);
+  VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
+  Flights &fl = h->fl;
+  if (fl.count == 0) return set_error (VFHIP_ERR_INVALID, "no frame in flight");
+  const int k = fl.head;
+  fl.head ^= 1; fl.count--;
+  return download_finish (h->st, (size_t) k * COMP_FLIGHT_SLOTS, &fl.f[k].out, fl.f[k].staged, h->st.ev_done[k]);
+}
+
+int vfhip_compositor_in_flight (VfHipCompositor *h)
+{
+  if (!h) return 0;
+  std::lock_guard<std::mutex> lk (h->mu);
+  return h->fl.count;
+}
+
 void vfhip_compositor_cleanup (VfHipCompositor *h)
 {
   if (!h) return;
   std::lock_guard<std::mutex> lk (h->mu);
   (void) hipSetDevice (h->dev->ordinal);
+  flights_abandon (h->st, h->fl);
   for (int k = 0; k < 2; k++) { if (h->scratch[k]) (void) hipFree (h->scratch[k]); h->scratch[k] = nullptr; }
   for (auto &b : h->st.slots) { if (b.host) (void) hipHostFree (b.host); if (b.devp) (void) hipFree (b.devp); }
   h->st.slots.clear ();

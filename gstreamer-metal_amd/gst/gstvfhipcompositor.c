@@ -685,13 +685,19 @@ typedef struct
   gboolean have_out_info, out_is_device;
   guint64 n_frames;
   GstVfHipPinStats pin;                         /* recurring pageable input memories are page-locked in place */
+  /* async-depth=1: the composite submitted last (vfhip_compositor_submit); its input buffers and its output buffer stay
+   * mapped until the next aggregate() has submitted its own and waits for this one */
+  gint pref_w, pref_h, pref_fn, pref_fd;        /* what update_src_caps found: bounding box of the pads, highest input frame rate */
+  gint async_depth;
+  gboolean have_pending;
+  struct { GstBuffer *outbuf; GstVideoFrame out; guint n; GstBuffer **bufs; GstVideoFrame *frames; } pending;
 } GstVfHipCompositor;
 typedef struct
 {
   GstAggregatorClass parent_class;
 } GstVfHipCompositorClass;
 
-enum { PROP_0, PROP_BACKGROUND, PROP_ZERO_SIZE_IS_UNSCALED, PROP_DEVICE_ID };
+enum { PROP_0, PROP_BACKGROUND, PROP_ZERO_SIZE_IS_UNSCALED, PROP_DEVICE_ID, PROP_ASYNC_DEPTH };
 
 static GstStaticPadTemplate comp_src_template = GST_STATIC_PAD_TEMPLATE ("src", GST_PAD_SRC, GST_PAD_ALWAYS,
     GST_STATIC_CAPS (GST_VFHIP_CAPS (VFHIP_COMP_FORMATS)));
@@ -792,7 +798,7 @@ comp_update_src_caps (GstAggregator * agg, GstCaps * caps, GstCaps ** ret)
   gint bw = -1, bh = -1, fn = -1, fd = -1;
   gdouble best = 0.0;
   GList *l;
-  GstCaps *tmpl, *size;
+  GstCaps *tmpl;
   GST_OBJECT_LOCK (agg);
   for (l = GST_ELEMENT (agg)->sinkpads; l; l = l->next) {
     GstVfHipCompositorPad *cpad = CPAD (l->data);
@@ -811,15 +817,13 @@ comp_update_src_caps (GstAggregator * agg, GstCaps * caps, GstCaps ** ret)
   if (bw <= 0 || bh <= 0)
     return GST_AGGREGATOR_FLOW_NEED_DATA;                 /* no pad has caps yet */
   if (fn <= 0 || fd <= 0) { fn = 25; fd = 1; }
-  size = gst_caps_new_simple ("video/x-raw", "width", G_TYPE_INT, bw, "height", G_TYPE_INT, bh, "framerate", GST_TYPE_FRACTION, fn, fd, NULL);
-  {                                                           /* the output may stay in HBM for a downstream vfhip element */
-    GstCaps *both = gst_vfhip_caps_both_memories (size);
-    gst_caps_unref (size);
-    size = both;
-  }
+  /* like the reference's _update_caps / _fixate_caps (gstvfmetalcompositor.m:394-540): the pads' bounding box and the highest
+   * input frame rate are what the output PREFERS; a downstream caps filter may still ask for another size (fixate_src_caps
+   * takes the nearest one) */
+  self->pref_w = bw; self->pref_h = bh; self->pref_fn = fn; self->pref_fd = fd;
   tmpl = gst_static_pad_template_get_caps (&comp_src_template);
-  *ret = gst_caps_intersect (size, tmpl);
-  gst_caps_unref (size); gst_caps_unref (tmpl);
+  *ret = gst_caps_copy (tmpl);
+  gst_caps_unref (tmpl);
   if (caps) {
     GstCaps *tmp = gst_caps_intersect (*ret, caps);
     gst_caps_unref (*ret);
@@ -831,11 +835,16 @@ comp_update_src_caps (GstAggregator * agg, GstCaps * caps, GstCaps ** ret)
 static GstCaps *
 comp_fixate_src_caps (GstAggregator * agg, GstCaps * caps)
 {
+  GstVfHipCompositor *self = COMP (agg);
   GstStructure *s;
-  (void) agg;
-  caps = gst_caps_make_writable (caps);
+  caps = gst_caps_make_writable (gst_caps_truncate (caps));
   s = gst_caps_get_structure (caps, 0);
   gst_structure_fixate_field_string (s, "format", "BGRA");
+  if (self->pref_w > 0 && self->pref_h > 0) {
+    gst_structure_fixate_field_nearest_int (s, "width", self->pref_w);
+    gst_structure_fixate_field_nearest_int (s, "height", self->pref_h);
+    gst_structure_fixate_field_nearest_fraction (s, "framerate", self->pref_fn, self->pref_fd);
+  }
   if (gst_structure_has_field (s, "pixel-aspect-ratio"))
     gst_structure_fixate_field_nearest_fraction (s, "pixel-aspect-ratio", 1, 1);
   return gst_caps_fixate (caps);
@@ -871,6 +880,38 @@ padref_cmp (const void *a, const void *b)
   return x->order < y->order ? -1 : (x->order > y->order);
 }
 
+/* completes the composite in flight: waits for it, releases its inputs and pushes (or, with push = FALSE, drops) its output */
+static GstFlowReturn
+comp_finish_pending (GstVfHipCompositor * self, gboolean push)
+{
+  GstFlowReturn flow = GST_FLOW_OK;
+  GstBuffer *outbuf;
+  guint i;
+  gint rc;
+  if (!self->have_pending)
+    return GST_FLOW_OK;
+  self->have_pending = FALSE;
+  rc = vfhip_compositor_wait (self->renderer);
+  gst_video_frame_unmap (&self->pending.out);
+  for (i = 0; i < self->pending.n; i++) {
+    if (self->pending.frames[i].buffer) gst_video_frame_unmap (&self->pending.frames[i]);
+    if (self->pending.bufs[i]) gst_buffer_unref (self->pending.bufs[i]);
+  }
+  g_free (self->pending.frames); g_free (self->pending.bufs);
+  outbuf = self->pending.outbuf;
+  memset (&self->pending, 0, sizeof (self->pending));
+  if (rc != VFHIP_OK) {
+    GST_ERROR_OBJECT (self, "HIP compositing failed: %s", vfhip_last_error_string ());
+    gst_buffer_unref (outbuf);
+    return GST_FLOW_ERROR;
+  }
+  if (push)
+    flow = gst_aggregator_finish_buffer (GST_AGGREGATOR (self), outbuf);
+  else
+    gst_buffer_unref (outbuf);
+  return flow;
+}
+
 static GstFlowReturn
 comp_aggregate (GstAggregator * agg, gboolean timeout)
 {
@@ -883,7 +924,7 @@ comp_aggregate (GstAggregator * agg, gboolean timeout)
   VfHipPadInput *pads;
   VfHipFrame vout;
   GstAllocator *alloc;
-  gboolean covered = FALSE;
+  gboolean covered = FALSE, keep = FALSE;
   gint rc;
   (void) timeout;
   if (!self->renderer || !self->have_out_info)
@@ -920,7 +961,8 @@ comp_aggregate (GstAggregator * agg, gboolean timeout)
     used++;
   }
   if (n > 0 && n_eos == n) {
-    rc = GST_FLOW_EOS;
+    rc = comp_finish_pending (self, TRUE);                 /* the last frame of an async-depth=1 stream */
+    if (rc == GST_FLOW_OK) rc = GST_FLOW_EOS;
     goto done;
   }
   alloc = self->out_is_device ? gst_vfhip_device_allocator_get (gst_vfhip_element_device (self)) : gst_vfhip_pinned_allocator_get ();
@@ -932,6 +974,27 @@ comp_aggregate (GstAggregator * agg, gboolean timeout)
     goto done;
   }
   gst_vfhip_frame (&out, &vout);
+  if (self->async_depth > 0) {
+    /* submit this composite, THEN complete the previous one: its download overlaps this one's uploads and kernel */
+    rc = vfhip_compositor_submit (self->renderer, pads, (int) used, (covered && used > 0) ? VFHIP_BG_TRANSPARENT : self->background, &vout);
+    if (rc != VFHIP_OK) {
+      GST_ERROR_OBJECT (self, "HIP compositing failed: %s", vfhip_last_error_string ());
+      gst_video_frame_unmap (&out);
+      gst_buffer_unref (outbuf);
+      rc = GST_FLOW_ERROR;
+      goto done;
+    }
+    if (GST_VIDEO_INFO_FPS_N (&self->out_info) > 0) {
+      GST_BUFFER_PTS (outbuf) = gst_util_uint64_scale (self->n_frames, GST_SECOND * GST_VIDEO_INFO_FPS_D (&self->out_info), GST_VIDEO_INFO_FPS_N (&self->out_info));
+      GST_BUFFER_DURATION (outbuf) = gst_util_uint64_scale (1, GST_SECOND * GST_VIDEO_INFO_FPS_D (&self->out_info), GST_VIDEO_INFO_FPS_N (&self->out_info));
+    }
+    self->n_frames++;
+    rc = comp_finish_pending (self, TRUE);
+    self->pending.outbuf = outbuf; self->pending.out = out; self->pending.n = n; self->pending.bufs = bufs; self->pending.frames = frames;
+    self->have_pending = TRUE;
+    keep = TRUE;                                           /* inputs and output stay mapped until their wait */
+    goto done;
+  }
   rc = vfhip_compositor_composite (self->renderer, pads, (int) used, (covered && used > 0) ? VFHIP_BG_TRANSPARENT : self->background, &vout);
   gst_video_frame_unmap (&out);
   if (rc != VFHIP_OK) {
@@ -948,11 +1011,12 @@ comp_aggregate (GstAggregator * agg, gboolean timeout)
   rc = gst_aggregator_finish_buffer (agg, outbuf);
 done:
   for (i = 0; i < n; i++) {
-    if (frames[i].buffer) gst_video_frame_unmap (&frames[i]);
-    if (bufs[i]) gst_buffer_unref (bufs[i]);
+    if (!keep && frames[i].buffer) gst_video_frame_unmap (&frames[i]);
+    if (!keep && bufs[i]) gst_buffer_unref (bufs[i]);
     gst_object_unref (refs[i].pad);
   }
-  g_free (pads); g_free (frames); g_free (bufs); g_free (refs);
+  if (!keep) { g_free (frames); g_free (bufs); }
+  g_free (pads); g_free (refs);
   return (GstFlowReturn) rc;
 }
 
@@ -974,10 +1038,18 @@ comp_propose_allocation (GstAggregator * agg, GstAggregatorPad * pad, GstQuery *
   return TRUE;
 }
 
+static GstFlowReturn
+comp_flush (GstAggregator * agg)
+{
+  (void) comp_finish_pending (COMP (agg), FALSE);          /* a flushed frame is completed and dropped */
+  return GST_FLOW_OK;
+}
+
 static gboolean
 comp_stop (GstAggregator * agg)
 {
   GstVfHipCompositor *self = COMP (agg);
+  (void) comp_finish_pending (self, FALSE);
   if (self->renderer)
     vfhip_compositor_cleanup (self->renderer);
   self->n_frames = 0;
@@ -993,6 +1065,7 @@ comp_set_property (GObject * object, guint id, const GValue * value, GParamSpec 
     case PROP_BACKGROUND: self->background = g_value_get_enum (value); break;
     case PROP_ZERO_SIZE_IS_UNSCALED: self->zero_size_is_unscaled = g_value_get_boolean (value); break;
     case PROP_DEVICE_ID: self->device_id = g_value_get_int (value); break;
+    case PROP_ASYNC_DEPTH: self->async_depth = g_value_get_int (value); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
   }
 }
@@ -1005,6 +1078,7 @@ comp_get_property (GObject * object, guint id, GValue * value, GParamSpec * pspe
     case PROP_BACKGROUND: g_value_set_enum (value, self->background); break;
     case PROP_ZERO_SIZE_IS_UNSCALED: g_value_set_boolean (value, self->zero_size_is_unscaled); break;
     case PROP_DEVICE_ID: g_value_set_int (value, self->device_id); break;
+    case PROP_ASYNC_DEPTH: g_value_set_int (value, self->async_depth); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
   }
 }
@@ -1084,6 +1158,7 @@ gst_vfhip_compositor_class_init (GstVfHipCompositorClass * klass)
   ac->negotiated_src_caps = GST_DEBUG_FUNCPTR (comp_negotiated_src_caps);
   ac->aggregate = GST_DEBUG_FUNCPTR (comp_aggregate);
   ac->stop = GST_DEBUG_FUNCPTR (comp_stop);
+  ac->flush = GST_DEBUG_FUNCPTR (comp_flush);
   ac->propose_allocation = GST_DEBUG_FUNCPTR (comp_propose_allocation);
 
   g_object_class_install_property (oc, PROP_BACKGROUND, g_param_spec_enum ("background", "Background", "Background type",
@@ -1093,6 +1168,7 @@ gst_vfhip_compositor_class_init (GstVfHipCompositorClass * klass)
           G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (oc, PROP_DEVICE_ID, g_param_spec_int ("device-id", "Device ID",
           "GPU ordinal to run on (-1: $VFHIP_DEVICE, else 0)", -1, 63, GST_VFHIP_DEFAULT_DEVICE_ID, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_ASYNC_DEPTH, gst_vfhip_async_depth_pspec ());
 
   gst_element_class_add_static_pad_template_with_gtype (ec, &comp_src_template, GST_TYPE_AGGREGATOR_PAD);
   gst_element_class_add_static_pad_template_with_gtype (ec, &comp_sink_template, gst_vfhip_compositor_pad_get_type ());

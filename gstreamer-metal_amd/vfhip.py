@@ -81,6 +81,9 @@ def _load():
     lib.vfhip_videofilter_set_lut.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.vfhip_compositor_configure.argtypes = [C.c_void_p, C.POINTER(VideoInfo)]
     lib.vfhip_compositor_composite.argtypes = [C.c_void_p, C.POINTER(PadInput), C.c_int, C.c_int, C.POINTER(Frame)]
+    lib.vfhip_compositor_submit.argtypes = lib.vfhip_compositor_composite.argtypes
+    lib.vfhip_compositor_wait.argtypes = [C.c_void_p]
+    lib.vfhip_compositor_in_flight.argtypes = [C.c_void_p]
     lib.vfhip_compositor_composite_device.argtypes = [C.c_void_p, C.POINTER(PadInput), C.c_int, C.c_int, C.POINTER(Frame), C.c_void_p]
     lib.vfhip_transform_configure.argtypes = [C.c_void_p, C.POINTER(VideoInfo), C.POINTER(VideoInfo)]
     lib.vfhip_transform_process.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(Frame), C.POINTER(TransformParams)]

@@ -254,6 +254,12 @@ int vfhip_compositor_composite_device (VfHipCompositor *h, const VfHipPadInput *
  * at out0->data[p] + k * out_frame_pitch; at most 16 pads */
 int vfhip_compositor_composite_device_batch (VfHipCompositor *h, const VfHipPadInput *inputs, const size_t *pad_frame_pitch, int count,
     int background, VfHipFrame *out0, size_t out_frame_pitch, int n_frames, void *stream);
+/* pipelined host path, two deep like the other elements' _submit / _wait: submit enqueues the uploads of every pad, the
+ * kernel and the download and returns; wait blocks until the OLDEST output is complete.  Pad frames and the output frame
+ * must stay valid (mapped) until the wait of their submit returns. */
+int vfhip_compositor_submit (VfHipCompositor *h, const VfHipPadInput *inputs, int count, int background, VfHipFrame *out);
+int vfhip_compositor_wait (VfHipCompositor *h);
+int vfhip_compositor_in_flight (VfHipCompositor *h);
 void vfhip_compositor_cleanup (VfHipCompositor *h);
 void vfhip_compositor_free (VfHipCompositor *h);
 

@@ -320,3 +320,43 @@ def test_elements_take_padded_and_misaligned_frames(vfhip, ifmt, ofmt, pad, base
         pads = [vfhip.Compositor.pad(ifmt, w, h, i, 3, 2, w, h, 0.8, "over", "bt709", layout=il), vfhip.Compositor.pad(ifmt, w, h, i, -11, 9, 40, 25, 0.5, "add", "bt709", layout=il)]
         e.composite_device(pads, o, background="checker", stream=s.cuda_stream, out_layout=ol)
     run(lambda: vfhip.Compositor(0).configure(ofmt, w, h, colorimetry="bt709"), comp, frames[:1], "compositor")
+
+
+def test_compositor_submit_wait_pipeline(vfhip):
+    """the compositor's pipelined host path: composites submitted two deep come back in order and equal the synchronous
+    results (pads change from frame to frame); misuse is reported"""
+    w, h, n = 160, 90, 6
+    rng = np.random.default_rng(5)
+    lib = vfhip.lib
+    comp = vfhip.Compositor(0).configure("BGRA", w, h, colorimetry="bt709")
+    a = [rng.integers(0, 256, vfhip.plane_layout("BGRA", 64, 48)[1], dtype=np.uint8) for _ in range(n)]
+    b = [rng.integers(0, 256, vfhip.plane_layout("NV12", 80, 60)[1], dtype=np.uint8) for _ in range(n)]
+
+    def pads(k):
+        return [("BGRA", 64, 48, a[k], 5 + k, 3, 64, 48, 0.9, "over", "bt709"), ("NV12", 80, 60, b[k], 60, 20 - k, 100, 70, 0.6, "add", "bt709")]
+    want = [comp.composite(pads(k), background="checker") for k in range(n)]
+    outs = [np.zeros(w * h * 4, np.uint8) for _ in range(n)]
+    keep, done = [], 0
+    assert lib.vfhip_compositor_wait(comp.h) == -1 and lib.vfhip_compositor_in_flight(comp.h) == 0
+    for k in range(n):
+        arr = (vfhip.PadInput * 2)()
+        for i, p in enumerate(pads(k)):
+            arr[i] = vfhip.Compositor.pad(p[0], p[1], p[2], p[3].ctypes.data, *p[4:])
+        fo = vfhip.frame_from_base(comp.info, "BGRA", w, h, outs[k].ctypes.data)
+        keep.append((arr, fo))
+        vfhip.check(lib.vfhip_compositor_submit(comp.h, arr, 2, vfhip.BACKGROUNDS["checker"], C.byref(fo)))
+        if lib.vfhip_compositor_in_flight(comp.h) == 2:
+            if k == 1:
+                assert lib.vfhip_compositor_submit(comp.h, arr, 2, 0, C.byref(fo)) == -1
+                assert lib.vfhip_compositor_composite(comp.h, arr, 2, 0, C.byref(fo)) == -1
+            vfhip.check(lib.vfhip_compositor_wait(comp.h))
+            assert np.array_equal(outs[done], want[done]), f"frame {done}"
+            done += 1
+    while lib.vfhip_compositor_in_flight(comp.h):
+        vfhip.check(lib.vfhip_compositor_wait(comp.h))
+        assert np.array_equal(outs[done], want[done]), f"frame {done}"
+        done += 1
+    assert done == n
+    # cleanup with a frame still in flight must not crash
+    vfhip.check(lib.vfhip_compositor_submit(comp.h, keep[0][0], 2, 0, C.byref(keep[0][1])))
+    comp.close()

@@ -404,3 +404,21 @@ def test_pixel_parity_yuv_outputs_other_methods(tmp_path, ifmt, iw, ih, ofmt, ow
     x, y = np.fromfile(a, np.uint8), np.fromfile(b, np.uint8)
     assert x.size == y.size and x.size > 0
     assert np.array_equal(x, y), f"max diff {np.abs(x.astype(int) - y.astype(int)).max()}, {(x != y).sum()} bytes differ"
+
+
+@pytest.mark.parametrize("n", [1, 6])
+@pytest.mark.parametrize("ofmt", ["BGRA", "NV12"])
+def test_compositor_async_depth_same_frames(tmp_path, n, ofmt):
+    """vfhipcompositor async-depth=1 (submit this composite, then complete the previous one): the same frames in the same
+    order as the synchronous element, none lost at EOS"""
+    outs = []
+    for depth in (1, 0):
+        path = tmp_path / f"c{depth}.raw"
+        r = gst_env.launch(f"vfhipcompositor name=c background=checker async-depth={depth} sink_0::alpha=0.8 sink_1::xpos=100 sink_1::ypos=40 sink_1::width=200 sink_1::height=120 "
+                           f"sink_1::operator=add ! {caps(ofmt, 480, 270)} ! filesink location={path} "
+                           f"videotestsrc num-buffers={n} pattern=ball ! {caps('BGRA', 320, 240)} ! c.sink_0 "
+                           f"videotestsrc num-buffers={n} pattern=smpte ! {caps('NV12', 160, 120)} ! c.sink_1", timeout=300)
+        assert r.returncode == 0, r.stderr
+        outs.append(np.fromfile(path, np.uint8))
+    assert outs[0].size == outs[1].size and outs[0].size > 0 and outs[0].size % n == 0
+    assert np.array_equal(outs[0], outs[1])

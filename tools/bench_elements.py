@@ -233,6 +233,49 @@ def e2e():
     cs.close()
 
 
+def e2e_compositor():
+    """C4 at the element level (PCIe-inclusive): 4 x BGRA 1080p + NV12 720p pinned host frames -> BGRA 2160p pinned host frame,
+    synchronous vfhip_compositor_composite vs two composites in flight (vfhip_compositor_submit / _wait)"""
+    import ctypes as C
+    import time
+    import numpy as np
+    ow, oh = 3840, 2160
+    comp = vfhip.Compositor(0).configure("BGRA", ow, oh, colorimetry="bt709")
+    specs = [("BGRA", 1920, 1080, 0, 0), ("BGRA", 1920, 1080, 1920, 0), ("BGRA", 1920, 1080, 0, 1080), ("BGRA", 1920, 1080, 1920, 1080), ("NV12", 1280, 720, 1280, 720)]
+    rng = np.random.default_rng(0)
+    arr = (vfhip.PadInput * len(specs))()
+    total = 0
+    for i, (fmt, w, h, x, y) in enumerate(specs):
+        size = vfhip.plane_layout(fmt, w, h)[1]
+        total += size
+        p = vfhip.lib.vfhip_pinned_alloc(0, size)
+        np.ctypeslib.as_array((C.c_uint8 * size).from_address(p))[:] = rng.integers(0, 256, size, dtype=np.uint8)
+        arr[i] = vfhip.Compositor.pad(fmt, w, h, p, x, y, w, h, 1.0 if i < 4 else 0.7, "over", "bt709")
+    out_size = 4 * ow * oh
+    total += out_size
+    fo = vfhip.frame_from_base(comp.info, "BGRA", ow, oh, vfhip.lib.vfhip_pinned_alloc(0, out_size))
+    lib, bg = vfhip.lib, vfhip.BACKGROUNDS["black"]
+    for _ in range(3):
+        vfhip.check(lib.vfhip_compositor_composite(comp.h, arr, len(specs), bg, C.byref(fo)))
+    n, t0 = 60, time.perf_counter()
+    for _ in range(n):
+        vfhip.check(lib.vfhip_compositor_composite(comp.h, arr, len(specs), bg, C.byref(fo)))
+    dt = time.perf_counter() - t0
+    print(json.dumps({"config": "C4 end-to-end vfhip_compositor_composite, pinned host frames (sync per frame)", "frames_per_s": round(n / dt, 1),
+                      "ms_per_frame": round(dt / n * 1e3, 3), "pcie_GBps": round(total * n / dt / 1e9, 2)}), flush=True)
+    n, t0 = 120, time.perf_counter()
+    for _ in range(n):
+        vfhip.check(lib.vfhip_compositor_submit(comp.h, arr, len(specs), bg, C.byref(fo)))
+        if lib.vfhip_compositor_in_flight(comp.h) == 2:
+            vfhip.check(lib.vfhip_compositor_wait(comp.h))
+    while lib.vfhip_compositor_in_flight(comp.h):
+        vfhip.check(lib.vfhip_compositor_wait(comp.h))
+    dt = time.perf_counter() - t0
+    print(json.dumps({"config": "C4 end-to-end vfhip_compositor_submit/_wait, pinned host frames (two composites in flight)", "frames_per_s": round(n / dt, 1),
+                      "ms_per_frame": round(dt / n * 1e3, 3), "pcie_GBps": round(total * n / dt / 1e9, 2)}), flush=True)
+    comp.close()
+
+
 def e2e_chain():
     """C5 chain at the element level (synchronous *_process calls, pinned host frames at both ends): deinterlace ->
     convertscale with the intermediate frame (a) in host memory — what a pipeline of system-memory elements does, four
@@ -278,8 +321,11 @@ if __name__ == "__main__":
         main()
     elif len(sys.argv) > 1 and sys.argv[1] == "staged":
         staged()
+    elif len(sys.argv) > 1 and sys.argv[1] == "e2e_compositor":
+        e2e_compositor()
     elif len(sys.argv) > 1 and sys.argv[1] == "e2e":
         e2e()
+        e2e_compositor()
         e2e_chain()
     else:
         main()
