@@ -941,13 +941,35 @@ comp_aggregate (GstAggregator * agg, gboolean timeout)
   bufs = g_new0 (GstBuffer *, MAX (n, 1));
   frames = g_new0 (GstVideoFrame, MAX (n, 1));
   pads = g_new0 (VfHipPadInput, MAX (n, 1));
+  for (i = 0; i < n; i++) {                                /* take this frame's buffer of every pad */
+    GstVfHipCompositorPad *cpad = refs[i].pad;
+    if (gst_aggregator_pad_is_eos (GST_AGGREGATOR_PAD (cpad))) { n_eos++; continue; }
+    bufs[i] = gst_aggregator_pad_pop_buffer (GST_AGGREGATOR_PAD (cpad));
+  }
   for (i = 0; i < n; i++) {
     GstVfHipCompositorPad *cpad = refs[i].pad;
     gint w, h, xo, yo;
-    if (gst_aggregator_pad_is_eos (GST_AGGREGATOR_PAD (cpad))) { n_eos++; continue; }
-    bufs[i] = gst_aggregator_pad_pop_buffer (GST_AGGREGATOR_PAD (cpad));
+    guint j;
+    gboolean obscured = FALSE;
     if (!bufs[i] || !cpad->have_info || cpad->alpha == 0.0)
       continue;
+    /* a pad completely behind an opaque later one is never seen: not mapped, not uploaded, not drawn (the reference's
+     * pad_obscures_rectangle, gstvfmetalcompositor.m:329-358; here the later pad must also REPLACE what is under it —
+     * operator source or over — since an `add` pad lets the lower one through) */
+    comp_pad_rect (self, cpad, GST_VIDEO_INFO_PAR_N (&self->out_info), GST_VIDEO_INFO_PAR_D (&self->out_info), &w, &h, &xo, &yo);
+    for (j = i + 1; j < n && !obscured; j++) {
+      GstVfHipCompositorPad *up = refs[j].pad;
+      gint uw, uh, uxo, uyo;
+      if (!bufs[j] || !up->have_info || up->alpha != 1.0 || GST_VIDEO_INFO_HAS_ALPHA (&up->info) || up->op == VFHIP_BLEND_ADD)
+        continue;
+      comp_pad_rect (self, up, GST_VIDEO_INFO_PAR_N (&self->out_info), GST_VIDEO_INFO_PAR_D (&self->out_info), &uw, &uh, &uxo, &uyo);
+      obscured = up->xpos + uxo <= cpad->xpos + xo && up->ypos + uyo <= cpad->ypos + yo &&
+          up->xpos + uxo + uw >= cpad->xpos + xo + w && up->ypos + uyo + uh >= cpad->ypos + yo + h;
+    }
+    if (obscured) {
+      GST_LOG_OBJECT (cpad, "obscured by a later opaque pad: skipped");
+      continue;
+    }
     gst_vfhip_pin_foreign_memory (bufs[i], &self->pin);
     if (!gst_video_frame_map (&frames[i], &cpad->info, bufs[i], (GstMapFlags) (GST_MAP_READ | gst_vfhip_map_flag (bufs[i], gst_vfhip_element_device (self)))))
       continue;

@@ -422,3 +422,22 @@ def test_compositor_async_depth_same_frames(tmp_path, n, ofmt):
         outs.append(np.fromfile(path, np.uint8))
     assert outs[0].size == outs[1].size and outs[0].size > 0 and outs[0].size % n == 0
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_compositor_skips_obscured_pads(tmp_path):
+    """a pad completely behind a later opaque pad is neither uploaded nor drawn (reference pad_obscures_rectangle,
+    gstvfmetalcompositor.m:329-358) and the frame is the same as without it; an `add` pad on top obscures nothing"""
+    def run(top_op, with_lower, debug=None):
+        path = tmp_path / f"o_{top_op}_{int(with_lower)}.raw"
+        lower = f"videotestsrc num-buffers=2 pattern=ball ! {caps('BGRA', 160, 120)} ! c.sink_0 " if with_lower else ""
+        pads = "sink_0::xpos=50 sink_0::ypos=40 sink_1::operator=" + top_op if with_lower else "sink_0::operator=" + top_op
+        r = gst_env.launch(f"vfhipcompositor name=c background=black {pads} ! {caps('BGRA', 320, 240)} ! filesink location={path} {lower}"
+                           f"videotestsrc num-buffers=2 pattern=smpte ! {caps('NV12', 320, 240)} ! c.sink_{1 if with_lower else 0}", timeout=60, debug=debug)
+        assert r.returncode == 0, r.stderr
+        return np.fromfile(path, np.uint8), r.stderr
+    both, log = run("over", True, debug="vfhip:7")
+    only, _ = run("over", False)
+    assert both.size == only.size == 2 * 320 * 240 * 4 and np.array_equal(both, only)
+    assert "obscured by a later opaque pad" in log
+    added, log = run("add", True, debug="vfhip:7")
+    assert "obscured by a later opaque pad" not in log and not np.array_equal(added, only)
