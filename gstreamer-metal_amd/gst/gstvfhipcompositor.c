@@ -1042,6 +1042,48 @@ done:
   return (GstFlowReturn) rc;
 }
 
+/* Pointer navigation events travelling upstream go to the sink pads whose picture lies under the pointer, with the
+ * coordinates translated into that input's own pixels (reference _src_event / src_pad_mouse_event,
+ * gstvfmetalcompositor.m:704-787).  The event's structure is read directly ("event" = mouse-move, mouse-button-press,
+ * mouse-button-release, mouse-scroll), so this needs nothing newer than GStreamer 1.14. */
+static gboolean
+comp_src_event (GstAggregator * agg, GstEvent * event)
+{
+  GstVfHipCompositor *self = COMP (agg);
+  const GstStructure *st;
+  const gchar *kind;
+  gdouble px, py;
+  GList *l, *pads = NULL;
+  gboolean res = FALSE;
+  if (GST_EVENT_TYPE (event) != GST_EVENT_NAVIGATION || !(st = gst_event_get_structure (event)) ||
+      !(kind = gst_structure_get_string (st, "event")) || !g_str_has_prefix (kind, "mouse-") ||
+      !gst_structure_get_double (st, "pointer_x", &px) || !gst_structure_get_double (st, "pointer_y", &py) || !self->have_out_info)
+    return GST_AGGREGATOR_CLASS (gst_vfhip_compositor_parent_class)->src_event (agg, event);
+  GST_OBJECT_LOCK (agg);
+  for (l = GST_ELEMENT (agg)->sinkpads; l; l = l->next)
+    pads = g_list_prepend (pads, gst_object_ref (l->data));
+  GST_OBJECT_UNLOCK (agg);
+  for (l = pads; l; l = l->next) {
+    GstVfHipCompositorPad *cpad = CPAD (l->data);
+    gint w, h, xo, yo;
+    if (cpad->have_info) {
+      gdouble x0, y0;
+      comp_pad_rect (self, cpad, GST_VIDEO_INFO_PAR_N (&self->out_info), GST_VIDEO_INFO_PAR_D (&self->out_info), &w, &h, &xo, &yo);
+      x0 = cpad->xpos + xo; y0 = cpad->ypos + yo;
+      if (w > 0 && h > 0 && px >= x0 && px < x0 + w && py >= y0 && py < y0 + h) {
+        GstStructure *copy = gst_structure_copy (st);
+        gst_structure_set (copy, "pointer_x", G_TYPE_DOUBLE, (px - x0) * GST_VIDEO_INFO_WIDTH (&cpad->info) / (gdouble) w,
+            "pointer_y", G_TYPE_DOUBLE, (py - y0) * GST_VIDEO_INFO_HEIGHT (&cpad->info) / (gdouble) h, NULL);
+        res |= gst_pad_push_event (GST_PAD (cpad), gst_event_new_navigation (copy));
+      }
+    }
+    gst_object_unref (l->data);
+  }
+  g_list_free (pads);
+  gst_event_unref (event);
+  return res;
+}
+
 /* upstream of every sink pad is offered the device allocator (memory:HIPMemory caps) or the pinned host one, plus video meta */
 static gboolean
 comp_propose_allocation (GstAggregator * agg, GstAggregatorPad * pad, GstQuery * decide_query, GstQuery * query)
@@ -1181,6 +1223,7 @@ gst_vfhip_compositor_class_init (GstVfHipCompositorClass * klass)
   ac->aggregate = GST_DEBUG_FUNCPTR (comp_aggregate);
   ac->stop = GST_DEBUG_FUNCPTR (comp_stop);
   ac->flush = GST_DEBUG_FUNCPTR (comp_flush);
+  ac->src_event = GST_DEBUG_FUNCPTR (comp_src_event);
   ac->propose_allocation = GST_DEBUG_FUNCPTR (comp_propose_allocation);
 
   g_object_class_install_property (oc, PROP_BACKGROUND, g_param_spec_enum ("background", "Background", "Background type",

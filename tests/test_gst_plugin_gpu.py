@@ -441,3 +441,25 @@ def test_compositor_skips_obscured_pads(tmp_path):
     assert "obscured by a later opaque pad" in log
     added, log = run("add", True, debug="vfhip:7")
     assert "obscured by a later opaque pad" not in log and not np.array_equal(added, only)
+
+
+def test_compositor_forwards_pointer_events_to_the_pads_under_them(tmp_path):
+    """navigation (mouse) events sent upstream reach the sink pads whose picture is under the pointer, in that input's own
+    pixel coordinates (reference _src_event, gstvfmetalcompositor.m:704-787)"""
+    import os
+    import subprocess
+    exe = tmp_path / "nav_probe"
+    inc = ["-I/opt/conda/include/gstreamer-1.0", "-I/opt/conda/include/glib-2.0", "-I/opt/conda/lib/glib-2.0/include"]
+    lib = ["-L/opt/conda/lib", "-lgstreamer-1.0", "-lgobject-2.0", "-lglib-2.0", "-Wl,-rpath,/opt/conda/lib"]
+    subprocess.check_call(["gcc", "-O1", "-o", str(exe), os.path.join(os.path.dirname(__file__), "nav_probe.c")] + inc + lib)
+
+    def seen(x, y):
+        r = subprocess.run([str(exe), str(x), str(y)], env=gst_env.env(), capture_output=True, text=True, timeout=90)
+        assert r.returncode == 0, r.stderr
+        return {ln.split()[0]: (float(ln.split()[1]), float(ln.split()[2])) for ln in r.stdout.splitlines() if ln and ln[0] in "ab"}
+    # output = bounding box 360 x 240; pad b is 80x120 shown as 160x60 at (200, 100)
+    assert seen(10, 20) == {"a": (10.0, 20.0)}                                   # only the full-size pad
+    both = seen(240, 130)                                                          # inside both pictures
+    assert both["a"] == (240.0, 130.0) and both["b"] == ((240 - 200) * 80 / 160, (130 - 100) * 120 / 60)
+    assert seen(340, 120) == {"b": ((340 - 200) * 80 / 160, (120 - 100) * 120 / 60)}   # right of pad a's 320 columns
+    assert seen(340, 200) == {}                                                   # background only
