@@ -53,6 +53,7 @@ struct VfHipConvertScale {
   PlaneCfg plane[3];
   int n_out_planes = 0;
   bool need_convert = false, need_scale = false;
+  void *nt_tmp = nullptr; size_t nt_tmp_bytes = 0;    // intermediate plane of the two-pass n-tap path (YUV outputs, method=bicubic)
   void *mid = nullptr; size_t mid_bytes = 0; int mid_frames = 0;   // mid_bytes: one intermediate frame; mid holds mid_frames of them
   // K_NTAP (method=bicubic): optional conversion at the input size by a private child handle, then the n-tap passes
   VfHipConvertScale *conv = nullptr;
@@ -76,6 +77,8 @@ static void free_tables (VfHipConvertScale *h)
   }
   if (h->mid) (void) hipFree (h->mid);
   h->mid = nullptr; h->mid_bytes = 0; h->mid_frames = 0;
+  if (h->nt_tmp) (void) hipFree (h->nt_tmp);
+  h->nt_tmp = nullptr; h->nt_tmp_bytes = 0;
   if (h->d_nt_h) (void) hipFree (h->d_nt_h);
   if (h->d_nt_v) (void) hipFree (h->d_nt_v);
   if (h->nt_mid0) (void) hipFree (h->nt_mid0);
@@ -656,6 +659,28 @@ static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
     p.in = (const uint8_t *) mid.data[k]; p.is = mid.stride[k];
     p.out = (uint8_t *) out->data[k]; p.os = out->stride[k];
     p.vec = (((uintptr_t) p.in | (uintptr_t) p.is | (uintptr_t) mid_pitch) & 3) == 0 && getenv ("VFHIP_PLANE_SCALAR") == nullptr;
+    if (pc.vmode == 2 && pc.hmode == 4 && getenv ("VFHIP_PLANE_COMPOSED") == nullptr) {
+      // method=bicubic, both directions: two passes through an intermediate plane (n_v + n_h loads per sample, not n_v x n_h)
+      const int wb_in = pc.n * pc.w, wb_out = pc.n * pc.ow;
+      const size_t ts = ((size_t) (pc.vfirst ? wb_in : wb_out) + 15) / 16 * 16, tbytes = ts * (size_t) (pc.vfirst ? pc.oh : pc.h);
+      if (h->nt_tmp_bytes < tbytes * (size_t) n_frames) {
+        if (h->nt_tmp) (void) hipFree (h->nt_tmp);
+        h->nt_tmp = nullptr; h->nt_tmp_bytes = 0;
+        VFHIP_CHECK_HIP (hipMalloc (&h->nt_tmp, tbytes * (size_t) n_frames));
+        h->nt_tmp_bytes = tbytes * (size_t) n_frames;
+      }
+      PlaneTapParams a {}, b {};
+      a.in = p.in; a.is = p.is; a.in_pitch = mid_pitch; a.out = (uint8_t *) h->nt_tmp; a.os = (int) ts; a.out_pitch = tbytes; a.n = pc.n;
+      b.in = (const uint8_t *) h->nt_tmp; b.is = (int) ts; b.in_pitch = tbytes; b.out = p.out; b.os = p.os; b.out_pitch = out_pitch; b.n = pc.n;
+      a.vec = (((uintptr_t) a.in | (uintptr_t) a.is | (uintptr_t) a.in_pitch) & 3) == 0; b.vec = 1;
+      if (pc.vfirst) { a.wb = wb_in; a.rows = pc.oh; a.tab = pc.d_vnt; a.nt = pc.nv; b.wb = wb_out; b.rows = pc.oh; b.tab = pc.d_hnt; b.nt = pc.nh; }
+      else { a.wb = wb_out; a.rows = pc.h; a.tab = pc.d_hnt; a.nt = pc.nh; b.wb = wb_out; b.rows = pc.oh; b.tab = pc.d_vnt; b.nt = pc.nv; }
+      dim3 ga ((unsigned) ((a.wb + 255) / 256), (unsigned) ((a.rows + 3) / 4), nz), gb ((unsigned) ((b.wb + 255) / 256), (unsigned) ((b.rows + 3) / 4), nz);
+      if (pc.vfirst) { hipLaunchKernelGGL (k_plane_vtap, ga, dim3 (64, 4), 0, s, a); hipLaunchKernelGGL (k_plane_htap, gb, dim3 (64, 4), 0, s, b); }
+      else { hipLaunchKernelGGL (k_plane_htap, ga, dim3 (64, 4), 0, s, a); hipLaunchKernelGGL (k_plane_vtap, gb, dim3 (64, 4), 0, s, b); }
+      VFHIP_CHECK_HIP (hipGetLastError ());
+      continue;
+    }
     // contiguous source bytes (no horizontal pass, or an exact half): 8 output bytes per lane; 2-tap gathers and n-tap tables:
     // 4 bytes per lane, each family in its own small kernel
     const bool twotap = p.vec && pc.vmode <= 1;

@@ -366,6 +366,64 @@ __global__ __launch_bounds__ (256) void k_scale_plane (const PlaneScaleParams p0
   }
 }
 
+// ---- n-tap passes as two kernels through an intermediate plane (method=bicubic on a plane that is scaled both ways): n_v + n_h
+// loads per sample instead of the n_v x n_h of the composed form above.  Same arithmetic: every pass clamp ((sum + 32) >> 6).
+struct PlaneTapParams {
+  const uint8_t *in; int is;
+  uint8_t *out; int os;
+  int wb, rows;            // output row bytes (n * samples) and output rows of THIS pass
+  int n;                   // components per sample (horizontal pass)
+  const int2 *tab; int nt; // out * nt * {source index, 6-bit tap}
+  size_t in_pitch, out_pitch;
+  int vec;                 // source rows 4-byte aligned (vertical pass: dword loads)
+};
+
+__device__ __forceinline__ void store4 (uint8_t *d, uint32_t v, int bx, int wb)
+{
+  if (bx + 3 < wb && ((uintptr_t) d & 3) == 0) *reinterpret_cast<uint32_t *> (d) = v;
+  else for (int k = 0; k < 4 && bx + k < wb; k++) d[k] = (uint8_t) (v >> (8 * k));
+}
+
+__global__ __launch_bounds__ (256) void k_plane_vtap (const PlaneTapParams p)
+{
+  const int bx = 4 * (blockIdx.x * 64 + threadIdx.x), y = blockIdx.y * 4 + threadIdx.y;
+  if (bx >= p.wb || y >= p.rows) return;
+  const uint8_t *in = p.in + (size_t) blockIdx.z * p.in_pitch;
+  int acc[4] = { 32, 32, 32, 32 };
+  const bool wide = p.vec && bx + 3 < p.wb;
+  for (int l = 0; l < p.nt; l++) {
+    const int2 e = p.tab[y * p.nt + l];
+    const uint8_t *row = in + (size_t) e.x * p.is + bx;
+    if (wide) {
+      const uint32_t v = *reinterpret_cast<const uint32_t *> (row);
+#pragma unroll
+      for (int k = 0; k < 4; k++) acc[k] += (int) ((v >> (8 * k)) & 0xff) * e.y;
+    } else {
+      for (int k = 0; k < 4 && bx + k < p.wb; k++) acc[k] += row[k] * e.y;
+    }
+  }
+  uint32_t v = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) v |= (uint32_t) min (max (acc[k] >> 6, 0), 255) << (8 * k);
+  store4 (p.out + (size_t) blockIdx.z * p.out_pitch + (size_t) y * p.os + bx, v, bx, p.wb);
+}
+
+__global__ __launch_bounds__ (256) void k_plane_htap (const PlaneTapParams p)
+{
+  const int bx = 4 * (blockIdx.x * 64 + threadIdx.x), y = blockIdx.y * 4 + threadIdx.y;
+  if (bx >= p.wb || y >= p.rows) return;
+  const uint8_t *row = p.in + (size_t) blockIdx.z * p.in_pitch + (size_t) y * p.is;
+  uint32_t v = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int b = min (bx + k, p.wb - 1), x = p.n == 2 ? b >> 1 : b, c = p.n == 2 ? b & 1 : 0;
+    int acc = 32;
+    for (int l = 0; l < p.nt; l++) { const int2 e = p.tab[x * p.nt + l]; acc += row[e.x * p.n + c] * e.y; }
+    v |= (uint32_t) min (max (acc >> 6, 0), 255) << (8 * k);
+  }
+  store4 (p.out + (size_t) blockIdx.z * p.out_pitch + (size_t) y * p.os + bx, v, bx, p.wb);
+}
+
 // videoscale on a packed 4:2:2 frame: one lane = one output macro-pixel (Y0 U Y1 V in the frame's byte order), the three
 // interleaved lines each with their own tables; pl[0] = luma (step 2), pl[1] = U, pl[2] = V (step 4)
 struct PackedScaleParams { PlaneScaleParams pl[3]; int yo, uo, vo; };

@@ -579,3 +579,19 @@ def test_gst_exact_letterbox(vfhip, oracle, ifmt, ofmt, w, h, ow, oh, method):
     mask = np.ones((oh, ow), bool)
     mask[ry:ry + rh, rx:rx + rw] = False
     assert (got[mask] == colour).all() and (rw < ow or rh < oh or not mask.any())
+
+
+def test_bicubic_yuv_composed_and_two_pass_forms_agree(vfhip, oracle, monkeypatch):
+    """method=bicubic on planes runs as two kernels through an intermediate plane; the composed one-kernel form (kept for packed
+    frames and mixed 2-tap / n-tap planes, forced here) gives the same bytes"""
+    rng = np.random.default_rng(29)
+    cases = [("NV12", "NV12", 200, 120, 96, 50), ("I420", "I420", 96, 54, 200, 120), ("BGRA", "NV12", 121, 77, 64, 90), ("NV12", "I420", 130, 200, 90, 60)]
+    for composed in (False, True):
+        if composed:
+            monkeypatch.setenv("VFHIP_PLANE_COMPOSED", "1")
+        for (ifmt, ofmt, w, h, ow, oh) in cases:
+            raw = np.random.default_rng(w).integers(0, 256, oracle_lib.raw_layout(ifmt, w, h)[1], dtype=np.uint8)
+            got, _ = run(vfhip, ifmt, w, h, raw, "bt709", "mpeg2", "bicubic", ofmt, ow, oh)
+            want = oracle.convertscale(ifmt, w, h, raw, "bt709", "mpeg2", "bicubic", ofmt, ow, oh)
+            assert np.array_equal(meaningful(ofmt, ow, oh, got), meaningful(ofmt, ow, oh, want)), (composed, ifmt, ofmt)
+    del rng

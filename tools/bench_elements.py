@@ -174,7 +174,8 @@ def staged():
                                                ("I420", 1920, 1080, "I420", 1280, 720, "bilinear"), ("BGRA", 1920, 1080, "NV12", 1920, 1080, "bilinear"),
                                                ("BGRA", 1920, 1080, "I420", 1280, 720, "bilinear"), ("NV12", 1920, 1080, "UYVY", 1920, 1080, "bilinear"),
                                                ("UYVY", 1920, 1080, "NV12", 1920, 1080, "bilinear"), ("UYVY", 1920, 1080, "UYVY", 1280, 720, "bilinear"),
-                                               ("NV12", 3840, 2160, "NV12", 1920, 1080, "nearest")]:
+                                               ("NV12", 3840, 2160, "NV12", 1920, 1080, "nearest"), ("NV12", 1920, 1080, "NV12", 1280, 720, "bicubic"),
+                                               ("NV12", 3840, 2160, "NV12", 1920, 1080, "bicubic")]:
         isz, osz = vfhip.plane_layout(ifmt, w, h)[1], vfhip.plane_layout(ofmt, ow, oh)[1]
         N = max(16, int(1.2e9 // (isz + osz)))                     # > 1 GB per launch: several times the 256 MB infinity cache
         ip, op = (isz + 255) // 256 * 256, (osz + 255) // 256 * 256
