@@ -647,6 +647,7 @@ static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
       q.pl[k].out = (uint8_t *) out->data[0]; q.pl[k].os = out->stride[0];
     }
     q.yo = h->plane[0].off; q.uo = h->plane[1].off; q.vo = h->plane[2].off;
+    q.fast = h->plane[0].hmode == 3 && h->plane[1].hmode == 3 && h->plane[2].hmode == 3 && h->plane[0].vmode <= 1 && getenv ("VFHIP_PLANE_SCALAR") == nullptr;
     dim3 grid ((unsigned) ((h->plane[1].ow + 63) / 64), (unsigned) ((h->plane[0].oh + 3) / 4), nz);
     hipLaunchKernelGGL (k_scale_packed422, grid, dim3 (64, 4), 0, s, q);
     VFHIP_CHECK_HIP (hipGetLastError ());

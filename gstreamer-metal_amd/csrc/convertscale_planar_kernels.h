@@ -201,8 +201,8 @@ __device__ __forceinline__ int hpass (const PlaneScaleParams &p, int x, At at)
     }
     case 2: return (at (2 * x) + at (2 * x + 1) + 1) >> 1;      // exactly halved (1 x u8)
     case 3: case 5: {                                // 2-tap, centre-aligned 6-bit table (also nearest: second tap 0); 5 = the table is (2k, 2k+1, 32)
-      const int i0 = p.htab[4 * x], i1 = p.htab[4 * x + 1], t = p.htab[4 * x + 2];
-      return (at (i0) * (64 - t) + at (i1) * t + 32) >> 6;
+      const int4 e = reinterpret_cast<const int4 *> (p.htab)[x];          // one 16-byte load per table entry
+      return (at (e.x) * (64 - e.z) + at (e.y) * e.z + 32) >> 6;
     }
     case 6: return at (p.htab[4 * x]);               // nearest: one source column
     default: {                                       // n taps, 6-bit (catrom; un-limited linear)
@@ -219,9 +219,9 @@ __device__ __forceinline__ int vpass (const PlaneScaleParams &p, int y, At at)
   switch (p.vmode) {
     case 0: return at (y);
     case 1: {                                        // 2-tap, 8-bit: only the second tap is used
-      const int i0 = p.vtab[4 * y], i1 = p.vtab[4 * y + 1], wt = p.vtab[4 * y + 2];
-      const int a = at (i0), b = at (i1);
-      return a + (((b - a) * wt + 128) >> 8);
+      const int4 e = reinterpret_cast<const int4 *> (p.vtab)[y];
+      const int a = at (e.x), b = at (e.y);
+      return a + (((b - a) * e.z + 128) >> 8);
     }
     case 3: return at (p.vtab[4 * y]);               // nearest: one source row
     default: {
@@ -426,7 +426,7 @@ __global__ __launch_bounds__ (256) void k_plane_htap (const PlaneTapParams p)
 
 // videoscale on a packed 4:2:2 frame: one lane = one output macro-pixel (Y0 U Y1 V in the frame's byte order), the three
 // interleaved lines each with their own tables; pl[0] = luma (step 2), pl[1] = U, pl[2] = V (step 4)
-struct PackedScaleParams { PlaneScaleParams pl[3]; int yo, uo, vo; };
+struct PackedScaleParams { PlaneScaleParams pl[3]; int yo, uo, vo; int fast; };   // fast: every line 2-tap-table scaled horizontally, <= 2 taps vertically
 
 __global__ __launch_bounds__ (256) void k_scale_packed422 (const PackedScaleParams q)
 {
@@ -434,10 +434,49 @@ __global__ __launch_bounds__ (256) void k_scale_packed422 (const PackedScalePara
   if (k >= q.pl[1].ow || y >= q.pl[0].oh) return;
   const size_t fin = (size_t) blockIdx.z * q.pl[0].in_pitch, fout = (size_t) blockIdx.z * q.pl[0].out_pitch;
   // (constant indices only: a dynamically indexed parameter struct or byte array ends up in scratch memory)
-  const uint32_t Y0 = (uint32_t) plane_sample (q.pl[0], q.pl[0].in + fin, 2 * k, y, 0);
-  const uint32_t Y1 = 2 * k + 1 < q.pl[0].ow ? (uint32_t) plane_sample (q.pl[0], q.pl[0].in + fin, 2 * k + 1, y, 0) : Y0;   // spare slot of an odd width
-  const uint32_t U = (uint32_t) plane_sample (q.pl[1], q.pl[1].in + fin, k, y, 0);
-  const uint32_t V = (uint32_t) plane_sample (q.pl[2], q.pl[2].in + fin, k, y, 0);
+  uint32_t Y0, Y1, U, V;
+  if (q.fast) {
+    // 2-tap tables both ways: the two taps of a luma sample lie in ONE 4-byte window of the row, the U and V taps of a chroma
+    // sample in ONE 8-byte window (two neighbouring macro-pixels) -> 6 loads per output macro-pixel instead of 16
+    const PlaneScaleParams &py = q.pl[0];
+    int r0i = y, r1i = y, wt = 0;
+    if (py.vmode == 1) { const int4 e = reinterpret_cast<const int4 *> (py.vtab)[y]; r0i = e.x; r1i = e.y; wt = e.z; }
+    const uint8_t *base = py.in - q.yo + fin;                          // first byte of the frame's rows (pl[0].in points at the first luma byte)
+    const uint8_t *r0 = base + (size_t) r0i * py.is, *r1 = base + (size_t) r1i * py.is;
+    const bool vf = py.vfirst != 0, vs = py.vmode == 1;
+    auto mix = [&] (int a0, int a1, int b0, int b1, int t) {           // a = taps in row r0, b = in row r1
+      if (!vs) return (a0 * (64 - t) + a1 * t + 32) >> 6;
+      if (vf) { const int l = a0 + (((b0 - a0) * wt + 128) >> 8), m = a1 + (((b1 - a1) * wt + 128) >> 8); return (l * (64 - t) + m * t + 32) >> 6; }
+      const int l = (a0 * (64 - t) + a1 * t + 32) >> 6, m = (b0 * (64 - t) + b1 * t + 32) >> 6;
+      return l + (((m - l) * wt + 128) >> 8);
+    };
+    auto luma = [&] (int x) -> uint32_t {
+      const int4 e = reinterpret_cast<const int4 *> (py.htab)[x];
+      if (e.y != e.x + 1) return (uint32_t) plane_sample (py, py.in + fin, x, y, 0);      // clamped at the row end
+      uint32_t a, b;
+      __builtin_memcpy (&a, r0 + 2 * e.x, 4); __builtin_memcpy (&b, r1 + 2 * e.x, 4);
+      const int sh = 8 * q.yo;
+      return (uint32_t) mix ((a >> sh) & 0xff, (a >> (sh + 16)) & 0xff, (b >> sh) & 0xff, (b >> (sh + 16)) & 0xff, e.z);
+    };
+    Y0 = luma (2 * k);
+    Y1 = 2 * k + 1 < py.ow ? luma (2 * k + 1) : Y0;                    // spare slot of an odd width
+    const int4 e = reinterpret_cast<const int4 *> (q.pl[1].htab)[k];
+    if (e.y != e.x + 1) {
+      U = (uint32_t) plane_sample (q.pl[1], q.pl[1].in + fin, k, y, 0);
+      V = (uint32_t) plane_sample (q.pl[2], q.pl[2].in + fin, k, y, 0);
+    } else {
+      uint2 a, b;
+      __builtin_memcpy (&a, r0 + 4 * e.x, 8); __builtin_memcpy (&b, r1 + 4 * e.x, 8);
+      const int su = 8 * q.uo, sv = 8 * q.vo;
+      U = (uint32_t) mix ((a.x >> su) & 0xff, (a.y >> su) & 0xff, (b.x >> su) & 0xff, (b.y >> su) & 0xff, e.z);
+      V = (uint32_t) mix ((a.x >> sv) & 0xff, (a.y >> sv) & 0xff, (b.x >> sv) & 0xff, (b.y >> sv) & 0xff, e.z);
+    }
+  } else {
+    Y0 = (uint32_t) plane_sample (q.pl[0], q.pl[0].in + fin, 2 * k, y, 0);
+    Y1 = 2 * k + 1 < q.pl[0].ow ? (uint32_t) plane_sample (q.pl[0], q.pl[0].in + fin, 2 * k + 1, y, 0) : Y0;   // spare slot of an odd width
+    U = (uint32_t) plane_sample (q.pl[1], q.pl[1].in + fin, k, y, 0);
+    V = (uint32_t) plane_sample (q.pl[2], q.pl[2].in + fin, k, y, 0);
+  }
   uint8_t *d = q.pl[0].out + fout + (size_t) y * q.pl[0].os + 4 * k;
   const uint32_t v = q.yo == 0 ? (Y0 | U << 8 | Y1 << 16 | V << 24) : (U | Y0 << 8 | V << 16 | Y1 << 24);
   if (((uintptr_t) d & 3) == 0) *reinterpret_cast<uint32_t *> (d) = v;
