@@ -535,15 +535,16 @@ struct ToPackedParams {
   int c[9];                // RGB -> YUV matrix (RGB inputs)
 };
 
-// one lane = one macro-pixel (two luma samples + U + V) of the packed output
-__global__ __launch_bounds__ (256) void k_to_packed422 (const ToPackedParams p0)
+__device__ __forceinline__ uint32_t pack_macro (int yuy2, int Y0, int Y1, int U, int V)
 {
-  ToPackedParams p = p0;
-  for (int t = 0; t < 3; t++) if (p.in[t]) p.in[t] += (size_t) blockIdx.z * p.in_pitch;
-  p.out += (size_t) blockIdx.z * p.out_pitch;
-  const int k = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  return yuy2 ? (uint32_t) Y0 | (uint32_t) U << 8 | (uint32_t) Y1 << 16 | (uint32_t) V << 24
+              : (uint32_t) U | (uint32_t) Y0 << 8 | (uint32_t) V << 16 | (uint32_t) Y1 << 24;
+}
+
+// macro-pixel k of row y (two luma samples + U + V) of the packed output; p's pointers already at the frame
+__device__ __forceinline__ uint32_t to_packed_one (const ToPackedParams &p, int k, int y)
+{
   const int cw = (p.w + 1) >> 1;
-  if (k >= cw || y >= p.h) return;
   const int x = 2 * k, x1 = min (x + 1, p.w - 1);
   int Y0, Y1, U, V;
   switch (p.in_fmt) {
@@ -611,11 +612,24 @@ __global__ __launch_bounds__ (256) void k_to_packed422 (const ToPackedParams p0)
       break;
     }
   }
-  uint8_t *d = p.out + (size_t) y * p.os + 4 * k;
-  const uint32_t v = p.out_yuy2 ? (uint32_t) Y0 | (uint32_t) U << 8 | (uint32_t) Y1 << 16 | (uint32_t) V << 24
-                                : (uint32_t) U | (uint32_t) Y0 << 8 | (uint32_t) V << 16 | (uint32_t) Y1 << 24;
+  return pack_macro (p.out_yuy2, Y0, Y1, U, V);
+}
+
+__device__ __forceinline__ void store_macro (uint8_t *d, uint32_t v)
+{
   if (((uintptr_t) d & 3) == 0) *reinterpret_cast<uint32_t *> (d) = v;
   else { d[0] = (uint8_t) v; d[1] = (uint8_t) (v >> 8); d[2] = (uint8_t) (v >> 16); d[3] = (uint8_t) (v >> 24); }
+}
+
+// one lane = one macro-pixel
+__global__ __launch_bounds__ (256) void k_to_packed422 (const ToPackedParams p0)
+{
+  ToPackedParams p = p0;
+  for (int t = 0; t < 3; t++) if (p.in[t]) p.in[t] += (size_t) blockIdx.z * p.in_pitch;
+  p.out += (size_t) blockIdx.z * p.out_pitch;
+  const int k = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (k >= ((p.w + 1) >> 1) || y >= p.h) return;
+  store_macro (p.out + (size_t) y * p.os + 4 * k, to_packed_one (p, k, y));
 }
 
 struct FromPackedParams {
