@@ -595,3 +595,16 @@ def test_bicubic_yuv_composed_and_two_pass_forms_agree(vfhip, oracle, monkeypatc
             want = oracle.convertscale(ifmt, w, h, raw, "bt709", "mpeg2", "bicubic", ofmt, ow, oh)
             assert np.array_equal(meaningful(ofmt, ow, oh, got), meaningful(ofmt, ow, oh, want)), (composed, ifmt, ofmt)
     del rng
+
+
+@pytest.mark.parametrize("ifmt,ofmt,ow,oh", [("NV12", "BGRA", 3840, 2160), ("NV12", "NV12", 3840, 2160), ("I420", "RGBA", 2731, 1537)])
+def test_8k_frames(vfhip, oracle, ifmt, ofmt, ow, oh):
+    """7680 x 4320 inputs (the largest size the reference's caps template allows is 8192): index arithmetic and grids at 8K"""
+    w, h = 7680, 4320
+    raw = np.random.default_rng(8).integers(0, 256, oracle_lib.raw_layout(ifmt, w, h)[1], dtype=np.uint8)
+    got, _ = run(vfhip, ifmt, w, h, raw, "bt2020", "mpeg2", "bilinear", ofmt, ow, oh)
+    want = oracle.convertscale(ifmt, w, h, raw, "bt2020", "mpeg2", "bilinear", ofmt, ow, oh)
+    if ofmt in ("BGRA", "RGBA"):
+        assert np.array_equal(got, want)
+    else:
+        assert np.array_equal(meaningful(ofmt, ow, oh, got), meaningful(ofmt, ow, oh, want))
