@@ -148,6 +148,15 @@ struct HalfCtx {
   uint32_t wgt[4];
 };
 
+// 16 output bytes that nothing in the kernel reads again: a non-temporal store (measured on the headline config, three
+// interleaved A/B rounds on one box: 235.0 -> 237.6 k frames/s; non-temporal LOADS on top changed nothing)
+__device__ __forceinline__ void store_stream16 (uint8_t *dst, const uint32_t v[4])
+{
+  typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
+  const v4u q = { v[0], v[1], v[2], v[3] };
+  __builtin_nontemporal_store (q, reinterpret_cast<v4u *> (dst));
+}
+
 // One output row `y` of one lane (4 output pixels).  In: chroma state (hc = h-filtered chroma row y, mid_up = floor
 // average of rows y-1 and y) and the prefetched raw rows of THIS row.  Out: the state for row y+1 and the prefetch of
 // row y+1 (issued before this row's arithmetic: register double buffer).  Called twice per loop trip with the two
@@ -190,7 +199,7 @@ __device__ __forceinline__ void half_row (const HalfCtx &k, int y, const CRow &h
     const uint32_t lo = RGBA ? perm_b32 (hg, hr, 0x0c0c0501u) : perm_b32 (hg, hb, 0x0c0c0501u);      // [X>>8, G>>8, -, -]
     out[n] = perm_b32 (RGBA ? hb : hr, lo, 0x0d050100u);                                               // [X, G, Z, 0xff]
   }
-  *reinterpret_cast<uint4 *> (k.op + (__umul24 ((uint32_t) y, k.os) + 2u * k.cx)) = make_uint4 (out[0], out[1], out[2], out[3]);
+  store_stream16 (k.op + (__umul24 ((uint32_t) y, k.os) + 2u * k.cx), out);
 }
 
 // grid: 1-D, ceil(cgpr * strips / 256) blocks of 256 lanes per frame, frames back to back (cgpr = out_w / 4 column
@@ -314,7 +323,7 @@ __global__ __launch_bounds__ (256, 8) void k_cs_i420_half (const CsParams p)
       const uint32_t lo = RGBA ? perm_b32 (hg, hr, 0x0c0c0501u) : perm_b32 (hg, hb, 0x0c0c0501u);
       out[n] = perm_b32 (RGBA ? hb : hr, lo, 0x0d050100u);
     }
-    *reinterpret_cast<uint4 *> (op + (__umul24 ((uint32_t) y, os) + 2u * cx)) = make_uint4 (out[0], out[1], out[2], out[3]);
+    store_stream16 (op + (__umul24 ((uint32_t) y, os) + 2u * cx), out);
     yt = nyt; yb = nyb; u4 = nu4; v4 = nv4;
   }
 }
