@@ -212,7 +212,13 @@ __device__ __forceinline__ void store_block (const OutImg &o, int bx, int by, co
         }
         // the pair goes out as ONE 8-byte store when the address allows: a dword store per pixel leaves every store
         // instruction half-coalesced (lane stride 8 bytes)
-        if (x0 + 1 < o.w && ((reinterpret_cast<uintptr_t> (row) & 7) == 0)) *reinterpret_cast<uint2 *> (row + x0) = make_uint2 (v0, v1);
+        // ... and non-temporal: the frame is not read again, and keeping it out of L2 leaves the inputs (compositor pads, the
+        // filter's LUT) there — A/B on one box: C4 43.7 k -> 48.2 k frames/s, C3 15.0 k -> 16.3 k
+        if (x0 + 1 < o.w && ((reinterpret_cast<uintptr_t> (row) & 7) == 0)) {
+          typedef uint32_t v2u __attribute__ ((ext_vector_type (2)));
+          const v2u pair = { v0, v1 };
+          __builtin_nontemporal_store (pair, reinterpret_cast<v2u *> (row + x0));
+        }
         else { row[x0] = v0; if (x0 + 1 < o.w) row[x0 + 1] = v1; }
       }
       return;
@@ -235,7 +241,7 @@ __device__ __forceinline__ void store_block (const OutImg &o, int bx, int by, co
       for (int dy = 0; dy < 2; dy++) {
         if (y0 + dy >= o.h) break;
         uint8_t *d = o.p[0] + (size_t) (y0 + dy) * o.s[0] + x0;
-        if (x0 + 1 < o.w && !((uintptr_t) d & 1)) *reinterpret_cast<uint16_t *> (d) = (uint16_t) (yq[dy][0] | (yq[dy][1] << 8));
+        if (x0 + 1 < o.w && !((uintptr_t) d & 1)) __builtin_nontemporal_store ((uint16_t) (yq[dy][0] | (yq[dy][1] << 8)), reinterpret_cast<uint16_t *> (d));   // non-temporal like the RGB pairs (C5: +4 %)
         else { d[0] = (uint8_t) yq[dy][0]; if (x0 + 1 < o.w) d[1] = (uint8_t) yq[dy][1]; }
       }
       sr *= 0.25f; sg *= 0.25f; sb *= 0.25f;
@@ -243,7 +249,7 @@ __device__ __forceinline__ void store_block (const OutImg &o, int bx, int by, co
       if (o.fmt == VFHIP_FORMAT_NV12) {
         uint8_t *d = o.p[1] + (size_t) by * o.s[1] + 2 * bx;
         const uint32_t U = quant8 (u), V = quant8 (v);
-        if (!((uintptr_t) d & 1)) *reinterpret_cast<uint16_t *> (d) = (uint16_t) (U | (V << 8));
+        if (!((uintptr_t) d & 1)) __builtin_nontemporal_store ((uint16_t) (U | (V << 8)), reinterpret_cast<uint16_t *> (d));
         else { d[0] = (uint8_t) U; d[1] = (uint8_t) V; }
       } else {
         o.p[1][(size_t) by * o.s[1] + bx] = (uint8_t) quant8 (u);
