@@ -224,6 +224,7 @@ int vfhip_compositor_configure (VfHipCompositor *h, const VfHipVideoInfo *out)
 {
   if (!h || !out) return set_error (VFHIP_ERR_INVALID, "null argument");
   std::lock_guard<std::mutex> lk (h->mu);
+  if (h->fl.count) return set_error (VFHIP_ERR_INVALID, "configure with %d submitted composite(s) still in flight: wait for them first", h->fl.count);
   if (out->width <= 0 || out->height <= 0 || out->width > 32768 || out->height > 32768)
     return set_error (VFHIP_ERR_INVALID, "bad output size %dx%d", out->width, out->height);
   if (out->format < VFHIP_FORMAT_BGRA || out->format > VFHIP_FORMAT_I420)

@@ -850,11 +850,14 @@ comp_fixate_src_caps (GstAggregator * agg, GstCaps * caps)
   return gst_caps_fixate (caps);
 }
 
+static GstFlowReturn comp_finish_pending (GstVfHipCompositor * self, gboolean push);
+
 static gboolean
 comp_negotiated_src_caps (GstAggregator * agg, GstCaps * caps)
 {
   GstVfHipCompositor *self = COMP (agg);
   VfHipVideoInfo out;
+  (void) comp_finish_pending (self, TRUE);                 /* a renegotiation mid-stream: the composite in flight belongs to the old caps */
   if (!gst_video_info_from_caps (&self->out_info, caps))
     return FALSE;
   self->have_out_info = TRUE;
