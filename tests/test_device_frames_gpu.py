@@ -360,3 +360,37 @@ def test_compositor_submit_wait_pipeline(vfhip):
     # cleanup with a frame still in flight must not crash
     vfhip.check(lib.vfhip_compositor_submit(comp.h, keep[0][0], 2, 0, C.byref(keep[0][1])))
     comp.close()
+
+
+def test_compositor_pipelined_with_more_pads_than_one_pass_takes(vfhip):
+    """20 pads (> 16 per kernel pass: the passes chain through the handle's two scratch targets) submitted two deep: the
+    scratch targets are shared by the composites in flight and must be reused in stream order"""
+    w, h, n, npads = 128, 72, 4, 20
+    rng = np.random.default_rng(9)
+    lib = vfhip.lib
+    comp = vfhip.Compositor(0).configure("NV12", w, h, colorimetry="bt709")
+    frames = [[rng.integers(0, 256, vfhip.plane_layout("BGRA", 24, 16)[1], dtype=np.uint8) for _ in range(npads)] for _ in range(n)]
+
+    def pads(k):
+        return [("BGRA", 24, 16, frames[k][i], (i * 11) % 100, (i * 7 + k) % 50, 30, 20, 0.4 + 0.03 * i, ["over", "add", "source"][i % 3], "bt709") for i in range(npads)]
+    want = [comp.composite(pads(k), background="white") for k in range(n)]
+    size = vfhip.plane_layout("NV12", w, h)[1]
+    outs = [np.zeros(size, np.uint8) for _ in range(n)]
+    keep, done = [], 0
+    for k in range(n):
+        arr = (vfhip.PadInput * npads)()
+        for i, p in enumerate(pads(k)):
+            arr[i] = vfhip.Compositor.pad(p[0], p[1], p[2], p[3].ctypes.data, *p[4:])
+        fo = vfhip.frame_from_base(comp.info, "NV12", w, h, outs[k].ctypes.data)
+        keep.append((arr, fo))
+        vfhip.check(lib.vfhip_compositor_submit(comp.h, arr, npads, vfhip.BACKGROUNDS["white"], C.byref(fo)))
+        if lib.vfhip_compositor_in_flight(comp.h) == 2:
+            vfhip.check(lib.vfhip_compositor_wait(comp.h))
+            assert np.array_equal(outs[done], want[done]), f"frame {done}"
+            done += 1
+    while lib.vfhip_compositor_in_flight(comp.h):
+        vfhip.check(lib.vfhip_compositor_wait(comp.h))
+        assert np.array_equal(outs[done], want[done]), f"frame {done}"
+        done += 1
+    assert done == n
+    comp.close()
