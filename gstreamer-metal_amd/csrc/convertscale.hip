@@ -53,6 +53,7 @@ struct VfHipConvertScale {
   PlaneCfg plane[3];
   int n_out_planes = 0;
   bool need_convert = false, need_scale = false;
+  bool lb = false;                                    // staged path with borders: the planes are written through a sub-rectangle view
   void *nt_tmp = nullptr; size_t nt_tmp_bytes = 0;    // intermediate plane of the two-pass n-tap path (YUV outputs, method=bicubic)
   void *mid = nullptr; size_t mid_bytes = 0; int mid_frames = 0;   // mid_bytes: one intermediate frame; mid holds mid_frames of them
   // K_NTAP (method=bicubic): optional conversion at the input size by a private child handle, then the n-tap passes
@@ -366,7 +367,7 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
   if (in->color_matrix < 0 || in->color_matrix > 2 || out->color_matrix < 0 || out->color_matrix > 2)
     return set_error (VFHIP_ERR_INVALID, "bad colour matrix");
   VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
-  h->configured = false;
+  h->configured = false; h->lb = false;
   free_tables (h);
   h->in = *in; h->out = *out; h->method = method; h->add_borders = add_borders ? 1 : 0;
   h->border_color = border_color; h->numerics = numerics;
@@ -385,9 +386,14 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
   // packed frame scaled horizontally (GStreamer 1.14 emits out-of-line garbage for it) -> metal arithmetic
   const bool out_packed = out->format == VFHIP_FORMAT_UYVY || out->format == VFHIP_FORMAT_YUY2;
   const bool any_yuv_in = in_yuv || in_packed;
-  const bool staged = numerics == VFHIP_NUMERICS_GST_EXACT && !h->add_borders &&
+  // add-borders with a YUV output: the reference's centred rectangle (compute_rect) receives exactly what the two-step path
+  // gives at the rectangle's size, the rest is the border colour through the RGB -> YUV matrix — when the rectangle sits on
+  // chroma-sample boundaries (even x / width; even y / height as well for 4:2:0); otherwise metal arithmetic
+  const bool lb = h->add_borders && (h->rw != out->width || h->rh != out->height);
+  const bool lb_ok = !lb || (!((h->rx | h->rw) & 1) && (out_packed || !((h->ry | h->rh) & 1)));
+  const bool staged = numerics == VFHIP_NUMERICS_GST_EXACT && lb_ok &&
                       ((in_420_or_rgb && out_420) || out_packed || (in_packed && out_420)) &&
-                      !(out_packed && in->width == 2 && out->width != 2) &&
+                      !(out_packed && in->width == 2 && h->rw != 2) &&
                       (!any_yuv_in || (in->color_matrix == out->color_matrix && in->chroma_site == out->chroma_site));
   if (method == VFHIP_SCALE_BICUBIC && !staged) {
     const int iw = in->width, ih = in->height, ow = out->width, oh = out->height;
@@ -431,7 +437,8 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
     return VFHIP_OK;
   }
   if (staged) {
-    const int iw = in->width, ih = in->height, ow = out->width, oh = out->height;
+    const int iw = in->width, ih = in->height, ow = h->rw, oh = h->rh;      // the destination rectangle (= the frame without borders)
+    h->lb = lb;
     h->need_convert = in->format != out->format;
     h->need_scale = iw != ow || ih != oh;
     h->n_out_planes = out->format == VFHIP_FORMAT_NV12 ? 2 : 3;
@@ -543,6 +550,27 @@ static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
   const int iw = h->in.width, ih = h->in.height;
   const bool out_planar = h->out.format == VFHIP_FORMAT_I420;
   const bool out_packed = h->out.format == VFHIP_FORMAT_UYVY || h->out.format == VFHIP_FORMAT_YUY2;
+  VfHipFrame view = *out;
+  if (h->lb) {
+    // borders first (every sample outside the rectangle), then the two-step path writes the rectangle through a view of the frame
+    BorderFillParams b {};
+    const uint32_t argb = h->border_color;
+    const int r = (argb >> 16) & 0xff, g = (argb >> 8) & 0xff, bl = argb & 0xff;
+    const int *c = kRgb2Yuv[h->out.color_matrix];
+    b.yuv[0] = ((c[0] * r + c[1] * g + c[2] * bl) >> 8) + 16; b.yuv[1] = ((c[3] * r + c[4] * g + c[5] * bl) >> 8) + 128; b.yuv[2] = ((c[6] * r + c[7] * g + c[8] * bl) >> 8) + 128;
+    for (int k = 0; k < 3; k++) { b.p[k] = (uint8_t *) out->data[k]; b.s[k] = out->stride[k]; }
+    b.fmt = h->out.format; b.w = h->out.width; b.h = h->out.height; b.rx = h->rx; b.ry = h->ry; b.rw = h->rw; b.rh = h->rh; b.pitch = out_pitch;
+    dim3 grid ((unsigned) (((h->out.width + 1) / 2 + 63) / 64), (unsigned) ((h->out.height + 3) / 4), (unsigned) n_frames);
+    hipLaunchKernelGGL (k_border_fill_yuv, grid, dim3 (64, 4), 0, s, b);
+    VFHIP_CHECK_HIP (hipGetLastError ());
+    if (out_packed) view.data[0] = (uint8_t *) out->data[0] + (size_t) h->ry * out->stride[0] + 2 * h->rx;
+    else {
+      view.data[0] = (uint8_t *) out->data[0] + (size_t) h->ry * out->stride[0] + h->rx;
+      view.data[1] = (uint8_t *) out->data[1] + (size_t) (h->ry / 2) * out->stride[1] + (out_planar ? h->rx / 2 : h->rx);
+      if (out_planar) view.data[2] = (uint8_t *) out->data[2] + (size_t) (h->ry / 2) * out->stride[2] + h->rx / 2;
+    }
+    out = &view;
+  }
   const bool in_packed = h->in.format == VFHIP_FORMAT_UYVY || h->in.format == VFHIP_FORMAT_YUY2;
   const unsigned nz = (unsigned) n_frames;
   // where stage 1 writes / stage 2 reads: the output itself (no scaling), the input itself (no conversion), or `mid`

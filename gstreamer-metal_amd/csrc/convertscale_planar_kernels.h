@@ -424,6 +424,35 @@ __global__ __launch_bounds__ (256) void k_plane_htap (const PlaneTapParams p)
   store4 (p.out + (size_t) blockIdx.z * p.out_pitch + (size_t) y * p.os + bx, v, bx, p.wb);
 }
 
+// add-borders with a YUV output: every sample OUTSIDE the destination rectangle gets the border colour (already through the
+// RGB -> YUV matrix).  One lane = one column pair (x, x+1) of one row; the rectangle sits on chroma-sample boundaries.
+struct BorderFillParams {
+  uint8_t *p[3]; int s[3];
+  int fmt, w, h, rx, ry, rw, rh;
+  int yuv[3];
+  size_t pitch;
+};
+
+__global__ __launch_bounds__ (256) void k_border_fill_yuv (const BorderFillParams p)
+{
+  const int k = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y, x = 2 * k;
+  if (x >= p.w || y >= p.h) return;
+  if (x >= p.rx && x < p.rx + p.rw && y >= p.ry && y < p.ry + p.rh) return;       // (x even, rx / rw even: the pair is in or out as one)
+  const size_t f = (size_t) blockIdx.z * p.pitch;
+  const uint8_t Y = (uint8_t) p.yuv[0], U = (uint8_t) p.yuv[1], V = (uint8_t) p.yuv[2];
+  if (p.fmt == VFHIP_FORMAT_UYVY || p.fmt == VFHIP_FORMAT_YUY2) {
+    uint8_t *d = p.p[0] + f + (size_t) y * p.s[0] + 4 * k;
+    if (p.fmt == VFHIP_FORMAT_YUY2) { d[0] = Y; d[1] = U; d[2] = Y; d[3] = V; } else { d[0] = U; d[1] = Y; d[2] = V; d[3] = Y; }
+    return;
+  }
+  uint8_t *d = p.p[0] + f + (size_t) y * p.s[0] + x;
+  d[0] = Y; if (x + 1 < p.w) d[1] = Y;
+  if (!(y & 1)) {                                            // the chroma sample of this 2x2 block (ry / rh even: in or out as one)
+    if (p.fmt == VFHIP_FORMAT_NV12) { uint8_t *c = p.p[1] + f + (size_t) (y >> 1) * p.s[1] + 2 * k; c[0] = U; c[1] = V; }
+    else { p.p[1][f + (size_t) (y >> 1) * p.s[1] + k] = U; p.p[2][f + (size_t) (y >> 1) * p.s[2] + k] = V; }
+  }
+}
+
 // videoscale on a packed 4:2:2 frame: one lane = one output macro-pixel (Y0 U Y1 V in the frame's byte order), the three
 // interleaved lines each with their own tables; pl[0] = luma (step 2), pl[1] = U, pl[2] = V (step 4)
 struct PackedScaleParams { PlaneScaleParams pl[3]; int yo, uo, vo; int fast; };   // fast: every line 2-tap-table scaled horizontally, <= 2 taps vertically

@@ -239,7 +239,7 @@ def test_golden_gstreamer_vectors_bicubic(vfhip, case, tile, monkeypatch):
 
 def test_bicubic_outside_the_pinned_domain_is_refused(vfhip):
     cs = vfhip.ConvertScale(0)
-    for (w, h, ow, oh, ofmt, kw) in [(3, 3, 7, 5, "BGRA", {}), (16, 16, 1, 1, "BGRA", {}), (6, 36, 3, 18, "NV12", {}), (64, 36, 32, 18, "NV12", dict(add_borders=True)),
+    for (w, h, ow, oh, ofmt, kw) in [(3, 3, 7, 5, "BGRA", {}), (16, 16, 1, 1, "BGRA", {}), (6, 36, 3, 18, "NV12", {}), (64, 36, 33, 33, "NV12", dict(add_borders=True)),
                                      (64, 36, 32, 18, "BGRA", dict(numerics="metal")),
                                      (64, 36, 32, 18, "BGRA", dict(add_borders=True))]:
         with pytest.raises(vfhip.VfHipError) as e:
@@ -608,3 +608,76 @@ def test_8k_frames(vfhip, oracle, ifmt, ofmt, ow, oh):
         assert np.array_equal(got, want)
     else:
         assert np.array_equal(meaningful(ofmt, ow, oh, got), meaningful(ofmt, ow, oh, want))
+
+
+@pytest.mark.parametrize("ifmt,ofmt,w,h,ow,oh,method", [("NV12", "NV12", 64, 36, 64, 64, "bilinear"), ("BGRA", "I420", 36, 64, 64, 64, "bilinear"), ("I420", "UYVY", 64, 16, 32, 31, "nearest"),
+                                                        ("UYVY", "NV12", 128, 72, 64, 64, "bilinear"), ("NV12", "YUY2", 96, 54, 64, 64, "bicubic"), ("RGBA", "NV12", 40, 30, 64, 64, "bilinear")])
+def test_gst_exact_letterbox_yuv_outputs(vfhip, oracle, ifmt, ofmt, w, h, ow, oh, method):
+    """add-borders with gst-exact numerics and a YUV output: the reference's centred rectangle holds exactly what the two-step
+    path gives at the rectangle's size, every other sample is the border colour through the RGB -> YUV matrix (rectangles on
+    chroma-sample boundaries; others run the metal arithmetic)"""
+    import math
+    raw = np.random.default_rng(ow + oh).integers(0, 256, vfhip.plane_layout(ifmt, w, h)[1], dtype=np.uint8)
+    cs = vfhip.ConvertScale(0)
+    cs.configure(ifmt, w, h, ofmt, ow, oh, method=method, add_borders=True, border_color=0xFF2060C0, colorimetry="bt601", chroma_site="jpeg")
+    assert cs.kernel_name.startswith("k_cs_staged")
+    got = cs.process(raw)
+    cs.close()
+    src, dst = np.float32(w) / np.float32(h), np.float32(ow) / np.float32(oh)
+    rw, rh = ow, oh
+    if src > dst:
+        rh = int(math.floor(float(oh) * float(np.float32(dst / src)) + 0.5))
+    else:
+        rw = int(math.floor(float(ow) * float(np.float32(src / dst)) + 0.5))
+    rx, ry = (ow - rw) // 2, (oh - rh) // 2
+    assert not (rx | rw) & 1 and (ofmt in ("UYVY", "YUY2") or not (ry | rh) & 1), "pick a case whose rectangle is aligned"
+    inner = np.asarray(oracle.convertscale(ifmt, w, h, raw, "bt601", "jpeg", method, ofmt, rw, rh))
+    r, g, b = 0x20, 0x60, 0xC0
+    Y, U, V = ((66 * r + 129 * g + 25 * b) >> 8) + 16, ((-38 * r - 74 * g + 112 * b) >> 8) + 128, ((112 * r - 94 * g - 18 * b) >> 8) + 128
+    opl, _ = vfhip.plane_layout(ofmt, ow, oh)
+    ipl, _ = vfhip.plane_layout(ofmt, rw, rh)
+    want = np.zeros_like(got)
+    if ofmt in ("UYVY", "YUY2"):
+        (o0, os_, _), (i0, is_, _) = opl[0], ipl[0]
+        rows = want[o0: o0 + os_ * oh].reshape(oh, os_)
+        mp = [Y, U, Y, V] if ofmt == "YUY2" else [U, Y, V, Y]
+        rows[:, : 4 * ((ow + 1) // 2)] = np.tile(np.array(mp, np.uint8), (ow + 1) // 2)
+        rows[ry: ry + rh, 2 * rx: 2 * rx + 2 * rw] = inner[i0: i0 + is_ * rh].reshape(rh, is_)[:, : 2 * rw]
+    else:
+        for k, ((oo, os_, orows), (io, is_, irows)) in enumerate(zip(opl, ipl)):
+            sub = 1 if k == 0 else 2
+            n = 2 if (ofmt == "NV12" and k == 1) else 1
+            pw, ph = (ow if k == 0 else (ow + 1) // 2), (oh if k == 0 else (oh + 1) // 2)
+            plane = want[oo: oo + os_ * orows].reshape(orows, os_)
+            if k == 0:
+                plane[:ph, :pw] = Y
+            elif ofmt == "NV12":
+                plane[:ph, 0: 2 * pw: 2] = U
+                plane[:ph, 1: 2 * pw: 2] = V
+            else:
+                plane[:ph, :pw] = U if k == 1 else V
+            iw_, ih_ = (rw if k == 0 else rw // 2), (rh if k == 0 else rh // 2)
+            plane[ry // sub: ry // sub + ih_, n * (rx // sub): n * (rx // sub) + n * iw_] = inner[io: io + is_ * irows].reshape(irows, is_)[:ih_, : n * iw_]
+    assert np.array_equal(meaningful(ofmt, ow, oh, got), meaningful(ofmt, ow, oh, want))
+
+
+def test_gst_exact_letterbox_yuv_batched(vfhip):
+    """the bordered YUV output as a batch on device frames equals the one-frame host call, frame by frame"""
+    import torch
+    w, h, ow, oh, n = 64, 36, 64, 64, 4
+    isz, osz = vfhip.plane_layout("NV12", w, h)[1], vfhip.plane_layout("I420", ow, oh)[1]
+    ip, op = (isz + 255) // 256 * 256, (osz + 255) // 256 * 256
+    cs = vfhip.ConvertScale(0)
+    cs.configure("NV12", w, h, "I420", ow, oh, add_borders=True, border_color=0xFF804020, colorimetry="bt709", chroma_site="mpeg2")
+    assert cs.kernel_name == "k_cs_staged_420"
+    host = torch.randint(0, 256, (n, ip), dtype=torch.uint8, generator=torch.Generator().manual_seed(3))
+    want = [cs.process(host[k, :isz].numpy()) for k in range(n)]
+    dev_in, dev_out = host.cuda(), torch.zeros((n, op), dtype=torch.uint8, device="cuda")
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    cs.process_device(dev_in.data_ptr(), dev_out.data_ptr(), stream=s.cuda_stream, n_frames=n, in_pitch=ip, out_pitch=op)
+    s.synchronize()
+    out = dev_out.cpu().numpy()
+    for k in range(n):
+        assert np.array_equal(meaningful("I420", ow, oh, out[k, :osz]), meaningful("I420", ow, oh, want[k])), f"frame {k}"
+    cs.close()

@@ -60,9 +60,9 @@ def test_convertscale_metal_matrix(vfhip, metalref, ifmt, ofmt):
 def test_convertscale_gst_exact_falls_back_to_metal_for_unpinned_cells(vfhip, metalref):
     raw = smooth("UYVY", 64, 32, 1)
     cs = vfhip.ConvertScale(0)
-    cs.configure("UYVY", 64, 32, "NV12", 32, 32, add_borders=True, numerics="gst-exact")     # borders with a YUV output: not pinned
+    cs.configure("UYVY", 64, 32, "NV12", 30, 30, add_borders=True, numerics="gst-exact")     # borders whose rectangle (30 x 15) is not on chroma-sample boundaries: not pinned
     assert cs.kernel_name == "k_cs_metal"
-    close(cs.process(raw), metalref.convertscale("UYVY", 64, 32, raw, "NV12", 32, 32, add_borders=True), "UYVY->NV12 borders")
+    close(cs.process(raw), metalref.convertscale("UYVY", 64, 32, raw, "NV12", 30, 30, add_borders=True), "UYVY->NV12 borders")
     cs.close()
 
 
