@@ -322,3 +322,61 @@ def load_metalref():
 def mr_filter_params(p):
     """vfhip.VideoFilterParams -> MrFilterParams (same field order)."""
     return MrFilterParams(*[getattr(p, f[0]) for f in p._fields_])
+
+
+def letterbox_rect(w, h, ow, oh):
+    """the reference's centred aspect-preserving rectangle (metalconvertscalerenderer.m:137-166; float32 ratios, round to nearest)"""
+    import math
+    src, dst = np.float32(w) / np.float32(h), np.float32(ow) / np.float32(oh)
+    rw, rh = ow, oh
+    if src > dst:
+        rh = int(math.floor(float(oh) * float(np.float32(dst / src)) + 0.5))
+    else:
+        rw = int(math.floor(float(ow) * float(np.float32(src / dst)) + 0.5))
+    rw, rh = min(max(rw, 1), ow), min(max(rh, 1), oh)
+    return (ow - rw) // 2, (oh - rh) // 2, rw, rh
+
+
+def convertscale_with_borders(oracle, fmt, w, h, raw, colorimetry, chroma_site, method, out_format, ow, oh, border_argb):
+    """add-borders on top of the gst-exact path: the rectangle holds what `videoconvert ! videoscale` gives at
+    its size, the rest is the border colour (RGB outputs: in the output's byte order; YUV outputs: through the RGB -> YUV matrix).
+    Returns the raw output frame, or None when a YUV output's rectangle is not on chroma-sample boundaries (metal arithmetic then)."""
+    rx, ry, rw, rh = letterbox_rect(w, h, ow, oh)
+    a, r, g, b = (border_argb >> 24) & 0xff, (border_argb >> 16) & 0xff, (border_argb >> 8) & 0xff, border_argb & 0xff
+    inner = np.asarray(oracle.convertscale(fmt, w, h, raw, colorimetry, chroma_site, method, out_format, rw, rh))
+    if out_format in ("BGRA", "RGBA"):
+        out = np.empty((oh, ow, 4), np.uint8)
+        out[:] = np.array([r, g, b, a] if out_format == "RGBA" else [b, g, r, a], np.uint8)
+        out[ry:ry + rh, rx:rx + rw] = inner
+        return out.reshape(-1)
+    packed = out_format in ("UYVY", "YUY2")
+    if rw == ow and rh == oh:
+        return inner.reshape(-1)                          # same aspect ratio: no borders
+    if ((rx | rw) & 1) or (not packed and ((ry | rh) & 1)):
+        return None
+    m = {"bt601": (66, 129, 25, -38, -74, 112, 112, -94, -18), "bt709": (47, 157, 16, -26, -87, 112, 112, -102, -10),
+         "bt2020": (58, 149, 13, -31, -81, 112, 112, -103, -9)}[colorimetry]
+    Y, U, V = ((m[0] * r + m[1] * g + m[2] * b) >> 8) + 16, ((m[3] * r + m[4] * g + m[5] * b) >> 8) + 128, ((m[6] * r + m[7] * g + m[8] * b) >> 8) + 128
+    opl, osz = raw_layout(out_format, ow, oh)
+    ipl, _ = raw_layout(out_format, rw, rh)
+    want = np.zeros(osz, np.uint8)
+    if packed:
+        (o0, os_), (i0, is_) = opl[0], ipl[0]
+        rows = want[o0: o0 + os_ * oh].reshape(oh, os_)
+        rows[:, : 4 * ((ow + 1) // 2)] = np.tile(np.array([Y, U, Y, V] if out_format == "YUY2" else [U, Y, V, Y], np.uint8), (ow + 1) // 2)
+        rows[ry: ry + rh, 2 * rx: 2 * rx + 2 * rw] = inner[i0: i0 + is_ * rh].reshape(rh, is_)[:, : 2 * rw]
+        return want
+    for k, ((oo, os_), (io, is_)) in enumerate(zip(opl, ipl)):
+        sub, n = (1 if k == 0 else 2), (2 if (out_format == "NV12" and k == 1) else 1)
+        pw, ph = (ow if k == 0 else (ow + 1) // 2), (oh if k == 0 else (oh + 1) // 2)
+        irows = rh if k == 0 else (rh + 1) // 2
+        plane = want[oo: oo + os_ * ph].reshape(ph, os_)
+        if k == 0:
+            plane[:, :pw] = Y
+        elif out_format == "NV12":
+            plane[:, 0: 2 * pw: 2], plane[:, 1: 2 * pw: 2] = U, V
+        else:
+            plane[:, :pw] = U if k == 1 else V
+        iw_ = rw if k == 0 else (rw + 1) // 2
+        plane[ry // sub: ry // sub + irows, n * (rx // sub): n * (rx // sub) + n * iw_] = inner[io: io + is_ * irows].reshape(irows, is_)[:, : n * iw_]
+    return want

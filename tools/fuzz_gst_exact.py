@@ -32,16 +32,24 @@ for case in range(N):
         method = "bilinear"
     col, site = ["bt601", "bt709", "bt2020"][rng.integers(3)], ["jpeg", "mpeg2"][rng.integers(2)]
     raw = rng.integers(0, 256, vfhip.plane_layout(ifmt, w, h)[1], dtype=np.uint8)
+    borders = rng.integers(5) == 0 and not (w * oh == h * ow)
     cs = vfhip.ConvertScale(0)
     try:
-        cs.configure(ifmt, w, h, ofmt, ow, oh, method=method, colorimetry=col, chroma_site=site)
+        cs.configure(ifmt, w, h, ofmt, ow, oh, method=method, colorimetry=col, chroma_site=site, add_borders=bool(borders), border_color=0xC0123456)
         got = cs.process(raw)
         k = cs.kernel_name
     except vfhip.VfHipError as e:
         # bicubic on a line shorter than its filter (here: a chroma line): refused — the oracle must refuse the same case
         assert e.code == -2 and method == "bicubic", (e, ifmt, (w, h), ofmt, (ow, oh), method)
+        if borders and ofmt in ("BGRA", "RGBA"):
+            kernels["refused (bicubic with borders, RGB output)"] = kernels.get("refused (bicubic with borders, RGB output)", 0) + 1
+            continue
         try:
-            orc.convertscale(ifmt, w, h, raw, col, site, method, ofmt, ow, oh)
+            if borders:
+                if oracle_lib.convertscale_with_borders(orc, ifmt, w, h, raw, col, site, method, ofmt, ow, oh, 0xC0123456) is None:
+                    raise RuntimeError("unaligned rectangle: bicubic has no metal fallback")
+            else:
+                orc.convertscale(ifmt, w, h, raw, col, site, method, ofmt, ow, oh)
             bad += 1
             print("REFUSED BY THE LIBRARY ONLY", ifmt, (w, h), "->", ofmt, (ow, oh), flush=True)
         except RuntimeError:
@@ -52,7 +60,22 @@ for case in range(N):
     kernels[k] = kernels.get(k, 0) + 1
     if k == "k_cs_metal":
         continue                                                     # an unpinned cell (not gst-exact): nothing to compare
-    want = orc.convertscale(ifmt, w, h, raw, col, site, method, ofmt, ow, oh)
+    try:
+        want = (oracle_lib.convertscale_with_borders(orc, ifmt, w, h, raw, col, site, method, ofmt, ow, oh, 0xC0123456) if borders
+                else orc.convertscale(ifmt, w, h, raw, col, site, method, ofmt, ow, oh))
+    except RuntimeError:
+        if borders:
+            kernels["borders: rectangle outside the bicubic domain"] = kernels.get("borders: rectangle outside the bicubic domain", 0) + 1
+            bad += 1
+            print("LIBRARY ACCEPTED WHAT THE ORACLE REFUSES", ifmt, (w, h), "->", ofmt, (ow, oh), method, flush=True)
+            continue
+        raise
+    if want is None:
+        bad += 1
+        print("EXACT KERNEL ON AN UNALIGNED BORDER RECTANGLE", ifmt, (w, h), "->", ofmt, (ow, oh), k, flush=True)
+        continue
+    if borders:
+        kernels["(with borders)"] = kernels.get("(with borders)", 0) + 1
     if not np.array_equal(np.asarray(got).reshape(-1), np.asarray(want).reshape(-1)):
         bad += 1
         d = (np.asarray(got).reshape(-1) != np.asarray(want).reshape(-1)).sum()
