@@ -396,9 +396,9 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
                       !(out_packed && in->width == 2 && h->rw != 2) &&
                       (!any_yuv_in || (in->color_matrix == out->color_matrix && in->chroma_site == out->chroma_site));
   if (method == VFHIP_SCALE_BICUBIC && !staged) {
-    const int iw = in->width, ih = in->height, ow = out->width, oh = out->height;
-    if (numerics != VFHIP_NUMERICS_GST_EXACT || !(in_420_or_rgb || in_packed) || !out_rgb || h->add_borders)
-      return set_error (VFHIP_ERR_UNSUPPORTED, "method=bicubic needs numerics=gst-exact and no borders (YUV -> YUV: the same matrix and chroma siting on both sides)");
+    const int iw = in->width, ih = in->height, ow = h->rw, oh = h->rh;      // the destination rectangle (= the frame without borders)
+    if (numerics != VFHIP_NUMERICS_GST_EXACT || !(in_420_or_rgb || in_packed) || !out_rgb)
+      return set_error (VFHIP_ERR_UNSUPPORTED, "method=bicubic needs numerics=gst-exact (YUV outputs: the same matrix and chroma siting on both sides, borders only on chroma-sample boundaries)");
     if (!cubic_in_domain (iw, ow) || !cubic_in_domain (ih, oh))
       return set_error (VFHIP_ERR_UNSUPPORTED, "method=bicubic: %dx%d -> %dx%d has a line shorter than its filter (or more than 64 taps)", iw, ih, ow, oh);
     std::vector<int2> th_, tv_;
@@ -736,7 +736,7 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
 // method=bicubic: [conversion at the input size ->] n-tap pass -> n-tap pass, in GstVideoScaler's order
 static int ntap_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame *out, hipStream_t s)
 {
-  const int iw = h->in.width, ih = h->in.height, ow = h->out.width, oh = h->out.height;
+  const int iw = h->in.width, ih = h->in.height, ow = h->rw, oh = h->rh;      // `out` is the view of the destination rectangle
   const uint8_t *src = (const uint8_t *) in->data[0];
   int ss = in->stride[0];
   if (h->conv) {
@@ -777,6 +777,20 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
 {
   if (n_frames <= 0) return VFHIP_OK;
   if (n_frames > 65535) return set_error (VFHIP_ERR_INVALID, "batch of %d frames exceeds 65535", n_frames);
+  VfHipFrame rect_view;
+  if (h->kernel == VfHipConvertScale::K_NTAP && (h->rw != h->out.width || h->rh != h->out.height)) {
+    // add-borders: the border colour everywhere outside the rectangle, then the bicubic path writes the rectangle through a view
+    RgbBorderParams b {};
+    b.out = (uint8_t *) out->data[0]; b.os = out->stride[0]; b.pitch = out_pitch;
+    b.w = h->out.width; b.h = h->out.height; b.rx = h->rx; b.ry = h->ry; b.rw = h->rw; b.rh = h->rh;
+    b.colour = border_in_output_order (h->border_color, h->out.format);
+    dim3 grid ((unsigned) ((b.w + 63) / 64), (unsigned) ((b.h + 3) / 4), (unsigned) n_frames);
+    hipLaunchKernelGGL (k_border_fill_rgb, grid, dim3 (64, 4), 0, s, b);
+    VFHIP_CHECK_HIP (hipGetLastError ());
+    rect_view = *out;
+    rect_view.data[0] = (uint8_t *) out->data[0] + (size_t) h->ry * out->stride[0] + 4 * (size_t) h->rx;
+    out = &rect_view;
+  }
   if (h->kernel == VfHipConvertScale::K_NTAP && h->nt_tile) {
     CubicTileParams t {};
     for (int k = 0; k < 3; k++) { t.cs.in[k] = (const uint8_t *) in->data[k]; t.cs.is[k] = in->stride[k]; }
@@ -785,7 +799,7 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
     for (int k = 0; k < 5; k++) t.cs.c[k] = kOrcCoef[h->in.color_matrix][k];
     t.cs.cosited = h->in.chroma_site == VFHIP_CHROMA_SITE_H_COSITED;
     t.out = (uint8_t *) out->data[0]; t.os = out->stride[0];
-    t.ow = h->out.width; t.oh = h->out.height; t.nh = h->nt_h; t.nv = h->nt_v; t.vfirst = h->vfirst;
+    t.ow = h->rw; t.oh = h->rh; t.nh = h->nt_h; t.nv = h->nt_v; t.vfirst = h->vfirst;
     t.tab_h = h->d_nt_h; t.tab_v = h->d_nt_v;
     {
       const uintptr_t a = (uintptr_t) t.cs.in[0] | (uintptr_t) t.cs.in[1] | (uintptr_t) t.cs.is[0] | (uintptr_t) t.cs.is[1] | (uintptr_t) in_pitch;

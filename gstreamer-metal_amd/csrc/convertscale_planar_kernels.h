@@ -424,6 +424,18 @@ __global__ __launch_bounds__ (256) void k_plane_htap (const PlaneTapParams p)
   store4 (p.out + (size_t) blockIdx.z * p.out_pitch + (size_t) y * p.os + bx, v, bx, p.wb);
 }
 
+// add-borders with an RGB output whose rectangle another kernel writes (method=bicubic): the colour everywhere else
+struct RgbBorderParams { uint8_t *out; int os; size_t pitch; int w, h, rx, ry, rw, rh; uint32_t colour; };
+
+__global__ __launch_bounds__ (256) void k_border_fill_rgb (const RgbBorderParams p)
+{
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= p.w || y >= p.h || (x >= p.rx && x < p.rx + p.rw && y >= p.ry && y < p.ry + p.rh)) return;
+  uint8_t *d = p.out + (size_t) blockIdx.z * p.pitch + (size_t) y * p.os + 4 * (size_t) x;
+  if (((uintptr_t) d & 3) == 0) *reinterpret_cast<uint32_t *> (d) = p.colour;
+  else { d[0] = (uint8_t) p.colour; d[1] = (uint8_t) (p.colour >> 8); d[2] = (uint8_t) (p.colour >> 16); d[3] = (uint8_t) (p.colour >> 24); }
+}
+
 // add-borders with a YUV output: every sample OUTSIDE the destination rectangle gets the border colour (already through the
 // RGB -> YUV matrix).  One lane = one column pair (x, x+1) of one row; the rectangle sits on chroma-sample boundaries.
 struct BorderFillParams {

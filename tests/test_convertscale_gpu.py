@@ -241,7 +241,7 @@ def test_bicubic_outside_the_pinned_domain_is_refused(vfhip):
     cs = vfhip.ConvertScale(0)
     for (w, h, ow, oh, ofmt, kw) in [(3, 3, 7, 5, "BGRA", {}), (16, 16, 1, 1, "BGRA", {}), (6, 36, 3, 18, "NV12", {}), (64, 36, 33, 33, "NV12", dict(add_borders=True)),
                                      (64, 36, 32, 18, "BGRA", dict(numerics="metal")),
-                                     (64, 36, 32, 18, "BGRA", dict(add_borders=True))]:
+                                     (16, 64, 32, 8, "BGRA", dict(add_borders=True))]:      # the rectangle (2 x 8) is narrower than the 32-tap filter
         with pytest.raises(vfhip.VfHipError) as e:
             cs.configure("NV12", w, h, ofmt, ow, oh, method="bicubic", **kw)
         assert e.value.code == -2                       # VFHIP_ERR_UNSUPPORTED
@@ -552,7 +552,8 @@ def test_host_frames_with_padded_strides(vfhip, oracle, ifmt, ofmt, w, h, ow, oh
 
 
 @pytest.mark.parametrize("ifmt,ofmt,w,h,ow,oh,method", [("NV12", "BGRA", 64, 36, 48, 48, "bilinear"), ("I420", "RGBA", 36, 64, 50, 40, "bilinear"), ("BGRA", "BGRA", 40, 30, 64, 64, "nearest"),
-                                                        ("UYVY", "RGBA", 64, 16, 33, 31, "bilinear"), ("NV12", "BGRA", 128, 72, 64, 36, "bilinear")])
+                                                        ("UYVY", "RGBA", 64, 16, 33, 31, "bilinear"), ("NV12", "BGRA", 128, 72, 64, 36, "bilinear"),
+                                                        ("NV12", "BGRA", 64, 36, 48, 48, "bicubic"), ("I420", "RGBA", 200, 120, 97, 120, "bicubic"), ("BGRA", "BGRA", 40, 30, 64, 64, "bicubic")])
 def test_gst_exact_letterbox(vfhip, oracle, ifmt, ofmt, w, h, ow, oh, method):
     """add-borders with gst-exact numerics and an RGB output: the reference's centred aspect-preserving rectangle
     (metalconvertscalerenderer.m:137-166) holds exactly what `videoconvert ! videoscale` gives at the rectangle's size, the
