@@ -206,9 +206,9 @@ class ConvertScale:
 
     def configure(self, in_fmt, in_w, in_h, out_fmt, out_w, out_h, method="bilinear", add_borders=False,
                   border_color=0xFF000000, numerics="gst-exact", colorimetry="bt601", chroma_site="jpeg",
-                  out_colorimetry=None):
+                  out_colorimetry=None, out_chroma_site=None):
         self.in_info = make_info(in_fmt, in_w, in_h, colorimetry, chroma_site)
-        self.out_info = make_info(out_fmt, out_w, out_h, out_colorimetry or colorimetry, chroma_site)
+        self.out_info = make_info(out_fmt, out_w, out_h, out_colorimetry or colorimetry, out_chroma_site or chroma_site)
         check(lib.vfhip_convertscale_configure(self.h, C.byref(self.in_info), C.byref(self.out_info), METHODS[method],
                                                int(add_borders), border_color, NUMERICS[numerics]))
         self.cfg = (in_fmt, in_w, in_h, out_fmt, out_w, out_h)

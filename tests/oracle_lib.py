@@ -58,7 +58,7 @@ class Oracle:
     def _p(a, off=0):
         return C.c_void_p(a.ctypes.data + off)
 
-    def convertscale(self, fmt, w, h, raw, colorimetry, chroma_site, method, out_format, ow, oh):
+    def convertscale(self, fmt, w, h, raw, colorimetry, chroma_site, method, out_format, ow, oh, out_chroma_site=None):
         """GStreamer 1.14 `videoconvert ! videoscale` on one frame in GstVideoInfo default layout, any of
         {NV12, I420, BGRA, RGBA} -> any of them.  RGB outputs return (oh, ow, 4); YUV outputs the raw output frame."""
         if colorimetry is None:
@@ -66,6 +66,7 @@ class Oracle:
         raw = np.ascontiguousarray(np.frombuffer(raw, np.uint8) if isinstance(raw, (bytes, bytearray)) else raw, dtype=np.uint8)
         pl = planes(fmt, w, h, raw)
         cos = 1 if chroma_site == "mpeg2" else 0
+        cos_out = cos if out_chroma_site is None else (1 if out_chroma_site == "mpeg2" else 0)   # only the NV12 <-> packed and RGB -> YUV steps look at it
         meth = {"bilinear": 0, "nearest": 1, "bicubic": 2}[method]
         mat = MATRIX[colorimetry]
         L = self.lib
@@ -100,7 +101,7 @@ class Oracle:
             mid = np.zeros(ms * h, np.uint8)
             if fmt == "NV12":
                 (y, ys), (uv, us) = pl
-                rc = L.gst114_yuv420_to_packed422(self._p(y), ys, self._p(uv), us, self._p(uv, 1), us, 0, w, h, cos, cos, yuy2, self._p(mid), ms)
+                rc = L.gst114_yuv420_to_packed422(self._p(y), ys, self._p(uv), us, self._p(uv, 1), us, 0, w, h, cos, cos_out, yuy2, self._p(mid), ms)
             elif fmt == "I420":
                 (y, ys), (u, us), (v, vs) = pl
                 rc = L.gst114_yuv420_to_packed422(self._p(y), ys, self._p(u), us, self._p(v), vs, 1, w, h, cos, cos, yuy2, self._p(mid), ms)
@@ -126,7 +127,7 @@ class Oracle:
             planar = out_format == "I420"
             up = C[0]
             vp = C[1] if planar else C[0]
-            rc = L.gst114_packed422_to_yuv420(self._p(raw), r4(2 * w), int(fmt == "YUY2"), w, h, cos, cos, int(planar), self._p(Y), w,
+            rc = L.gst114_packed422_to_yuv420(self._p(raw), r4(2 * w), int(fmt == "YUY2"), w, h, cos, cos_out, int(planar), self._p(Y), w,
                                               self._p(up), up.strides[0], self._p(vp, 0 if planar else 1), vp.strides[0])
             assert rc == 0
         elif not yuv_in:

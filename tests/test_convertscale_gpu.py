@@ -682,3 +682,28 @@ def test_gst_exact_letterbox_yuv_batched(vfhip):
     for k in range(n):
         assert np.array_equal(meaningful("I420", ow, oh, out[k, :osz]), meaningful("I420", ow, oh, want[k])), f"frame {k}"
     cs.close()
+
+
+from test_oracle_golden import MANIFEST_MS, ZMS  # noqa: E402
+
+
+@pytest.mark.parametrize("case", MANIFEST_MS, ids=[c["name"] for c in MANIFEST_MS])
+def test_golden_gstreamer_vectors_mixed_sitings(vfhip, oracle, case):
+    """different chroma sitings on the two sides of a YUV -> YUV cell (NV12 <-> packed resample with both, the I420 <-> packed
+    fast paths and the UYVY <-> YUY2 swizzle ignore them)"""
+    c = case
+    cs = vfhip.ConvertScale(0)
+    cs.configure(c["in_format"], c["w"], c["h"], c["out_format"], c["ow"], c["oh"], colorimetry=c["colorimetry"], chroma_site=c["chroma_site"],
+                 out_chroma_site=c["out_chroma_site"])
+    assert cs.kernel_name.startswith("k_cs_staged")
+    got = cs.process(ZMS[c["name"] + "_in"])
+    cs.close()
+    a, b = (meaningful(c["out_format"], c["ow"], c["oh"], f) for f in gst_undefined_packed(oracle, c, [got, ZMS[c["name"] + "_out"]]))
+    assert np.array_equal(a, b)
+
+
+def test_420_to_420_with_a_siting_change_is_not_gst_exact(vfhip):
+    cs = vfhip.ConvertScale(0)
+    cs.configure("NV12", 64, 36, "I420", 64, 36, chroma_site="jpeg", out_chroma_site="mpeg2")
+    assert cs.kernel_name == "k_cs_metal"
+    cs.close()

@@ -176,6 +176,19 @@ def test_oracle_matches_gstreamer_bicubic_yuv_outputs(oracle, case):
     assert np.array_equal(meaningful(c["out_format"], c["ow"], c["oh"], got), meaningful(c["out_format"], c["ow"], c["oh"], want))
 
 
+# ---- YUV -> YUV with different chroma sitings on the two sides (8 vectors from the real elements) ----------------------------
+MANIFEST_MS, ZMS = oracle_lib.load_golden("convertscale_gst114_mixedsite.npz")
+
+
+@pytest.mark.parametrize("case", MANIFEST_MS, ids=[c["name"] for c in MANIFEST_MS])
+def test_oracle_matches_gstreamer_mixed_sitings(oracle, case):
+    c = case
+    got = oracle.convertscale(c["in_format"], c["w"], c["h"], ZMS[c["name"] + "_in"], c["colorimetry"], c["chroma_site"],
+                              c["method"], c["out_format"], c["ow"], c["oh"], out_chroma_site=c["out_chroma_site"])
+    got, want = gst_undefined_packed(oracle, c, [got, ZMS[c["name"] + "_out"]])
+    assert np.array_equal(meaningful(c["out_format"], c["ow"], c["oh"], got), meaningful(c["out_format"], c["ow"], c["oh"], want))
+
+
 # ---- bicubic (videoscale method=catrom): 76 vectors from the real elements ------------------------------------------
 MANIFEST_B, ZB = oracle_lib.load_golden("convertscale_gst114_bicubic.npz")
 

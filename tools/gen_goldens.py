@@ -369,6 +369,34 @@ def gen_yuv_cubic():
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "yuvcubic":
     gen_yuv_cubic()
     sys.exit(0)
+def gen_mixed_sites():
+    """YUV -> YUV with DIFFERENT chroma sitings on the two sides, where that is pinned (NV12 <-> packed resample with both; the
+    I420 <-> packed fast paths and the UYVY <-> YUY2 swizzle ignore it): tests/golden/convertscale_gst114_mixedsite.npz"""
+    cases, arrays = [], {}
+    rng = np.random.default_rng(20261011)
+    todo = [("NV12", "UYVY", 64, 36, 64, 36), ("NV12", "YUY2", 66, 34, 33, 17), ("UYVY", "NV12", 64, 36, 64, 36), ("YUY2", "NV12", 50, 20, 125, 20),
+            ("I420", "UYVY", 48, 40, 20, 38), ("YUY2", "I420", 33, 17, 33, 17), ("UYVY", "YUY2", 62, 30, 31, 12), ("NV12", "UYVY", 35, 29, 80, 41)]
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = build_helper(tmp)
+        for t, (ifmt, ofmt, w, h, ow, oh) in enumerate(todo):
+            col = ["bt601", "bt709", "bt2020"][t % 3]
+            si, so = (("jpeg", "mpeg2"), ("mpeg2", "jpeg"))[t % 2]
+            size = {"NV12": nv12_layout(w, h)[3], "I420": i420_layout(w, h)[4]}.get(ifmt, r4(2 * w) * h)
+            raw = rng.integers(0, 256, size, dtype=np.uint8).tobytes()
+            out = gst_run(exe, tmp, raw, len(raw), f"video/x-raw,format={ifmt},width={w},height={h},framerate=1/1,colorimetry={col},chroma-site={si}",
+                          "videoconvert ! videoscale", f"video/x-raw,format={ofmt},width={ow},height={oh},colorimetry={col},chroma-site={so}")
+            name = f"ms_{ifmt.lower()}_to_{ofmt.lower()}_{t:02d}_{w}x{h}_to_{ow}x{oh}_{si}_{so}"
+            arrays[name + "_in"], arrays[name + "_out"] = np.frombuffer(raw, np.uint8), np.frombuffer(out, np.uint8)
+            cases.append(dict(name=name, in_format=ifmt, w=w, h=h, colorimetry=col, chroma_site=si, out_chroma_site=so, method="bilinear", out_format=ofmt,
+                              ow=ow, oh=oh, in_sha256=hashlib.sha256(raw).hexdigest(), out_sha256=hashlib.sha256(out).hexdigest()))
+    arrays["manifest"] = np.frombuffer(json.dumps(cases).encode(), np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "convertscale_gst114_mixedsite.npz"), **arrays)
+    print("wrote", len(cases), "mixed-siting cases")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "mixedsite":
+    gen_mixed_sites()
+    sys.exit(0)
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ties":
     gen_ties()
     sys.exit(0)
