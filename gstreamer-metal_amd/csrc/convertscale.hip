@@ -395,10 +395,10 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
                       ((in_420_or_rgb && out_420) || out_packed || (in_packed && out_420)) &&
                       !(out_packed && in->width == 2 && h->rw != 2) &&
                       (!any_yuv_in || (in->color_matrix == out->color_matrix &&
-                                       // the siting may differ where GStreamer either ignores it (I420 <-> packed fast paths, the UYVY <-> YUY2
-                                       // swizzle) or resamples with both (NV12 <-> packed, the kernels take both); 4:2:0 -> 4:2:0 with a
-                                       // siting change is a resampling that is not restated
-                                       (in->chroma_site == out->chroma_site || (!(in_yuv && out_420) && in->format != out->format))));
+                                       // the siting may differ where GStreamer either ignores it (the same format on both sides: videoconvert
+                                       // passes through; I420 <-> packed fast paths; the UYVY <-> YUY2 swizzle) or resamples with both (NV12 <->
+                                       // packed, the kernels take both); NV12 <-> I420 with a siting change is a resampling that is not restated
+                                       (in->chroma_site == out->chroma_site || in->format == out->format || !(in_yuv && out_420))));
   if (method == VFHIP_SCALE_BICUBIC && !staged) {
     const int iw = in->width, ih = in->height, ow = h->rw, oh = h->rh;      // the destination rectangle (= the frame without borders)
     if (numerics != VFHIP_NUMERICS_GST_EXACT || !(in_420_or_rgb || in_packed) || !out_rgb)

@@ -702,7 +702,7 @@ def test_golden_gstreamer_vectors_mixed_sitings(vfhip, oracle, case):
     assert np.array_equal(a, b)
 
 
-def test_420_to_420_with_a_siting_change_is_not_gst_exact(vfhip):
+def test_nv12_i420_with_a_siting_change_is_not_gst_exact(vfhip):
     cs = vfhip.ConvertScale(0)
     cs.configure("NV12", 64, 36, "I420", 64, 36, chroma_site="jpeg", out_chroma_site="mpeg2")
     assert cs.kernel_name == "k_cs_metal"

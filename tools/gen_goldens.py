@@ -375,7 +375,8 @@ def gen_mixed_sites():
     cases, arrays = [], {}
     rng = np.random.default_rng(20261011)
     todo = [("NV12", "UYVY", 64, 36, 64, 36), ("NV12", "YUY2", 66, 34, 33, 17), ("UYVY", "NV12", 64, 36, 64, 36), ("YUY2", "NV12", 50, 20, 125, 20),
-            ("I420", "UYVY", 48, 40, 20, 38), ("YUY2", "I420", 33, 17, 33, 17), ("UYVY", "YUY2", 62, 30, 31, 12), ("NV12", "UYVY", 35, 29, 80, 41)]
+            ("I420", "UYVY", 48, 40, 20, 38), ("YUY2", "I420", 33, 17, 33, 17), ("UYVY", "YUY2", 62, 30, 31, 12), ("NV12", "UYVY", 35, 29, 80, 41),
+            ("NV12", "NV12", 64, 36, 40, 30), ("I420", "I420", 33, 17, 33, 17), ("UYVY", "UYVY", 64, 36, 100, 50), ("YUY2", "YUY2", 34, 18, 34, 18)]
     with tempfile.TemporaryDirectory() as tmp:
         exe = build_helper(tmp)
         for t, (ifmt, ofmt, w, h, ow, oh) in enumerate(todo):
