@@ -612,6 +612,17 @@ static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
       for (int k = 0; k < 9; k++) p.c[k] = kRgb2Yuv[h->out.color_matrix][k];
       p.vec = h->in.format == VFHIP_FORMAT_NV12 && getenv ("VFHIP_PLANE_SCALAR") == nullptr &&
               (((uintptr_t) p.in[0] | (uintptr_t) p.in[1] | (uintptr_t) p.is[0] | (uintptr_t) p.is[1] | (uintptr_t) in_pitch) & 1) == 0;
+      if (h->in.format == VFHIP_FORMAT_BGRA || h->in.format == VFHIP_FORMAT_RGBA) {
+        const bool rgba = h->in.format == VFHIP_FORMAT_RGBA;
+        auto pack = [&] (int r, int g, int b, bool neg) {
+          auto part = [&] (int c) { return (uint32_t) (neg ? (c < 0 ? -c : 0) : (c > 0 ? c : 0)); };
+          return (rgba ? part (r) : part (b)) | part (g) << 8 | (rgba ? part (b) : part (r)) << 16;
+        };
+        p.cy = pack (p.c[0], p.c[1], p.c[2], false);
+        p.cup = pack (p.c[3], p.c[4], p.c[5], false); p.cun = pack (p.c[3], p.c[4], p.c[5], true);
+        p.cvp = pack (p.c[6], p.c[7], p.c[8], false); p.cvn = pack (p.c[6], p.c[7], p.c[8], true);
+        p.vec = (((uintptr_t) p.in[0] | (uintptr_t) p.is[0] | (uintptr_t) in_pitch) & 3) == 0 && getenv ("VFHIP_RGB2YUV_SCALAR") == nullptr;
+      }
       // (tried: two macro-pixels per lane with the four U/V pairs as one unaligned 8-byte window — 3 loads per 8 output bytes
       // instead of 14 — was SLOWER, 168 k vs 214 k frames/s on NV12 1080p -> UYVY: misaligned 8-byte loads, half the lanes)
       hipLaunchKernelGGL (k_to_packed422, grid, dim3 (64, 4), 0, s, p);

@@ -572,8 +572,9 @@ struct ToPackedParams {
   const uint8_t *in[3]; int is[3];
   uint8_t *out; int os;
   int w, h, in_fmt, out_yuy2, cosited_in, cosited_out;
-  int vec;                 // NV12 rows are 2-byte aligned: a U/V (or luma) pair is one 16-bit load
+  int vec;                 // NV12: rows 2-byte aligned (a U/V or luma pair is one 16-bit load); RGB: rows 4-byte aligned (dword pixels)
   int c[9];                // RGB -> YUV matrix (RGB inputs)
+  uint32_t cy, cup, cun, cvp, cvn;     // the same coefficients packed per byte lane of the input, positive and negative parts apart
 };
 
 __device__ __forceinline__ uint32_t pack_macro (int yuy2, int Y0, int Y1, int U, int V)
@@ -594,6 +595,21 @@ __device__ __forceinline__ uint32_t to_packed_one (const ToPackedParams &p, int 
       const uint8_t *row = p.in[0] + (size_t) y * p.is[0];
       int xs[3], su[3], sv[3];
       chroma_down_cols (k, cw, p.w, p.cosited_out, xs);
+      if (p.vec) {
+        // 4-byte-aligned rows: one dword load per pixel, every matrix row one or two v_dot4_u32_u8 (like k_rgb_to_yuv420_fast)
+        const uint32_t *r32 = reinterpret_cast<const uint32_t *> (row);
+        const uint32_t pc = r32[x], pr = r32[x1];
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+          const uint32_t px = t == 1 ? pc : (xs[t] == x ? pc : (xs[t] == x1 ? pr : r32[xs[t]]));
+          su[t] = (((int) __builtin_amdgcn_udot4 (px, p.cup, 0u, false) - (int) __builtin_amdgcn_udot4 (px, p.cun, 0u, false)) >> 8) + 128;
+          sv[t] = (((int) __builtin_amdgcn_udot4 (px, p.cvp, 0u, false) - (int) __builtin_amdgcn_udot4 (px, p.cvn, 0u, false)) >> 8) + 128;
+        }
+        U = chroma_down (su, p.cosited_out); V = chroma_down (sv, p.cosited_out);
+        Y0 = (int) (__builtin_amdgcn_udot4 (pc, p.cy, 0u, false) >> 8) + 16;
+        Y1 = (int) (__builtin_amdgcn_udot4 (pr, p.cy, 0u, false) >> 8) + 16;
+        break;
+      }
 #pragma unroll
       for (int t = 0; t < 3; t++) {
         const uint8_t *px = row + 4 * xs[t];

@@ -441,7 +441,8 @@ def test_staged_scalar_fallbacks_match(vfhip, oracle, monkeypatch):
     rng = np.random.default_rng(77)
     for (ifmt, ofmt, w, h, ow, oh) in [("BGRA", "NV12", 64, 36, 64, 36), ("RGBA", "I420", 67, 41, 33, 20), ("NV12", "NV12", 128, 72, 64, 36),
                                        ("I420", "I420", 128, 72, 64, 72), ("NV12", "I420", 96, 54, 96, 27), ("NV12", "UYVY", 67, 41, 67, 41),
-                                       ("NV12", "YUY2", 64, 36, 50, 20), ("YUY2", "NV12", 67, 41, 67, 41), ("UYVY", "NV12", 64, 36, 90, 50)]:
+                                       ("NV12", "YUY2", 64, 36, 50, 20), ("YUY2", "NV12", 67, 41, 67, 41), ("UYVY", "NV12", 64, 36, 90, 50),
+                                       ("BGRA", "UYVY", 67, 41, 67, 41), ("RGBA", "YUY2", 64, 36, 32, 18)]:
         raw = rng.integers(0, 256, oracle_lib.raw_layout(ifmt, w, h)[1], dtype=np.uint8)
         got, _ = run(vfhip, ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", ofmt, ow, oh)
         want = oracle.convertscale(ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", ofmt, ow, oh)

@@ -172,7 +172,7 @@ def staged():
     s = torch.cuda.Stream()
     for (ifmt, w, h, ofmt, ow, oh, method) in [("NV12", 3840, 2160, "NV12", 1920, 1080, "bilinear"), ("NV12", 1920, 1080, "NV12", 1280, 720, "bilinear"),
                                                ("I420", 1920, 1080, "I420", 1280, 720, "bilinear"), ("BGRA", 1920, 1080, "NV12", 1920, 1080, "bilinear"),
-                                               ("BGRA", 1920, 1080, "I420", 1280, 720, "bilinear"), ("NV12", 1920, 1080, "UYVY", 1920, 1080, "bilinear"),
+                                               ("BGRA", 1920, 1080, "I420", 1280, 720, "bilinear"), ("BGRA", 1920, 1080, "UYVY", 1920, 1080, "bilinear"), ("NV12", 1920, 1080, "UYVY", 1920, 1080, "bilinear"),
                                                ("UYVY", 1920, 1080, "NV12", 1920, 1080, "bilinear"), ("UYVY", 1920, 1080, "UYVY", 1280, 720, "bilinear"),
                                                ("NV12", 3840, 2160, "NV12", 1920, 1080, "nearest"), ("NV12", 1920, 1080, "NV12", 1280, 720, "bicubic"),
                                                ("NV12", 3840, 2160, "NV12", 1920, 1080, "bicubic")]:
