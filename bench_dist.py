@@ -32,6 +32,15 @@ def max_over_ranks(seconds, device="cpu"):
     return float(t.item())
 
 
+def gather_objects(obj):
+    """every rank's small python object, in rank order (device list for the report)"""
+    if not dist.is_initialized():
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
 def stream_to_gpu(stream_index, n_gpus):
     """independent streams shard round-robin: stream s -> GPU s mod N"""
     return stream_index % n_gpus

@@ -363,7 +363,10 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
   if (format_n_planes (in->format) < 0 || format_n_planes (out->format) < 0) return VFHIP_ERR_INVALID;
   if (method != VFHIP_SCALE_BILINEAR && method != VFHIP_SCALE_NEAREST && method != VFHIP_SCALE_BICUBIC)
     return set_error (VFHIP_ERR_INVALID, "bad method %d", method);
-  if (numerics != VFHIP_NUMERICS_GST_EXACT && numerics != VFHIP_NUMERICS_METAL) return set_error (VFHIP_ERR_INVALID, "bad numerics %d", numerics);
+  if (numerics != VFHIP_NUMERICS_GST_EXACT && numerics != VFHIP_NUMERICS_METAL && numerics != VFHIP_NUMERICS_GST_EXACT_STRICT)
+    return set_error (VFHIP_ERR_INVALID, "bad numerics %d", numerics);
+  const bool strict = numerics == VFHIP_NUMERICS_GST_EXACT_STRICT;
+  if (strict) numerics = VFHIP_NUMERICS_GST_EXACT;
   if (in->color_matrix < 0 || in->color_matrix > 2 || out->color_matrix < 0 || out->color_matrix > 2)
     return set_error (VFHIP_ERR_INVALID, "bad colour matrix");
   VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
@@ -490,6 +493,12 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
   }
   const bool exact = numerics == VFHIP_NUMERICS_GST_EXACT && (in_420_or_rgb || in_packed) && out_rgb;
   if (!exact) {
+    // gst-exact asked for on a cell without pinned GStreamer arithmetic: never silently (vfhip_convertscale_numerics_in_effect,
+    // the element's warning), and not at all under gst-exact-strict
+    if (strict)
+      return set_error (VFHIP_ERR_UNSUPPORTED, "numerics=gst-exact-strict: no pinned GStreamer arithmetic for this cell (format %d %dx%d matrix %d site %d -> format %d %dx%d matrix %d site %d%s)",
+          in->format, in->width, in->height, in->color_matrix, in->chroma_site, out->format, out->width, out->height, out->color_matrix, out->chroma_site,
+          h->add_borders ? ", borders" : "");
     h->kernel = VfHipConvertScale::K_METAL; h->kernel_name = "k_cs_metal";
     h->configured = true;
     return VFHIP_OK;
@@ -529,6 +538,14 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
 }
 
 const char *vfhip_convertscale_kernel_name (VfHipConvertScale *h) { return h ? h->kernel_name : "none"; }
+
+int vfhip_convertscale_numerics_in_effect (VfHipConvertScale *h)
+{
+  if (!h) return set_error (VFHIP_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk (h->mu);
+  if (!h->configured) return set_error (VFHIP_ERR_NOT_CONFIGURED, "convertscale: not configured");
+  return h->kernel == VfHipConvertScale::K_METAL ? VFHIP_NUMERICS_METAL : VFHIP_NUMERICS_GST_EXACT;
+}
 
 static int validate_frames (VfHipConvertScale *h, const VfHipFrame *in, const VfHipFrame *out)
 {

@@ -6,7 +6,7 @@
  * format and size are unchanged (:279-280), DAR-preserving fixation (:160-248).  The renderer behind it is
  * libvfhip's vfhip_convertscale_* (include/vfhip.h) instead of MetalConvertScaleRenderer.
  *
- * Additive properties: device-id (GPU ordinal, -1 = $VFHIP_DEVICE or 0) and numerics {gst-exact, metal}.
+ * Additive properties: device-id (GPU ordinal, -1 = $VFHIP_DEVICE or 0) and numerics {gst-exact, metal, gst-exact-strict}.
  * Unlike the reference, property changes after negotiation reconfigure under the object lock
  * (the reference reconfigures unlocked from the application thread, :392-403). */
 #ifdef HAVE_CONFIG_H
@@ -26,6 +26,7 @@ typedef struct
   GstVideoInfo in_info, out_info;
   gboolean negotiated, passthrough;
   gint method, numerics;
+  gboolean warn_substituted;      /* gst-exact requested, metal arithmetic configured: warning not posted yet */
   gboolean add_borders;
   guint border_color;
   /* async-depth=1: one frame stays in flight across chain calls (cs_generate_output) */
@@ -68,6 +69,7 @@ gst_vfhip_numerics_get_type (void)
   static const GEnumValue v[] = {
     {VFHIP_NUMERICS_GST_EXACT, "Integer arithmetic of GStreamer's CPU videoconvert + videoscale (bit-exact)", "gst-exact"},
     {VFHIP_NUMERICS_METAL, "Float arithmetic of the vfmetal shaders", "metal"},
+    {VFHIP_NUMERICS_GST_EXACT_STRICT, "gst-exact, and refuse caps whose GStreamer arithmetic is not pinned (plain gst-exact warns and runs the metal arithmetic there)", "gst-exact-strict"},
     {0, NULL, NULL}
   };
   if (g_once_init_enter (&t))
@@ -173,7 +175,23 @@ cs_configure_locked (GstVfHipConvertScale * self)
     GST_ERROR_OBJECT (self, "configure failed: %s", vfhip_last_error_string ());
     return FALSE;
   }
+  /* gst-exact on a cell without pinned GStreamer arithmetic runs the shader arithmetic: say so (cs_post_substitution) */
+  self->warn_substituted = self->numerics == VFHIP_NUMERICS_GST_EXACT &&
+      vfhip_convertscale_numerics_in_effect (self->renderer) == VFHIP_NUMERICS_METAL;
   return TRUE;
+}
+
+/* outside the object lock (posts a bus message) */
+static void
+cs_post_substitution (GstVfHipConvertScale * self)
+{
+  if (!self->warn_substituted)
+    return;
+  self->warn_substituted = FALSE;
+  GST_ELEMENT_WARNING (self, STREAM, NOT_IMPLEMENTED,
+      ("numerics=gst-exact: GStreamer's arithmetic for this format / colorimetry / border combination is not pinned; running the vfmetal shader arithmetic (kernel %s)",
+          vfhip_convertscale_kernel_name (self->renderer)),
+      ("set numerics=gst-exact-strict to refuse such caps instead, or numerics=metal to ask for the shader arithmetic"));
 }
 
 static gboolean
@@ -229,6 +247,7 @@ cs_set_caps (GstBaseTransform * trans, GstCaps * incaps, GstCaps * outcaps)
   if (!same)
     ok = cs_ensure_renderer (self) && cs_configure_locked (self);
   GST_OBJECT_UNLOCK (self);
+  cs_post_substitution (self);
   return ok;
 }
 
@@ -257,6 +276,7 @@ cs_transform (GstBaseTransform * trans, GstBuffer * inbuf, GstBuffer * outbuf)
     GST_WARNING_OBJECT (self, "no HIP renderer");
     return GST_FLOW_ERROR;
   }
+  cs_post_substitution (self);                              /* after a property change reconfigured the renderer */
   gst_vfhip_pin_foreign_memory (inbuf, &self->pin);         /* recurring pageable upstream memory: page-lock it in place */
   dev = gst_vfhip_element_device (self);
   if (!gst_video_frame_map (&in, &self->in_info, inbuf, (GstMapFlags) (GST_MAP_READ | gst_vfhip_map_flag (inbuf, dev))))

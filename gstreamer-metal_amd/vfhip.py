@@ -17,7 +17,7 @@ FORMATS = {"BGRA": 0, "RGBA": 1, "NV12": 2, "I420": 3, "UYVY": 4, "YUY2": 5}
 MATRICES = {"bt601": 0, "bt709": 1, "bt2020": 2}
 CHROMA_SITES = {"jpeg": 0, "none": 0, "center": 0, "mpeg2": 1}
 METHODS = {"bilinear": 0, "nearest": 1, "bicubic": 2}
-NUMERICS = {"gst-exact": 0, "metal": 1}
+NUMERICS = {"gst-exact": 0, "metal": 1, "gst-exact-strict": 2}
 FRAME_FLAG_TFF = 1
 
 
@@ -69,7 +69,7 @@ def _load():
     lib.vfhip_convertscale_process_device.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(Frame), C.c_void_p]
     lib.vfhip_convertscale_process_device_batch.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(Frame), C.c_size_t,
                                                             C.c_size_t, C.c_int, C.c_void_p]
-    for n in ("vfhip_convertscale_cleanup", "vfhip_convertscale_free", "vfhip_convertscale_kernel_name"):
+    for n in ("vfhip_convertscale_cleanup", "vfhip_convertscale_free", "vfhip_convertscale_kernel_name", "vfhip_convertscale_numerics_in_effect"):
         getattr(lib, n).argtypes = [C.c_void_p]
     lib.vfhip_deinterlace_configure.argtypes = [C.c_void_p, C.POINTER(VideoInfo)]
     lib.vfhip_deinterlace_process.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(Frame), C.POINTER(DeinterlaceParams)]
@@ -217,6 +217,13 @@ class ConvertScale:
     @property
     def kernel_name(self):
         return lib.vfhip_convertscale_kernel_name(self.h).decode()
+
+    @property
+    def numerics_in_effect(self):
+        """'gst-exact' or 'metal': what the configured cell really computes (differs from the request on unpinned cells)"""
+        rc = lib.vfhip_convertscale_numerics_in_effect(self.h)
+        check(min(rc, 0))
+        return {0: "gst-exact", 1: "metal"}[rc]
 
     def process(self, raw_in):
         """raw_in: uint8 array in GstVideoInfo default layout (host). Returns the raw output frame (host)."""

@@ -74,8 +74,12 @@ typedef enum {
 
 /* Two sets of arithmetic exist for this path (SURVEY.md finding 3). */
 typedef enum {
-  VFHIP_NUMERICS_GST_EXACT = 0,  /* integer arithmetic of GStreamer 1.14 videoconvert+videoscale, bit-exact (default) */
-  VFHIP_NUMERICS_METAL = 1       /* float arithmetic of the reference's Metal shaders */
+  VFHIP_NUMERICS_GST_EXACT = 0,  /* integer arithmetic of GStreamer 1.14 videoconvert+videoscale, bit-exact (default).  The few
+                                  * cells of the format matrix whose GStreamer arithmetic is not pinned still
+                                  * configure, run the `metal` arithmetic, and say so: vfhip_convertscale_numerics_in_effect ()
+                                  * returns VFHIP_NUMERICS_METAL and the element posts a warning */
+  VFHIP_NUMERICS_METAL = 1,      /* float arithmetic of the reference's Metal shaders */
+  VFHIP_NUMERICS_GST_EXACT_STRICT = 2   /* gst-exact or nothing: configure refuses an unpinned cell with VFHIP_ERR_UNSUPPORTED */
 } VfHipNumerics;
 
 typedef struct {
@@ -134,8 +138,9 @@ typedef enum {
   VFHIP_SCALE_BILINEAR = 0,      /* VF_METAL_SCALE_BILINEAR, convertscale/metalconvertscalerenderer.h:30-33 */
   VFHIP_SCALE_NEAREST = 1,
   /* additive (the reference has no bicubic; north_star names it): GStreamer's `videoscale method=catrom`, bit-exact, for
-   * numerics = gst-exact, RGB outputs, no borders, and lines at least as long as the filter (ceil(4 * max(1, in/out)) taps,
-   * at most 64); anything else -> VFHIP_ERR_UNSUPPORTED at configure */
+   * numerics = gst-exact on every cell of the 6 x 6 format matrix whose 2-tap arithmetic is pinned (RGB, 4:2:0 and packed
+   * 4:2:2 outputs; borders on chroma-sample boundaries), for lines at least as long as the filter (ceil(4 * max(1, in/out))
+   * taps, at most 64); anything else -> VFHIP_ERR_UNSUPPORTED at configure */
   VFHIP_SCALE_BICUBIC = 2
 } VfHipScaleMethod;
 
@@ -148,6 +153,9 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
     int method, int add_borders, uint32_t border_color, int numerics);
 /* -processFrame:output: (metalconvertscalerenderer.m:332-512): host frames, synchronous */
 int vfhip_convertscale_process (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame *out);
+/* the arithmetic family the configured cell really runs: VFHIP_NUMERICS_GST_EXACT or VFHIP_NUMERICS_METAL (differs from the
+ * requested one exactly when gst-exact was asked for on an unpinned cell); < 0: not configured */
+int vfhip_convertscale_numerics_in_effect (VfHipConvertScale *h);
 /* device-resident frames, asynchronous on `stream` (a hipStream_t, NULL = the handle's own compute stream) */
 /* Pipelined variant of _process for host frames: _submit enqueues upload -> kernel -> download of one frame on the handle's
  * three streams and returns at once (pageable planes are copied into pinned staging before it returns; pinned planes and

@@ -47,3 +47,51 @@ def test_single_rank_is_a_noop():
     bd.barrier()
     assert bd.max_over_ranks(1.5) == 1.5
     assert bd.whole_job_rate(10, 2, 1, 0.5) == 40
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_bench_py_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py spawns 2 ranks itself (before touching a GPU), they meet
+    on gloo, rank 0 prints ONE line with n_gpus = 2 and both devices listed.  --selftest-cpu replaces the GPU step by a sleep
+    and marks the line as not-a-measurement (value null)."""
+    import json
+    r = _run_bench(["--gpus", "2", "--steps", "5", "--warmup", "1", "--selftest-cpu"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] is None and d["data"] == "selftest-no-gpu" and d["scaling"] == "weak"
+    assert [x["rank"] for x in d["config"]["devices"]] == [0, 1]
+    assert d["config"]["launches_per_step"] == 2                 # max over ranks of a per-rank value: the ranks really talked
+    assert d["ms_per_step"] >= 4.0 - 0.5                          # the slow rank (4 ms per step) sets the time
+
+
+def test_bench_py_refuses_a_world_size_mismatch():
+    r = _run_bench(["--gpus", "4", "--selftest-cpu"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29745"})
+    assert r.returncode != 0 and "must agree" in (r.stdout + r.stderr)
+    r = _run_bench(["--gpus", "1", "--selftest-cpu"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29746"})
+    assert r.returncode != 0 and "must agree" in (r.stdout + r.stderr)
+
+
+def test_bench_py_single_rank_selftest_and_traffic_key():
+    import json
+    r = _run_bench(["--selftest-cpu", "--steps", "3", "--warmup", "0"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1
+    sys.path.insert(0, ROOT)
+    import bench
+    t, note = bench.load_traffic(128)
+    with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
+        committed = json.load(f)
+    if committed.get("source_sha16") == bench.kernel_source_sha16():
+        assert t == round(committed["hbm_bytes_per_frame"] * 128)
+    else:
+        assert t is None and "re-run" in note                    # a PMC figure of another kernel source is never printed

@@ -62,7 +62,24 @@ def test_convertscale_gst_exact_falls_back_to_metal_for_unpinned_cells(vfhip, me
     cs = vfhip.ConvertScale(0)
     cs.configure("UYVY", 64, 32, "NV12", 30, 30, add_borders=True, numerics="gst-exact")     # borders whose rectangle (30 x 15) is not on chroma-sample boundaries: not pinned
     assert cs.kernel_name == "k_cs_metal"
+    assert cs.numerics_in_effect == "metal"                      # ... and says so: never a silent substitution
     close(cs.process(raw), metalref.convertscale("UYVY", 64, 32, raw, "NV12", 30, 30, add_borders=True), "UYVY->NV12 borders")
+    # gst-exact-strict refuses the cell instead (VFHIP_ERR_UNSUPPORTED) and leaves the handle unconfigured
+    with pytest.raises(vfhip.VfHipError) as e:
+        cs.configure("UYVY", 64, 32, "NV12", 30, 30, add_borders=True, numerics="gst-exact-strict")
+    assert e.value.code == -2
+    # a pinned cell configures under both spellings and reports gst-exact
+    for num in ("gst-exact", "gst-exact-strict"):
+        cs.configure("NV12", 64, 32, "BGRA", 32, 16, numerics=num, colorimetry="bt709", chroma_site="mpeg2")
+        assert cs.numerics_in_effect == "gst-exact" and cs.kernel_name == "k_cs_nv12_half"
+    cs.configure("NV12", 64, 32, "BGRA", 32, 16, numerics="metal")
+    assert cs.numerics_in_effect == "metal"
+    # the other unpinned families: YUV -> YUV with a matrix change, NV12 <-> I420 with a siting change
+    for kw in (dict(colorimetry="bt709", out_colorimetry="bt601"), dict(chroma_site="mpeg2", out_chroma_site="jpeg")):
+        cs.configure("NV12", 64, 32, "I420", 64, 32, numerics="gst-exact", **kw)
+        assert cs.numerics_in_effect == "metal", kw
+        with pytest.raises(vfhip.VfHipError):
+            cs.configure("NV12", 64, 32, "I420", 64, 32, numerics="gst-exact-strict", **kw)
     cs.close()
 
 
