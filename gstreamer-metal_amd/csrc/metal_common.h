@@ -5,7 +5,9 @@
 // Restates (does not copy) reference common/vfmetalshaders.m:40-168 (matrices, yuvToRGB, rgbaToNV12 /
 // rgbaToI420) and convertscale/metalconvertscale_shaders.h:151-269 (packed YUV fetch / store).
 // The CPU twin used by the tests is oracle/metalref.c; both are compiled with -ffp-contract=off and
-// evaluate every expression in the same order, so they normally agree bit for bit (tests allow +-1 LSB).
+// evaluate every expression in the same order — with explicit fmaf () in the same places (interpolation, colour
+// matrices, blur sums: what MSL's fast-math would contract; IEEE fma is deterministic on both sides) — so they
+// normally agree bit for bit (tests allow +-1 LSB).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -42,14 +44,15 @@ __device__ __forceinline__ F4 yuv_to_rgb (float y, float cb, float cr, int m709)
 {
   const float yy = y - 16.0f / 255.0f, u = cb - 128.0f / 255.0f, v = cr - 128.0f / 255.0f;
   F4 o;
+  const float ly = 1.164383f * yy;
   if (m709) {
-    o.r = 1.164383f * yy + 1.792741f * v;
-    o.g = 1.164383f * yy + -0.213249f * u + -0.532909f * v;
-    o.b = 1.164383f * yy + 2.112402f * u;
+    o.r = fmaf (1.792741f, v, ly);
+    o.g = fmaf (-0.532909f, v, fmaf (-0.213249f, u, ly));
+    o.b = fmaf (2.112402f, u, ly);
   } else {
-    o.r = 1.164383f * yy + 1.596027f * v;
-    o.g = 1.164383f * yy + -0.391762f * u + -0.812968f * v;
-    o.b = 1.164383f * yy + 2.017232f * u;
+    o.r = fmaf (1.596027f, v, ly);
+    o.g = fmaf (-0.812968f, v, fmaf (-0.391762f, u, ly));
+    o.b = fmaf (2.017232f, u, ly);
   }
   o.r = clamp01 (o.r); o.g = clamp01 (o.g); o.b = clamp01 (o.b); o.a = 1.0f;
   return o;
@@ -59,13 +62,13 @@ __device__ __forceinline__ F4 yuv_to_rgb (float y, float cb, float cr, int m709)
 __device__ __forceinline__ void rgb_to_yuv (float r, float g, float b, int m709, float *y, float *u, float *v)
 {
   if (m709) {
-    *y = 0.182586f * r + 0.614231f * g + 0.062007f * b + 16.0f / 255.0f;
-    *u = -0.100644f * r + -0.338572f * g + 0.439216f * b + 128.0f / 255.0f;
-    *v = 0.439216f * r + -0.398942f * g + -0.040274f * b + 128.0f / 255.0f;
+    *y = fmaf (0.062007f, b, fmaf (0.614231f, g, 0.182586f * r)) + 16.0f / 255.0f;
+    *u = fmaf (0.439216f, b, fmaf (-0.338572f, g, -0.100644f * r)) + 128.0f / 255.0f;
+    *v = fmaf (-0.040274f, b, fmaf (-0.398942f, g, 0.439216f * r)) + 128.0f / 255.0f;
   } else {
-    *y = 0.256788f * r + 0.504129f * g + 0.097906f * b + 16.0f / 255.0f;
-    *u = -0.148223f * r + -0.290993f * g + 0.439216f * b + 128.0f / 255.0f;
-    *v = 0.439216f * r + -0.367788f * g + -0.071427f * b + 128.0f / 255.0f;
+    *y = fmaf (0.097906f, b, fmaf (0.504129f, g, 0.256788f * r)) + 16.0f / 255.0f;
+    *u = fmaf (0.439216f, b, fmaf (-0.290993f, g, -0.148223f * r)) + 128.0f / 255.0f;
+    *v = fmaf (-0.071427f, b, fmaf (-0.367788f, g, 0.439216f * r)) + 128.0f / 255.0f;
   }
 }
 
@@ -81,7 +84,7 @@ __device__ __forceinline__ Taps lin_taps_px (int n, float x)           // x in t
 }
 __device__ __forceinline__ Taps lin_taps (int n, float coord) { return lin_taps_px (n, coord * (float) n - 0.5f); }   // coord normalised 0..1
 __device__ __forceinline__ int near_tap (int n, float coord) { return iclamp ((int) floorf (coord * (float) n), 0, n - 1); }
-__device__ __forceinline__ float lerp2 (float a, float b, float f) { return a + (b - a) * f; }
+__device__ __forceinline__ float lerp2 (float a, float b, float f) { return fmaf (b - a, f, a); }
 
 // one channel of a plane with `bpt` bytes per texel
 __device__ __forceinline__ float plane_taps (const uint8_t *p, int stride, int bpt, int ch, Taps tx, Taps ty)

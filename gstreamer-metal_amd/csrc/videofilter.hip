@@ -6,10 +6,11 @@
 // The reference runs 1 render pass + (sharpness != 0) 3 compute passes + 1 RGBA->YUV pass, every one a full
 // trip through an 8-bit texture (metalvideofilterrenderer.m:523-681).  Here:
 //   k_vf_point : sharpness == 0 — one kernel, each lane owns a 2x2 block (needed by the 4:2:0 store epilogue);
-//   k_vf_sharp : sharpness != 0 — one kernel, a 128x32 output tile per workgroup; the colour-adjusted tile plus
+//   k_vf_sharp : sharpness != 0 — one kernel, a 128x56 output tile per workgroup; the colour-adjusted tile plus
 //                its 4-pixel halo is quantised to 8 bits into LDS exactly where the reference wrote its render
-//                target, the 9-tap horizontal and vertical Gaussians and the unsharp mask run out of LDS (with the
-//                reference's 8-bit requantisation between passes), and only the final frame goes to HBM.
+//                target, the 9-tap horizontal and vertical Gaussians (sliding windows in registers) and the unsharp
+//                mask run out of LDS (with the reference's 8-bit requantisation between passes), and only the final
+//                frame goes to HBM.
 #include "vfhip_internal.h"
 #include "metal_common.h"
 #include <cctype>
@@ -44,12 +45,13 @@ using metal::F4;
 using metal::clamp01;
 
 __device__ __forceinline__ float fractf_ (float x) { return x - floorf (x); }
-__device__ __forceinline__ float mixf (float a, float b, float t) { return a + (b - a) * t; }
+__device__ __forceinline__ float mixf (float a, float b, float t) { return fmaf (b - a, t, a); }
 __device__ __forceinline__ float stepf (float e, float x) { return x < e ? 0.0f : 1.0f; }
 __device__ __forceinline__ float smoothstepf (float e0, float e1, float x)
 {
   if (!(e0 < e1)) return stepf (e0, x);          // MSL leaves e0 >= e1 undefined (smoothness = 0): defined as step
-  const float t = clamp01 ((x - e0) / (e1 - e0));
+  const float inv = 1.0f / (e1 - e0);            // wave-uniform edges: the division is scalar-rate work hoisted out of the pixel loop
+  const float t = clamp01 ((x - e0) * inv);
   return t * t * (3.0f - 2.0f * t);
 }
 __device__ __forceinline__ float hash12 (float px, float py, uint32_t frame)
@@ -85,8 +87,9 @@ __device__ __forceinline__ void hsv_to_rgb (float h, float s, float v, float *r,
 
 
 // pow(x, y) for x in [1e-4, 1], y > 0 (gamma stage): the same fixed sequence of IEEE single-precision operations as
-// oracle/metalref.c vf_powf — atanh-series log2 on the reduced mantissa, degree-7 exp2 — so both sides agree bit for
-// bit (libm and OCML powf do not, and MSL's fast-math pow is not correctly rounded anyway: SURVEY.md Appendix B item 8).
+// oracle/metalref.c vf_powf — atanh-series log2 on the reduced mantissa, degree-7 exp2, explicit fma steps — so both
+// sides agree bit for bit (libm and OCML powf do not, and MSL's fast-math pow is not correctly rounded anyway:
+// SURVEY.md Appendix B item 8).
 __device__ __forceinline__ float vf_powf (float x, float y)
 {
   const uint32_t ux = __float_as_uint (x);
@@ -95,24 +98,25 @@ __device__ __forceinline__ float vf_powf (float x, float y)
   if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
   const float t = (m - 1.0f) / (m + 1.0f), t2 = t * t;
   float p = 0.11111111f;
-  p = p * t2 + 0.14285714f; p = p * t2 + 0.2f; p = p * t2 + 0.33333333f; p = p * t2 + 1.0f;
-  const float l2 = (float) e + (t * p) * 2.88539008f;
+  p = fmaf (p, t2, 0.14285714f); p = fmaf (p, t2, 0.2f); p = fmaf (p, t2, 0.33333333f); p = fmaf (p, t2, 1.0f);
+  const float l2 = fmaf (t * p, 2.88539008f, (float) e);
   const float z = y * l2;
   if (z < -126.0f) return 0.0f;
   const float zi = floorf (z + 0.5f), f = (z - zi) * 0.69314718f;
   float q = 1.98412698e-4f;
-  q = q * f + 1.38888889e-3f; q = q * f + 8.33333333e-3f; q = q * f + 4.16666667e-2f; q = q * f + 0.16666667f;
-  q = q * f + 0.5f; q = q * f + 1.0f; q = q * f + 1.0f;
+  q = fmaf (q, f, 1.38888889e-3f); q = fmaf (q, f, 8.33333333e-3f); q = fmaf (q, f, 4.16666667e-2f); q = fmaf (q, f, 0.16666667f);
+  q = fmaf (q, f, 0.5f); q = fmaf (q, f, 1.0f); q = fmaf (q, f, 1.0f);
   return __uint_as_float (__float_as_uint (q) + (uint32_t) ((int) zi << 23));
 }
 
-// applyColorAdjustments (metalvideofilter_shaders.h:92-155), fixed order
+// applyColorAdjustments (metalvideofilter_shaders.h:92-155), fixed order.  Every `if` tests a wave-uniform parameter:
+// a disabled stage costs one scalar branch.
 __device__ __forceinline__ F4 color_adjust (F4 c, const VfHipVideoFilterParams &u, float tu, float tv, int W, int H)
 {
   float r = c.r, g = c.g, b = c.b, a = c.a;
   r += u.brightness; g += u.brightness; b += u.brightness;
-  r = (r - 0.5f) * u.contrast + 0.5f; g = (g - 0.5f) * u.contrast + 0.5f; b = (b - 0.5f) * u.contrast + 0.5f;
-  const float lum = r * 0.2126f + g * 0.7152f + b * 0.0722f;
+  r = fmaf (r - 0.5f, u.contrast, 0.5f); g = fmaf (g - 0.5f, u.contrast, 0.5f); b = fmaf (b - 0.5f, u.contrast, 0.5f);
+  const float lum = fmaf (b, 0.0722f, fmaf (g, 0.7152f, r * 0.2126f));
   r = mixf (lum, r, u.saturation); g = mixf (lum, g, u.saturation); b = mixf (lum, b, u.saturation);
   if (fabsf (u.hue) > 0.001f) {
     float h, s, v;
@@ -121,11 +125,12 @@ __device__ __forceinline__ F4 color_adjust (F4 c, const VfHipVideoFilterParams &
     hsv_to_rgb (h, s, v, &r, &g, &b);
   }
   const float ig = 1.0f / u.gamma;
-  r = vf_powf (fminf (fmaxf (r, 0.0001f), 1.0f), ig); g = vf_powf (fminf (fmaxf (g, 0.0001f), 1.0f), ig); b = vf_powf (fminf (fmaxf (b, 0.0001f), 1.0f), ig);
+  r = fminf (fmaxf (r, 0.0001f), 1.0f); g = fminf (fmaxf (g, 0.0001f), 1.0f); b = fminf (fmaxf (b, 0.0001f), 1.0f);
+  if (ig != 1.0f) { r = vf_powf (r, ig); g = vf_powf (g, ig); b = vf_powf (b, ig); }      // pow (x, 1) == x exactly
   if (u.sepia > 0.001f) {
-    const float sr = r * 0.393f + g * 0.769f + b * 0.189f;
-    const float sg = r * 0.349f + g * 0.686f + b * 0.168f;
-    const float sb = r * 0.272f + g * 0.534f + b * 0.131f;
+    const float sr = fmaf (b, 0.189f, fmaf (g, 0.769f, r * 0.393f));
+    const float sg = fmaf (b, 0.168f, fmaf (g, 0.686f, r * 0.349f));
+    const float sb = fmaf (b, 0.131f, fmaf (g, 0.534f, r * 0.272f));
     r = mixf (r, sr, u.sepia); g = mixf (g, sg, u.sepia); b = mixf (b, sb, u.sepia);
   }
   if (u.invert) { r = 1.0f - r; g = 1.0f - g; b = 1.0f - b; }
@@ -149,16 +154,18 @@ __device__ __forceinline__ F4 color_adjust (F4 c, const VfHipVideoFilterParams &
   return o;
 }
 
-// trilinear 3D LUT, coordinate c*(N-1)/N + .5/N (metalvideofilter_shaders.h:188-194); memory index (b*N+g)*N+r
+// trilinear 3D LUT, coordinate c*(N-1)/N + .5/N (metalvideofilter_shaders.h:188-194); memory index (b*N+g)*N+r.
+// 32-bit entry indices (N <= 64): no 64-bit multiplies in the address arithmetic of the 8 gathers.
 __device__ __forceinline__ void lut_sample (const float4 *lut, int N, F4 &c)
 {
   const float scale = (float) (N - 1) / (float) N, offset = 0.5f / (float) N;
-  const metal::Taps tx = metal::lin_taps (N, c.r * scale + offset), ty = metal::lin_taps (N, c.g * scale + offset),
-                    tz = metal::lin_taps (N, c.b * scale + offset);
-#define L(x, y, z) lut[((size_t) (z) * N + (y)) * N + (x)]
-  const float4 a000 = L (tx.i0, ty.i0, tz.i0), a100 = L (tx.i1, ty.i0, tz.i0), a010 = L (tx.i0, ty.i1, tz.i0), a110 = L (tx.i1, ty.i1, tz.i0);
-  const float4 a001 = L (tx.i0, ty.i0, tz.i1), a101 = L (tx.i1, ty.i0, tz.i1), a011 = L (tx.i0, ty.i1, tz.i1), a111 = L (tx.i1, ty.i1, tz.i1);
-#undef L
+  const metal::Taps tx = metal::lin_taps (N, fmaf (c.r, scale, offset)), ty = metal::lin_taps (N, fmaf (c.g, scale, offset)),
+                    tz = metal::lin_taps (N, fmaf (c.b, scale, offset));
+  const uint32_t n = (uint32_t) N, z0 = (uint32_t) tz.i0 * n, z1 = (uint32_t) tz.i1 * n;
+  const uint32_t r00 = (z0 + (uint32_t) ty.i0) * n, r10 = (z0 + (uint32_t) ty.i1) * n, r01 = (z1 + (uint32_t) ty.i0) * n, r11 = (z1 + (uint32_t) ty.i1) * n;
+  const uint32_t x0 = (uint32_t) tx.i0, x1 = (uint32_t) tx.i1;
+  const float4 a000 = lut[r00 + x0], a100 = lut[r00 + x1], a010 = lut[r10 + x0], a110 = lut[r10 + x1];
+  const float4 a001 = lut[r01 + x0], a101 = lut[r01 + x1], a011 = lut[r11 + x0], a111 = lut[r11 + x1];
   using metal::lerp2;
   c.r = lerp2 (lerp2 (lerp2 (a000.x, a100.x, tx.f), lerp2 (a010.x, a110.x, tx.f), ty.f), lerp2 (lerp2 (a001.x, a101.x, tx.f), lerp2 (a011.x, a111.x, tx.f), ty.f), tz.f);
   c.g = lerp2 (lerp2 (lerp2 (a000.y, a100.y, tx.f), lerp2 (a010.y, a110.y, tx.f), ty.f), lerp2 (lerp2 (a001.y, a101.y, tx.f), lerp2 (a011.y, a111.y, tx.f), ty.f), tz.f);
@@ -189,74 +196,111 @@ __global__ __launch_bounds__ (256) void k_vf_point (const VfParams pp)
   metal::store_block (p.out, bx, by, q);
 }
 
-// Tile geometry of k_vf_sharp.  Pass 1 (colour adjustments + LUT, by far the most expensive part) has to be evaluated
-// for the tile AND its 4-pixel halo, so the tile is large: 128x32 + halo = 136x40 -> 1.33x redundancy with 512 lanes and
-// 42 KB of LDS per workgroup (the first version's 64x16 tile was 1.69x; 128x64 with 1024 lanes, 1.195x, measures the
-// same within noise and leaves a single frame with too few workgroups: profiles/r01y_vf_tile_ab.txt).
+// ------------------------------------------------------------------------------------------------------------------
+// k_vf_sharp: sharpness != 0.  One workgroup (512 lanes) per 128 x 56 output tile:
+//   1. pass 1 (colour adjustments + LUT — by far the most expensive part) for the tile and its 4-pixel halo,
+//      136 x 64 pixels = 1.21x redundancy (the first version's 64x16 tile: 1.69x, 128x32: 1.33x), quantised to 8 bits
+//      into LDS exactly where the reference wrote its render target;
+//   2. horizontal 9-tap Gaussian, LDS -> LDS: a lane owns one ROW of the region (64 rows = one wave) and a run of 16
+//      columns; it slides along the row, so every texel is unpacked once per run (24 unpacks for 16 outputs instead of
+//      144) and a wave reads one column at a time — conflict-free with the odd row stride;
+//   3. vertical 9-tap + unsharp mask: a lane owns one COLUMN and a run of 14 rows, sliding down (22 unpacks for 14
+//      outputs); RGB outputs go straight to HBM from here (coalesced dwords), YUV outputs pass through LDS once more
+//      for the 2x2-block store epilogue.
+// The alpha byte is not blurred: the unsharp mask keeps the pass-1 alpha (metalvideofilter_shaders.h:318-327), so the
+// blurred alpha of the reference's two temporaries is never read.
+// LDS: 64 x 137 + 64 x 129 dwords = 68 KB -> two workgroups (16 waves) per CU.
 constexpr int VF_HALO = 4;
+constexpr int VF_TW = 128, VF_TH = 56, VF_THREADS = 512;
+constexpr int VF_RW = VF_TW + 2 * VF_HALO, VF_RH = VF_TH + 2 * VF_HALO;      // 136 x 64
+constexpr int VF_RS = VF_RW + 1, VF_HS = VF_TW + 1;                          // odd LDS row strides (dwords)
+constexpr int VF_HRUN = 16, VF_VRUN = 14;
+static_assert (VF_RH == 64 && VF_THREADS == VF_RH * (VF_TW / VF_HRUN) && VF_THREADS == VF_TW * (VF_TH / VF_VRUN), "tile / lane mapping");
 __constant__ float kBlurW[9] = { 0.028532f, 0.067234f, 0.124009f, 0.179044f, 0.20236f, 0.179044f, 0.124009f, 0.067234f, 0.028532f };
 
-template <int VF_TW, int VF_TH, int VF_THREADS, int MIN_WAVES>
-__global__ __launch_bounds__ (VF_THREADS, MIN_WAVES) void k_vf_sharp (const VfParams pp)
+struct F3 { float r, g, b; };
+__device__ __forceinline__ F3 unpack_rgb8 (uint32_t q) { F3 o; o.r = metal::un8 (q & 0xff); o.g = metal::un8 ((q >> 8) & 0xff); o.b = metal::un8 ((q >> 16) & 0xff); return o; }
+__device__ __forceinline__ uint32_t quant_rgb8 (float r, float g, float b)
 {
-  constexpr int VF_RW = VF_TW + 2 * VF_HALO, VF_RH = VF_TH + 2 * VF_HALO;
-  constexpr int VF_PER_LANE = VF_TW * VF_TH / VF_THREADS;
+  uint32_t q = __builtin_amdgcn_cvt_pk_u8_f32 (r * 255.0f, 0u, 0u);
+  q = __builtin_amdgcn_cvt_pk_u8_f32 (g * 255.0f, 1u, q);
+  return __builtin_amdgcn_cvt_pk_u8_f32 (b * 255.0f, 2u, q);
+}
+
+__global__ __launch_bounds__ (VF_THREADS, 2) void k_vf_sharp (const VfParams pp)
+{
   const VfParams p = vf_frame (pp);
-  __shared__ uint32_t rt[VF_RH][VF_RW];       // pass-1 render target, tile + halo (clamped to the image like the blur's reads)
-  __shared__ uint32_t hb[VF_RH][VF_TW];       // horizontal blur (8-bit, like _blurTemp); its first VF_TH rows are reused for the result
+  __shared__ uint32_t rt[VF_RH * VF_RS];       // pass-1 render target, tile + halo (clamped to the image like the blur's reads)
+  __shared__ uint32_t hb[VF_RH * VF_HS];       // horizontal blur (8-bit, like _blurTemp); reused for the result of YUV outputs
   const int x0 = blockIdx.x * VF_TW, y0 = blockIdx.y * VF_TH;
   const int tid = threadIdx.x;
   const int w = p.out.w, h = p.out.h;
   for (int i = tid; i < VF_RW * VF_RH; i += VF_THREADS) {
     const int rx = i % VF_RW, ry = i / VF_RW;
-    rt[ry][rx] = vf_pass1 (p, x0 - VF_HALO + rx, y0 - VF_HALO + ry);
+    rt[ry * VF_RS + rx] = vf_pass1 (p, x0 - VF_HALO + rx, y0 - VF_HALO + ry);
   }
   __syncthreads ();
-  // horizontal 9-tap on every row of the region, for the tile's columns.  Reads clamp to the IMAGE (not the region):
-  // region column rx holds image column clamp(x0-4+rx), so an unclamped region read is the clamped image read,
-  // except that columns right of the image edge inside the tile must not be produced at all.
-  for (int i = tid; i < VF_TW * VF_RH; i += VF_THREADS) {
-    const int tx = i % VF_TW, ry = i / VF_TW;
-    F4 s; s.r = s.g = s.b = s.a = 0.0f;
+  // horizontal pass.  Reads clamp to the IMAGE (not the region): region column rx holds image column clamp(x0-4+rx)
+  // (vf_pass1 clamps), so an unclamped region read is the clamped image read.
+  {
+    const int row = tid & (VF_RH - 1), c0 = (tid >> 6) * VF_HRUN;
+    const uint32_t *src = rt + row * VF_RS + c0;
+    F3 px[VF_HRUN + 8];
 #pragma unroll
-    for (int k = 0; k < 9; k++) {
-      const F4 c = metal::unpack_rgba8 (rt[ry][tx + k]);
-      s.r += c.r * kBlurW[k]; s.g += c.g * kBlurW[k]; s.b += c.b * kBlurW[k]; s.a += c.a * kBlurW[k];
+    for (int k = 0; k < VF_HRUN + 8; k++) px[k] = unpack_rgb8 (src[k]);
+#pragma unroll
+    for (int j = 0; j < VF_HRUN; j++) {
+      float sr = 0.0f, sg = 0.0f, sb = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 9; k++) { sr = fmaf (px[j + k].r, kBlurW[k], sr); sg = fmaf (px[j + k].g, kBlurW[k], sg); sb = fmaf (px[j + k].b, kBlurW[k], sb); }
+      hb[row * VF_HS + c0 + j] = quant_rgb8 (sr, sg, sb);
     }
-    hb[ry][tx] = metal::quant_rgba8 (s);
   }
   __syncthreads ();
   const float amount = p.u.sharpness;
-  uint32_t res[VF_PER_LANE];
+  const int col = tid & (VF_TW - 1), r0 = (tid >> 7) * VF_VRUN;
+  uint32_t res[VF_VRUN];
+  {
+    const uint32_t *src = hb + r0 * VF_HS + col;
+    F3 px[VF_VRUN + 8];
 #pragma unroll
-  for (int j = 0; j < VF_PER_LANE; j++) {
-    const int i = tid + j * VF_THREADS;
-    const int tx = i % VF_TW, ty = i / VF_TW;
-    F4 s; s.r = s.g = s.b = s.a = 0.0f;
+    for (int k = 0; k < VF_VRUN + 8; k++) px[k] = unpack_rgb8 (src[k * VF_HS]);
 #pragma unroll
-    for (int k = 0; k < 9; k++) {
-      const F4 c = metal::unpack_rgba8 (hb[ty + k][tx]);
-      s.r += c.r * kBlurW[k]; s.g += c.g * kBlurW[k]; s.b += c.b * kBlurW[k]; s.a += c.a * kBlurW[k];
+    for (int j = 0; j < VF_VRUN; j++) {
+      float sr = 0.0f, sg = 0.0f, sb = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 9; k++) { sr = fmaf (px[j + k].r, kBlurW[k], sr); sg = fmaf (px[j + k].g, kBlurW[k], sg); sb = fmaf (px[j + k].b, kBlurW[k], sb); }
+      const F3 b = unpack_rgb8 (quant_rgb8 (sr, sg, sb));               // _blurResult is 8-bit as well
+      const uint32_t oq = rt[(r0 + j + VF_HALO) * VF_RS + col + VF_HALO];
+      const F3 o = unpack_rgb8 (oq);
+      float rr, rg, rb;
+      if (amount > 0.0f) {
+        rr = clamp01 (fmaf (o.r - b.r, amount, o.r)); rg = clamp01 (fmaf (o.g - b.g, amount, o.g)); rb = clamp01 (fmaf (o.b - b.b, amount, o.b));
+      } else {
+        const float t = fabsf (amount);
+        rr = mixf (o.r, b.r, t); rg = mixf (o.g, b.g, t); rb = mixf (o.b, b.b, t);
+      }
+      res[j] = quant_rgb8 (rr, rg, rb) | (oq & 0xff000000u);            // alpha: the pass-1 value, untouched
     }
-    const F4 b = metal::unpack_rgba8 (metal::quant_rgba8 (s));          // _blurResult is 8-bit as well
-    const F4 o = metal::unpack_rgba8 (rt[ty + VF_HALO][tx + VF_HALO]);
-    F4 r;
-    if (amount > 0.0f) {
-      r.r = clamp01 (o.r + (o.r - b.r) * amount); r.g = clamp01 (o.g + (o.g - b.g) * amount); r.b = clamp01 (o.b + (o.b - b.b) * amount);
-    } else {
-      const float t = fabsf (amount);
-      r.r = mixf (o.r, b.r, t); r.g = mixf (o.g, b.g, t); r.b = mixf (o.b, b.b, t);
+  }
+  if (p.out.fmt == VFHIP_FORMAT_BGRA || p.out.fmt == VFHIP_FORMAT_RGBA) {
+    // RGB outputs: a wave's 64 lanes are 64 consecutive pixels of one row -> 256-byte coalesced dword stores, straight from registers
+    const int gx = x0 + col;
+    if (gx < w) {
+#pragma unroll
+      for (int j = 0; j < VF_VRUN; j++) {
+        const int gy = y0 + r0 + j;
+        if (gy >= h) break;
+        uint32_t v = res[j];
+        if (p.out.fmt == VFHIP_FORMAT_BGRA) v = __builtin_amdgcn_perm (0u, v, 0x03000102u);
+        __builtin_nontemporal_store (v, reinterpret_cast<uint32_t *> (p.out.p[0] + (size_t) gy * p.out.s[0]) + gx);
+      }
     }
-    r.a = o.a;
-    res[j] = metal::quant_rgba8 (r);
+    return;
   }
   __syncthreads ();                                                      // every lane is done reading hb
-  uint32_t (*fin)[VF_TW] = hb;                                           // unsharp result (8-bit), tile rows only
 #pragma unroll
-  for (int j = 0; j < VF_PER_LANE; j++) {
-    const int i = tid + j * VF_THREADS;
-    fin[i / VF_TW][i % VF_TW] = res[j];
-  }
+  for (int j = 0; j < VF_VRUN; j++) hb[(r0 + j) * VF_HS + col] = res[j];   // unsharp result (8-bit), tile rows only
   __syncthreads ();
   // store epilogue: 2x2 blocks of the tile
   for (int i = tid; i < (VF_TW / 2) * (VF_TH / 2); i += VF_THREADS) {
@@ -269,7 +313,7 @@ __global__ __launch_bounds__ (VF_THREADS, MIN_WAVES) void k_vf_sharp (const VfPa
 #pragma unroll
       for (int dx = 0; dx < 2; dx++) {
         const int lx = min (gx + dx, w - 1) - x0, ly = min (gy + dy, h - 1) - y0;      // edge-clamped duplicates
-        q[dy][dx] = fin[ly][lx];
+        q[dy][dx] = hb[ly * VF_HS + lx];
       }
     metal::store_block (p.out, gx / 2, gy / 2, q);
   }
@@ -297,10 +341,8 @@ static int vf_launch (VfHipVideoFilter *h, const VfHipFrame *in, VfHipFrame *out
   p.u = *prm; p.lut = h->d_lut; p.lut_size = h->lut_size;
   const int w = h->out.width, hh = h->out.height;
   if (prm->sharpness < -0.001f || prm->sharpness > 0.001f) {
-    static const int variant = [] { const char *e = getenv ("VFHIP_VF_TILE"); return e ? atoi (e) : 0; } ();     // tuning knob
-    auto grid = [&] (int tw, int th) { return dim3 ((unsigned) ((w + tw - 1) / tw), (unsigned) ((hh + th - 1) / th), (unsigned) n_frames); };
-    if (variant == 1) hipLaunchKernelGGL ((k_vf_sharp<128, 64, 1024, 4>), grid (128, 64), dim3 (1024), 0, s, p);
-    else hipLaunchKernelGGL ((k_vf_sharp<128, 32, 512, 4>), grid (128, 32), dim3 (512), 0, s, p);
+    dim3 grid ((unsigned) ((w + VF_TW - 1) / VF_TW), (unsigned) ((hh + VF_TH - 1) / VF_TH), (unsigned) n_frames);
+    hipLaunchKernelGGL (k_vf_sharp, grid, dim3 (VF_THREADS), 0, s, p);
   } else {
     const int bw = (w + 1) / 2, bh = (hh + 1) / 2;
     dim3 grid ((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4), (unsigned) n_frames);

@@ -15,6 +15,10 @@
  * against THIS file to +-1 LSB; nothing here has been compared with real Metal output.
  *
  * Built with -ffp-contract=off so that every expression rounds exactly as written (the HIP side does the same).
+ * Multiply-adds that MSL's default fast-math would contract are written as explicit fmaf () — linear interpolation
+ * a + (b - a) * f, the colour matrices, the blur sums, the polynomial steps of vf_powf — in the SAME places on both
+ * sides (csrc/metal_common.h, csrc/videofilter.hip ...), so the two still agree bit for bit: IEEE fma is exact and
+ * deterministic on x86 (vfmadd / glibc) and on gfx950 (v_fma_f32) alike.
  */
 #include "metalref.h"
 #include <math.h>
@@ -27,7 +31,7 @@ static inline float un8 (uint32_t v) { return (float) v * (1.0f / 255.0f); }
 static inline float clamp01 (float x) { return fminf (fmaxf (x, 0.0f), 1.0f); }
 static inline uint32_t quant8 (float x) { return (uint32_t) lrintf (clamp01 (x) * 255.0f); }   /* RNE under the default rounding mode */
 static inline int iclamp (int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-static inline float lerp2 (float a, float b, float f) { return a + (b - a) * f; }
+static inline float lerp2 (float a, float b, float f) { return fmaf (b - a, f, a); }
 static inline uint32_t pack_rgba8 (uint32_t r, uint32_t g, uint32_t b, uint32_t a) { return r | (g << 8) | (b << 16) | (a << 24); }
 static inline uint32_t quant_rgba8 (F4 c) { return pack_rgba8 (quant8 (c.r), quant8 (c.g), quant8 (c.b), quant8 (c.a)); }
 static inline F4 unpack_rgba8 (uint32_t q) { F4 o = { un8 (q & 0xff), un8 ((q >> 8) & 0xff), un8 ((q >> 16) & 0xff), un8 (q >> 24) }; return o; }
@@ -36,14 +40,15 @@ static F4 yuv_to_rgb (float y, float cb, float cr, int m709)
 {
   const float yy = y - 16.0f / 255.0f, u = cb - 128.0f / 255.0f, v = cr - 128.0f / 255.0f;
   F4 o;
+  const float ly = 1.164383f * yy;                       /* the matrices' zero entries contribute nothing (finite inputs) */
   if (m709) {
-    o.r = 1.164383f * yy + 0.0f * u + 1.792741f * v;
-    o.g = 1.164383f * yy + -0.213249f * u + -0.532909f * v;
-    o.b = 1.164383f * yy + 2.112402f * u + 0.0f * v;
+    o.r = fmaf (1.792741f, v, ly);
+    o.g = fmaf (-0.532909f, v, fmaf (-0.213249f, u, ly));
+    o.b = fmaf (2.112402f, u, ly);
   } else {
-    o.r = 1.164383f * yy + 0.0f * u + 1.596027f * v;
-    o.g = 1.164383f * yy + -0.391762f * u + -0.812968f * v;
-    o.b = 1.164383f * yy + 2.017232f * u + 0.0f * v;
+    o.r = fmaf (1.596027f, v, ly);
+    o.g = fmaf (-0.812968f, v, fmaf (-0.391762f, u, ly));
+    o.b = fmaf (2.017232f, u, ly);
   }
   o.r = clamp01 (o.r); o.g = clamp01 (o.g); o.b = clamp01 (o.b); o.a = 1.0f;
   return o;
@@ -52,13 +57,13 @@ static F4 yuv_to_rgb (float y, float cb, float cr, int m709)
 static void rgb_to_yuv (float r, float g, float b, int m709, float *y, float *u, float *v)
 {
   if (m709) {
-    *y = 0.182586f * r + 0.614231f * g + 0.062007f * b + 16.0f / 255.0f;
-    *u = -0.100644f * r + -0.338572f * g + 0.439216f * b + 128.0f / 255.0f;
-    *v = 0.439216f * r + -0.398942f * g + -0.040274f * b + 128.0f / 255.0f;
+    *y = fmaf (0.062007f, b, fmaf (0.614231f, g, 0.182586f * r)) + 16.0f / 255.0f;
+    *u = fmaf (0.439216f, b, fmaf (-0.338572f, g, -0.100644f * r)) + 128.0f / 255.0f;
+    *v = fmaf (-0.040274f, b, fmaf (-0.398942f, g, 0.439216f * r)) + 128.0f / 255.0f;
   } else {
-    *y = 0.256788f * r + 0.504129f * g + 0.097906f * b + 16.0f / 255.0f;
-    *u = -0.148223f * r + -0.290993f * g + 0.439216f * b + 128.0f / 255.0f;
-    *v = 0.439216f * r + -0.367788f * g + -0.071427f * b + 128.0f / 255.0f;
+    *y = fmaf (0.097906f, b, fmaf (0.504129f, g, 0.256788f * r)) + 16.0f / 255.0f;
+    *u = fmaf (0.439216f, b, fmaf (-0.290993f, g, -0.148223f * r)) + 128.0f / 255.0f;
+    *v = fmaf (-0.071427f, b, fmaf (-0.367788f, g, 0.439216f * r)) + 128.0f / 255.0f;
   }
 }
 
@@ -277,12 +282,13 @@ int metalref_deinterlace (const MrImg *cur, const MrImg *prev, const MrImg *out,
 
 /* ---- videofilter -------------------------------------------------------------------------------------- */
 static inline float fractf (float x) { return x - floorf (x); }
-static inline float mixf (float a, float b, float t) { return a + (b - a) * t; }
+static inline float mixf (float a, float b, float t) { return fmaf (b - a, t, a); }
 static inline float stepf (float e, float x) { return x < e ? 0.0f : 1.0f; }
 static inline float smoothstepf (float e0, float e1, float x)
 {
   if (!(e0 < e1)) return stepf (e0, x);                 /* undefined in MSL for e0 >= e1: define as step (Appendix B item 8) */
-  const float t = clamp01 ((x - e0) / (e1 - e0));
+  const float inv = 1.0f / (e1 - e0);                   /* the edges are uniforms: one reciprocal per frame, a multiply per pixel */
+  const float t = clamp01 ((x - e0) * inv);
   return t * t * (3.0f - 2.0f * t);
 }
 static float hash12 (float px, float py, uint32_t frame)
@@ -331,14 +337,14 @@ static inline float vf_powf (float x, float y)
   if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
   const float t = (m - 1.0f) / (m + 1.0f), t2 = t * t;
   float p = 0.11111111f;
-  p = p * t2 + 0.14285714f; p = p * t2 + 0.2f; p = p * t2 + 0.33333333f; p = p * t2 + 1.0f;
-  const float l2 = (float) e + (t * p) * 2.88539008f;        /* 2 / ln 2 */
+  p = fmaf (p, t2, 0.14285714f); p = fmaf (p, t2, 0.2f); p = fmaf (p, t2, 0.33333333f); p = fmaf (p, t2, 1.0f);
+  const float l2 = fmaf (t * p, 2.88539008f, (float) e);     /* 2 / ln 2 */
   const float z = y * l2;
   if (z < -126.0f) return 0.0f;
   const float zi = floorf (z + 0.5f), f = (z - zi) * 0.69314718f;
   float q = 1.98412698e-4f;
-  q = q * f + 1.38888889e-3f; q = q * f + 8.33333333e-3f; q = q * f + 4.16666667e-2f; q = q * f + 0.16666667f;
-  q = q * f + 0.5f; q = q * f + 1.0f; q = q * f + 1.0f;
+  q = fmaf (q, f, 1.38888889e-3f); q = fmaf (q, f, 8.33333333e-3f); q = fmaf (q, f, 4.16666667e-2f); q = fmaf (q, f, 0.16666667f);
+  q = fmaf (q, f, 0.5f); q = fmaf (q, f, 1.0f); q = fmaf (q, f, 1.0f);
   uint32_t uq; memcpy (&uq, &q, 4);
   uq += (uint32_t) ((int) zi << 23);
   float r; memcpy (&r, &uq, 4);
@@ -349,8 +355,8 @@ static F4 color_adjust (F4 c, const MrFilterParams *u, float tu, float tv, int W
 {
   float r = c.r, g = c.g, b = c.b, a = c.a;
   r += u->brightness; g += u->brightness; b += u->brightness;
-  r = (r - 0.5f) * u->contrast + 0.5f; g = (g - 0.5f) * u->contrast + 0.5f; b = (b - 0.5f) * u->contrast + 0.5f;
-  const float lum = r * 0.2126f + g * 0.7152f + b * 0.0722f;
+  r = fmaf (r - 0.5f, u->contrast, 0.5f); g = fmaf (g - 0.5f, u->contrast, 0.5f); b = fmaf (b - 0.5f, u->contrast, 0.5f);
+  const float lum = fmaf (b, 0.0722f, fmaf (g, 0.7152f, r * 0.2126f));
   r = mixf (lum, r, u->saturation); g = mixf (lum, g, u->saturation); b = mixf (lum, b, u->saturation);
   if (fabsf (u->hue) > 0.001f) {
     float h, s, v;
@@ -359,11 +365,12 @@ static F4 color_adjust (F4 c, const MrFilterParams *u, float tu, float tv, int W
     hsv_to_rgb (h, s, v, &r, &g, &b);
   }
   const float ig = 1.0f / u->gamma;
-  r = vf_powf (fminf (fmaxf (r, 0.0001f), 1.0f), ig); g = vf_powf (fminf (fmaxf (g, 0.0001f), 1.0f), ig); b = vf_powf (fminf (fmaxf (b, 0.0001f), 1.0f), ig);
+  r = fminf (fmaxf (r, 0.0001f), 1.0f); g = fminf (fmaxf (g, 0.0001f), 1.0f); b = fminf (fmaxf (b, 0.0001f), 1.0f);
+  if (ig != 1.0f) { r = vf_powf (r, ig); g = vf_powf (g, ig); b = vf_powf (b, ig); }      /* pow (x, 1) == x exactly */
   if (u->sepia > 0.001f) {
-    const float sr = r * 0.393f + g * 0.769f + b * 0.189f;
-    const float sg = r * 0.349f + g * 0.686f + b * 0.168f;
-    const float sb = r * 0.272f + g * 0.534f + b * 0.131f;
+    const float sr = fmaf (b, 0.189f, fmaf (g, 0.769f, r * 0.393f));
+    const float sg = fmaf (b, 0.168f, fmaf (g, 0.686f, r * 0.349f));
+    const float sb = fmaf (b, 0.131f, fmaf (g, 0.534f, r * 0.272f));
     r = mixf (r, sr, u->sepia); g = mixf (g, sg, u->sepia); b = mixf (b, sb, u->sepia);
   }
   if (u->invert) { r = 1.0f - r; g = 1.0f - g; b = 1.0f - b; }
@@ -429,7 +436,7 @@ int metalref_videofilter (const MrImg *in, const MrImg *out, const MrFilterParam
           for (int i = 0; i < 9; i++) {
             const int xx = pass == 0 ? iclamp (x + i - 4, 0, w - 1) : x, yy = pass == 0 ? y : iclamp (y + i - 4, 0, h - 1);
             const F4 c = unpack_rgba8 (src[(size_t) yy * w + xx]);
-            s.r += c.r * kBlurW[i]; s.g += c.g * kBlurW[i]; s.b += c.b * kBlurW[i]; s.a += c.a * kBlurW[i];
+            s.r = fmaf (c.r, kBlurW[i], s.r); s.g = fmaf (c.g, kBlurW[i], s.g); s.b = fmaf (c.b, kBlurW[i], s.b); s.a = fmaf (c.a, kBlurW[i], s.a);
           }
           dst[(size_t) y * w + x] = quant_rgba8 (s);
         }
@@ -439,7 +446,7 @@ int metalref_videofilter (const MrImg *in, const MrImg *out, const MrFilterParam
       const F4 o = unpack_rgba8 (rt[i]), b = unpack_rgba8 (t2[i]);
       F4 r;
       if (amount > 0.0f) {
-        r.r = clamp01 (o.r + (o.r - b.r) * amount); r.g = clamp01 (o.g + (o.g - b.g) * amount); r.b = clamp01 (o.b + (o.b - b.b) * amount);
+        r.r = clamp01 (fmaf (o.r - b.r, amount, o.r)); r.g = clamp01 (fmaf (o.g - b.g, amount, o.g)); r.b = clamp01 (fmaf (o.b - b.b, amount, o.b));
       } else {
         const float t = fabsf (amount);
         r.r = mixf (o.r, b.r, t); r.g = mixf (o.g, b.g, t); r.b = mixf (o.b, b.b, t);
