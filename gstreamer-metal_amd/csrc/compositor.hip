@@ -81,26 +81,32 @@ __device__ __forceinline__ uint32_t comp_blend (const CompLayer &L, F4 s, uint32
   F4 o;
   if (L.blend == VFHIP_BLEND_SOURCE) o = s;
   else if (L.blend == VFHIP_BLEND_ADD) { o.r = s.r + d.r; o.g = s.g + d.g; o.b = s.b + d.b; o.a = s.a + d.a; }
-  else { const float k1 = 1.0f - s.a; o.r = s.r + d.r * k1; o.g = s.g + d.g * k1; o.b = s.b + d.b * k1; o.a = s.a + d.a * k1; }
+  else { const float k1 = 1.0f - s.a; o.r = fmaf (d.r, k1, s.r); o.g = fmaf (d.g, k1, s.g); o.b = fmaf (d.b, k1, s.b); o.a = fmaf (d.a, k1, s.a); }
   return metal::quant_rgba8 (o);
 }
 
-typedef uint2 __attribute__ ((aligned (4))) uint2_a4;
+typedef uint4 __attribute__ ((aligned (4))) uint4_a4;
 
-// Workgroup = 64 x 4 lanes, one lane = a 2x2 block of output pixels, so a wave covers a 128 x 2 pixel strip.  Layers are
-// the OUTER loop: a layer's parameters are fetched once per wave (scalar loads), a layer that misses the wave's strip is
-// skipped by a wave-uniform branch, and the four pixels of a lane are blended in the same trip (the first version looped
-// over the layers per pixel: 4x the scalar traffic and no culling).
+// Workgroup = 64 x 4 lanes; one lane = a 4 x 2 block of output pixels (two of the store epilogue's 2x2 blocks), so a wave
+// covers a 256 x 2 pixel strip and a lane carries eight independent blend chains (the first versions — one pixel, then
+// a 2x2 block per lane — were latency-bound: ~40 % VALU-busy with one dependent load -> blend chain per layer).
+// Layers are the OUTER loop: a layer's parameters are fetched once per wave (scalar loads) and a layer that misses the
+// wave's strip is skipped by a wave-uniform branch.  An unscaled RGBA / BGRA pad that covers all four columns of a lane
+// is fetched as ONE 16-byte load per row; RGBA / BGRA outputs leave as one 16-byte non-temporal store per row.
 __global__ __launch_bounds__ (256) void k_compositor (const CompParams p)
 {
-  const int bx = blockIdx.x * 64 + threadIdx.x;
+  const int bx = blockIdx.x * 64 + threadIdx.x;                                               // 4-pixel column group
   const int by = __builtin_amdgcn_readfirstlane ((int) (blockIdx.y * 4 + threadIdx.y));      // one row of lanes = one wave
   if (2 * by >= p.out.h) return;
-  const bool live = 2 * bx < p.out.w;
-  const int x0 = min (2 * bx, p.out.w - 1), x1 = min (2 * bx + 1, p.out.w - 1);
+  const bool live = 4 * bx < p.out.w;
+  int xs[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) xs[i] = min (4 * bx + i, p.out.w - 1);
   const int y0 = 2 * by, y1 = min (2 * by + 1, p.out.h - 1);
-  uint32_t q[2][2] = { { comp_background (p, x0, y0), comp_background (p, x1, y0) }, { comp_background (p, x0, y1), comp_background (p, x1, y1) } };
-  const int wx0 = (int) blockIdx.x * 128, wx1 = wx0 + 128;
+  uint32_t q[2][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) { q[0][i] = comp_background (p, xs[i], y0); q[1][i] = comp_background (p, xs[i], y1); }
+  const int wx0 = (int) blockIdx.x * 256, wx1 = wx0 + 256;
   const unsigned z = blockIdx.z;
   for (int k = 0; k < p.n; k++) {
     const CompLayer &L = p.layer[k];
@@ -108,30 +114,84 @@ __global__ __launch_bounds__ (256) void k_compositor (const CompParams p)
     const int lx1 = L.xpos + L.width, ly1 = L.ypos + L.height;
     if (wx1 <= L.xpos || wx0 >= lx1 || y1 < L.ypos || y0 >= ly1) continue;                   // wave-uniform
     const metal::Img im = metal::img_at (L.img, z * L.pitch);
-    const bool cx0 = x0 >= L.xpos && x0 < lx1, cx1 = x1 >= L.xpos && x1 < lx1;
+    bool cx[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) cx[i] = xs[i] >= L.xpos && xs[i] < lx1;
     const bool cy0 = y0 >= L.ypos && y0 < ly1, cy1 = y1 >= L.ypos && y1 < ly1;
     const bool rgba_in = im.fmt == VFHIP_FORMAT_RGBA;
-    // unscaled RGBA / BGRA pad with both pixels of the pair inside: their texels are 8 adjacent bytes -> one load per row
-    const bool pair = cx0 && cx1 && x1 == x0 + 1 && (rgba_in || im.fmt == VFHIP_FORMAT_BGRA) && L.width == L.img.w && L.height == L.img.h;
-    if (pair) {
+    const bool quad = cx[0] && cx[3] && xs[3] == xs[0] + 3 && (rgba_in || im.fmt == VFHIP_FORMAT_BGRA) && L.width == L.img.w && L.height == L.img.h;
+    if (quad) {
+      uint4 t[2];
+#pragma unroll
+      for (int r = 0; r < 2; r++)                       // both rows' loads first, then the eight blends
+        if (r ? cy1 : cy0) t[r] = *reinterpret_cast<const uint4_a4 *> (im.p[0] + (size_t) ((r ? y1 : y0) - L.ypos) * im.s[0] + 4 * (xs[0] - L.xpos));
 #pragma unroll
       for (int r = 0; r < 2; r++) {
-        const int y = r ? y1 : y0;
         if (!(r ? cy1 : cy0)) continue;
-        const uint2 t = *reinterpret_cast<const uint2_a4 *> (im.p[0] + (size_t) (y - L.ypos) * im.s[0] + 4 * (x0 - L.xpos));
-        q[r][0] = comp_blend (L, comp_texel (t.x, rgba_in), q[r][0]);
-        q[r][1] = comp_blend (L, comp_texel (t.y, rgba_in), q[r][1]);
+        q[r][0] = comp_blend (L, comp_texel (t[r].x, rgba_in), q[r][0]);
+        q[r][1] = comp_blend (L, comp_texel (t[r].y, rgba_in), q[r][1]);
+        q[r][2] = comp_blend (L, comp_texel (t[r].z, rgba_in), q[r][2]);
+        q[r][3] = comp_blend (L, comp_texel (t[r].w, rgba_in), q[r][3]);
+      }
+    } else if (cx[0] && cx[3] && xs[3] == xs[0] + 3 && cy0 && cy1 && y1 == y0 + 1 && (im.fmt == VFHIP_FORMAT_NV12 || im.fmt == VFHIP_FORMAT_I420) &&
+               L.width == L.img.w && L.height == L.img.h && !(((xs[0] - L.xpos) | (y0 - L.ypos)) & 1)) {
+      // unscaled 4:2:0 pad whose chroma grid is aligned with the lane's 4 x 2 block: the 8 pixels share 3 chroma rows x 4 chroma
+      // columns.  fetch_1to1's bilinear chroma (phases .25 / .75) from 12 (U, V) fetches + 2 luma dwords instead of 72 byte loads,
+      // the horizontal interpolation of the middle chroma row shared by both pixel rows.  Same operations per value as
+      // metal::fetch_1to1 / plane_taps, so the result is bit-identical to the general path.
+      const int px = xs[0] - L.xpos, py = y0 - L.ypos, j = px >> 1, m = py >> 1;
+      const int cw = (im.w + 1) >> 1, chh = (im.h + 1) >> 1;
+      typedef uint32_t __attribute__ ((aligned (1))) u32_any;
+      typedef uint16_t __attribute__ ((aligned (1))) u16_any;
+      uint32_t Y[2];
+      Y[0] = *reinterpret_cast<const u32_any *> (im.p[0] + (size_t) py * im.s[0] + px);
+      Y[1] = *reinterpret_cast<const u32_any *> (im.p[0] + (size_t) (py + 1) * im.s[0] + px);
+      float cu[3][4], cv[3][4];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const int row = metal::iclamp (m - 1 + r, 0, chh - 1);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const int col = metal::iclamp (j - 1 + c, 0, cw - 1);
+          if (im.fmt == VFHIP_FORMAT_NV12) {
+            const uint32_t uv = *reinterpret_cast<const u16_any *> (im.p[1] + (size_t) row * im.s[1] + 2 * col);
+            cu[r][c] = metal::un8 (uv & 0xffu); cv[r][c] = metal::un8 (uv >> 8);
+          } else {
+            cu[r][c] = metal::un8 (im.p[1][(size_t) row * im.s[1] + col]); cv[r][c] = metal::un8 (im.p[2][(size_t) row * im.s[2] + col]);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        // pixel px + i samples chroma at 0.5 (px + i) - 0.25: taps (j - 1 + (i + 1) / 2 ...), weight .75 for even i, .25 for odd i
+        const int a = (i + 1) >> 1;                          // index of the first tap in cu[][0..3]: i = 0 -> 0, 1 -> 1, 2 -> 1, 3 -> 2
+        const float fx = (i & 1) ? 0.25f : 0.75f;
+        float hu[3], hv[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) { hu[r] = metal::lerp2 (cu[r][a], cu[r][a + 1], fx); hv[r] = metal::lerp2 (cv[r][a], cv[r][a + 1], fx); }
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          const float fy = r ? 0.25f : 0.75f;
+          const float cb = metal::lerp2 (hu[r], hu[r + 1], fy), cr = metal::lerp2 (hv[r], hv[r + 1], fy);
+          const F4 c = metal::yuv_to_rgb (metal::un8 ((Y[r] >> (8 * i)) & 0xffu), cb, cr, im.m709);
+          q[r][i] = comp_blend (L, c, q[r][i]);
+        }
       }
     } else {
-      // general path (scaled pads, 4:2:0 pads, quad edges): ONE instance of the sampler, the four pixels take turns
-      // (unrolled, the four inlined samplers push the kernel to 132 VGPRs = 3 waves per SIMD)
+      // general path (scaled pads, 4:2:0 pads off the chroma grid, quad edges): ONE instance of the sampler, the eight pixels take turns
+      // (unrolled, the inlined samplers cost > 128 VGPRs)
 #pragma unroll 1
-      for (int i = 0; i < 4; i++) {
-        const bool c = i & 1, r = i >> 1;
-        if (!((c ? cx1 : cx0) && (r ? cy1 : cy0))) continue;
-        const uint32_t cur = r ? (c ? q[1][1] : q[1][0]) : (c ? q[0][1] : q[0][0]);
-        const uint32_t v = comp_blend (L, comp_sample (L, im, c ? x1 : x0, r ? y1 : y0), cur);
-        q[0][0] = i == 0 ? v : q[0][0]; q[0][1] = i == 1 ? v : q[0][1]; q[1][0] = i == 2 ? v : q[1][0]; q[1][1] = i == 3 ? v : q[1][1];
+      for (int i = 0; i < 8; i++) {
+        const int c = i & 3, r = i >> 2;
+        const bool cxi = c == 0 ? cx[0] : (c == 1 ? cx[1] : (c == 2 ? cx[2] : cx[3]));
+        if (!(cxi && (r ? cy1 : cy0))) continue;
+        const int xi = c == 0 ? xs[0] : (c == 1 ? xs[1] : (c == 2 ? xs[2] : xs[3]));
+        uint32_t cur = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) cur = i == j ? q[j >> 2][j & 3] : cur;
+        const uint32_t v = comp_blend (L, comp_sample (L, im, xi, r ? y1 : y0), cur);
+#pragma unroll
+        for (int j = 0; j < 8; j++) q[j >> 2][j & 3] = i == j ? v : q[j >> 2][j & 3];
       }
     }
   }
@@ -140,11 +200,31 @@ __global__ __launch_bounds__ (256) void k_compositor (const CompParams p)
 #pragma unroll
     for (int dy = 0; dy < 2; dy++)
 #pragma unroll
-      for (int dx = 0; dx < 2; dx++)
-        if (2 * bx + dx < p.out.w && 2 * by + dy < p.out.h) p.scratch[(size_t) (2 * by + dy) * p.scratch_stride + 2 * bx + dx] = q[dy][dx];
+      for (int dx = 0; dx < 4; dx++)
+        if (4 * bx + dx < p.out.w && 2 * by + dy < p.out.h) p.scratch[(size_t) (2 * by + dy) * p.scratch_stride + 4 * bx + dx] = q[dy][dx];
     return;
   }
-  metal::store_block (metal::out_at (p.out, z * p.out_pitch), bx, by, q);
+  const metal::OutImg o = metal::out_at (p.out, z * p.out_pitch);
+  if ((o.fmt == VFHIP_FORMAT_BGRA || o.fmt == VFHIP_FORMAT_RGBA) && 4 * bx + 3 < o.w && !(((uintptr_t) o.p[0] | (uintptr_t) o.s[0]) & 15)) {
+    typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
+#pragma unroll
+    for (int dy = 0; dy < 2; dy++) {
+      if (2 * by + dy >= o.h) break;
+      v4u v = { q[dy][0], q[dy][1], q[dy][2], q[dy][3] };
+      if (o.fmt == VFHIP_FORMAT_BGRA) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = __builtin_amdgcn_perm (0u, v[i], 0x03000102u);     // swap bytes 0 and 2
+      }
+      __builtin_nontemporal_store (v, reinterpret_cast<v4u *> (o.p[0] + (size_t) (2 * by + dy) * o.s[0]) + bx);
+    }
+    return;
+  }
+  const uint32_t qa[2][2] = { { q[0][0], q[0][1] }, { q[1][0], q[1][1] } };
+  metal::store_block (o, 2 * bx, by, qa);
+  if (4 * bx + 2 < o.w) {
+    const uint32_t qb[2][2] = { { q[0][2], q[0][3] }, { q[1][2], q[1][3] } };
+    metal::store_block (o, 2 * bx + 1, by, qb);
+  }
 }
 
 }  // namespace vfhip
@@ -163,7 +243,7 @@ static int comp_launch (VfHipCompositor *h, const VfHipPadInput *pads, int count
     int n_frames = 1, const size_t *pad_pitch = nullptr, size_t out_pitch = 0)
 {
   const int w = h->out.width, hh = h->out.height;
-  const int bw = (w + 1) / 2, bh = (hh + 1) / 2;
+  const int bw = (w + 3) / 4, bh = (hh + 1) / 2;             // lanes: 4 x 2 pixel blocks
   dim3 grid ((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4), (unsigned) n_frames);
   const int passes = count <= COMP_MAX_LAYERS ? 1 : (count + COMP_MAX_LAYERS - 1) / COMP_MAX_LAYERS;
   if (passes > 1)

@@ -8,6 +8,8 @@
 // and the history is the previous INPUT frame in its native format (12.4 MB for NV12 2160p instead of 33 MB).
 #include "vfhip_internal.h"
 #include "metal_common.h"
+#include <cmath>
+#include <cstdlib>
 
 using namespace vfhip;
 
@@ -168,6 +170,172 @@ __global__ __launch_bounds__ (256) void k_deinterlace_420 (const DeintParams pp)
   }
 }
 
+// ---- 4:2:0 in and out, width % 4 == 0, even height: four pixels per lane, float intermediates ------------------------
+// k_deinterlace_420q.  Same values as the kernels above (and as the reference's three passes), organised for the
+// machine: a lane owns FOUR adjacent pixels (one dword of luma, two chroma columns) and walks a strip of rows in pairs.
+//   * The reference's 8-bit RGBA intermediate lives in registers as the float an 8-bit texel reads back as — byte / 255
+//     with the byte obtained by x255, round-to-nearest-even (`quantf`) — so nothing is packed to bytes and unpacked again
+//     between the input pass, the method pass and the RGB -> YUV pass (each row used to be unpacked up to three times).
+//   * Every source row is converted once per strip and carried as the above / below tap of its neighbours.
+//   * greedy-H compares the squared distance with the smallest float whose correctly rounded square root reaches the
+//     threshold (computed on the host: `motion2_limit`), which decides exactly like sqrt (d2) < threshold without the
+//     square root.
+//   * Dword loads / stores on luma and on NV12 chroma, 32-bit offsets from wave-uniform plane bases.
+struct Rgb4 { float r[4], g[4], b[4]; };
+// the two matrices of metal_common.h as wave-uniform coefficient sets (selected once per kernel: no per-pixel branch on m709)
+struct YuvCoef { float rv, gu, gv, bu; };
+struct RgbCoef { float yr, yg, yb, ur, ug, ub, vr, vg, vb; };
+__device__ __forceinline__ YuvCoef yuv_coef (int m709)
+{
+  YuvCoef k;
+  k.rv = m709 ? 1.792741f : 1.596027f; k.gu = m709 ? -0.213249f : -0.391762f; k.gv = m709 ? -0.532909f : -0.812968f; k.bu = m709 ? 2.112402f : 2.017232f;
+  return k;
+}
+__device__ __forceinline__ RgbCoef rgb_coef (int m709)
+{
+  RgbCoef k;
+  k.yr = m709 ? 0.182586f : 0.256788f; k.yg = m709 ? 0.614231f : 0.504129f; k.yb = m709 ? 0.062007f : 0.097906f;
+  k.ur = m709 ? -0.100644f : -0.148223f; k.ug = m709 ? -0.338572f : -0.290993f; k.ub = 0.439216f;
+  k.vr = 0.439216f; k.vg = m709 ? -0.398942f : -0.367788f; k.vb = m709 ? -0.040274f : -0.071427f;
+  return k;
+}
+
+__device__ __forceinline__ float quantf (float x)        // what an 8-bit unorm texel written with x reads back as
+{
+  return __builtin_rintf (metal::clamp01 (x) * 255.0f) * (1.0f / 255.0f);
+}
+
+template <bool PLANAR>
+__device__ __forceinline__ Rgb4 deint_row4 (const uint8_t *yp, const uint8_t *up, const uint8_t *vp, uint32_t ys, uint32_t cs, const YuvCoef &k, uint32_t q, int y)
+{
+  const uint32_t Y4 = *reinterpret_cast<const uint32_t *> (yp + (__umul24 ((uint32_t) y, ys) + 4u * q));
+  uint32_t U0, V0, U1, V1;
+  if (PLANAR) {
+    const uint32_t co = __umul24 ((uint32_t) (y >> 1), cs) + 2u * q;
+    const uint32_t u2 = *reinterpret_cast<const uint16_t *> (up + co), v2 = *reinterpret_cast<const uint16_t *> (vp + co);
+    U0 = u2 & 0xffu; U1 = u2 >> 8; V0 = v2 & 0xffu; V1 = v2 >> 8;
+  } else {
+    const uint32_t c4 = *reinterpret_cast<const uint32_t *> (up + (__umul24 ((uint32_t) (y >> 1), cs) + 4u * q));
+    U0 = c4 & 0xffu; V0 = (c4 >> 8) & 0xffu; U1 = (c4 >> 16) & 0xffu; V1 = c4 >> 24;
+  }
+  const float cb[2] = { metal::un8 (U0), metal::un8 (U1) }, cr[2] = { metal::un8 (V0), metal::un8 (V1) };
+  Rgb4 o;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    // metal::yuv_to_rgb with the coefficients in registers (same operations, same order)
+    const float ly = 1.164383f * (metal::un8 ((Y4 >> (8 * i)) & 0xffu) - 16.0f / 255.0f);
+    const float u = cb[i >> 1] - 128.0f / 255.0f, v = cr[i >> 1] - 128.0f / 255.0f;
+    o.r[i] = quantf (fmaf (k.rv, v, ly)); o.g[i] = quantf (fmaf (k.gv, v, fmaf (k.gu, u, ly))); o.b[i] = quantf (fmaf (k.bu, u, ly));
+  }
+  return o;
+}
+
+// rows y (o0) and y+1 (o1) of one lane's four columns -> NV12 / I420 (the reference's rgbaToNV12 / rgbaToI420 pass:
+// luma per pixel, chroma from the mean of each 2x2 block, summed in the reference's order)
+template <bool PLANAR>
+__device__ __forceinline__ void deint_store4 (const metal::OutImg &o, const RgbCoef &k, uint32_t q, int y, const Rgb4 &o0, const Rgb4 &o1)
+{
+  uint32_t l0 = 0, l1 = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    // metal::rgb_to_yuv (luma row), coefficients in registers
+    const float Y0 = fmaf (k.yb, o0.b[i], fmaf (k.yg, o0.g[i], k.yr * o0.r[i])) + 16.0f / 255.0f;
+    const float Y1 = fmaf (k.yb, o1.b[i], fmaf (k.yg, o1.g[i], k.yr * o1.r[i])) + 16.0f / 255.0f;
+    l0 = __builtin_amdgcn_cvt_pk_u8_f32 (Y0 * 255.0f, (uint32_t) i, l0);
+    l1 = __builtin_amdgcn_cvt_pk_u8_f32 (Y1 * 255.0f, (uint32_t) i, l1);
+  }
+  const uint32_t lo = __umul24 ((uint32_t) y, (uint32_t) o.s[0]) + 4u * q;
+  __builtin_nontemporal_store (l0, reinterpret_cast<uint32_t *> (o.p[0] + lo));
+  __builtin_nontemporal_store (l1, reinterpret_cast<uint32_t *> (o.p[0] + (lo + (uint32_t) o.s[0])));
+  uint32_t uu[2], vv[2];
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    float sr = 0.0f, sg = 0.0f, sb = 0.0f;
+    sr += o0.r[2 * c]; sg += o0.g[2 * c]; sb += o0.b[2 * c];
+    sr += o0.r[2 * c + 1]; sg += o0.g[2 * c + 1]; sb += o0.b[2 * c + 1];
+    sr += o1.r[2 * c]; sg += o1.g[2 * c]; sb += o1.b[2 * c];
+    sr += o1.r[2 * c + 1]; sg += o1.g[2 * c + 1]; sb += o1.b[2 * c + 1];
+    sr *= 0.25f; sg *= 0.25f; sb *= 0.25f;
+    const float U = fmaf (k.ub, sb, fmaf (k.ug, sg, k.ur * sr)) + 128.0f / 255.0f;
+    const float V = fmaf (k.vb, sb, fmaf (k.vg, sg, k.vr * sr)) + 128.0f / 255.0f;
+    uu[c] = metal::quant8 (U); vv[c] = metal::quant8 (V);
+  }
+  if (PLANAR) {
+    const uint32_t co = __umul24 ((uint32_t) (y >> 1), (uint32_t) o.s[1]) + 2u * q;
+    *reinterpret_cast<uint16_t *> (o.p[1] + co) = (uint16_t) (uu[0] | (uu[1] << 8));
+    *reinterpret_cast<uint16_t *> (o.p[2] + (__umul24 ((uint32_t) (y >> 1), (uint32_t) o.s[2]) + 2u * q)) = (uint16_t) (vv[0] | (vv[1] << 8));
+  } else {
+    const uint32_t co = __umul24 ((uint32_t) (y >> 1), (uint32_t) o.s[1]) + 4u * q;
+    __builtin_nontemporal_store (uu[0] | (vv[0] << 8) | (uu[1] << 16) | (vv[1] << 24), reinterpret_cast<uint32_t *> (o.p[1] + co));
+  }
+}
+
+// the reconstructed line: own pixel `cur`, its neighbours in the kept field, the previous frame's pixel
+template <int METHOD>
+__device__ __forceinline__ Rgb4 deint_recon4 (const Rgb4 &cur, const Rgb4 &above, const Rgb4 &below, const Rgb4 &prev, float m2_limit)
+{
+  if (METHOD == VFHIP_DEINTERLACE_WEAVE) return prev;
+  Rgb4 o;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float br = quantf ((above.r[i] + below.r[i]) * 0.5f), bg = quantf ((above.g[i] + below.g[i]) * 0.5f), bb = quantf ((above.b[i] + below.b[i]) * 0.5f);
+    bool still = false;                                   // greedy-H: no motion against the previous frame -> weave (selects, no divergent branch)
+    if (METHOD == VFHIP_DEINTERLACE_GREEDYH) {
+      const float dr = cur.r[i] - prev.r[i], dg = cur.g[i] - prev.g[i], db = cur.b[i] - prev.b[i];
+      still = dr * dr + dg * dg + db * db < m2_limit;
+    }
+    o.r[i] = still ? prev.r[i] : br; o.g[i] = still ? prev.g[i] : bg; o.b[i] = still ? prev.b[i] : bb;
+  }
+  return o;
+}
+
+constexpr int DEINTQ_ROWS = 8;
+
+template <bool PLANAR, bool TFF, int METHOD>
+__global__ __launch_bounds__ (256) void k_deinterlace_420q (const DeintParams pp, float m2_limit)
+{
+  const DeintParams p = deint_frame (pp, blockIdx.y);
+  const int quads = p.out.w >> 2, h = p.out.h;
+  const int strips = (h + DEINTQ_ROWS - 1) / DEINTQ_ROWS;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= quads * strips) return;
+  const int strip = t / quads;
+  const uint32_t q = (uint32_t) (t - strip * quads);
+  const int y0 = strip * DEINTQ_ROWS, yend = min (y0 + DEINTQ_ROWS, h);
+  constexpr bool NEED_PREV = METHOD == VFHIP_DEINTERLACE_WEAVE || METHOD == VFHIP_DEINTERLACE_GREEDYH;
+  // frame 0 of a stream (or of a batch on a fresh handle) has no history: weave / greedy-H fall back to bob for that frame
+  // only (wave-uniform: blockIdx.y picks the frame), the rest of the batch uses its predecessor in the batch
+  const bool hist = p.prev.p[0] != nullptr;
+  const uint8_t *cy = p.cur.p[0], *cu = p.cur.p[1], *cv = p.cur.p[2];
+  const uint8_t *py = p.prev.p[0], *pu = p.prev.p[1], *pv = p.prev.p[2];
+  const uint32_t ys = (uint32_t) p.cur.s[0], cs = (uint32_t) p.cur.s[1], pys = (uint32_t) p.prev.s[0], pcs = (uint32_t) p.prev.s[1];
+  const YuvCoef kc = yuv_coef (p.cur.m709), kp = yuv_coef (p.prev.m709);
+  const RgbCoef ko = rgb_coef (p.out.m709);
+  // TFF: even rows are kept, odd rows reconstructed from the kept rows above (y) and below (y + 2);
+  // BFF: odd rows are kept, even rows reconstructed from the kept rows above (y - 1) and below (y + 1).
+  Rgb4 carry = deint_row4<PLANAR> (cy, cu, cv, ys, cs, kc, q, TFF ? y0 : max (y0 - 1, 0));
+  for (int y = y0; y < yend; y += 2) {
+    Rgb4 prev {};
+    if (TFF) {
+      const Rgb4 cur = deint_row4<PLANAR> (cy, cu, cv, ys, cs, kc, q, y + 1);
+      const Rgb4 below = deint_row4<PLANAR> (cy, cu, cv, ys, cs, kc, q, min (y + 2, h - 1));
+      if (NEED_PREV && hist) prev = deint_row4<PLANAR> (py, pu, pv, pys, pcs, kp, q, y + 1);
+      const Rgb4 rec = (!NEED_PREV || hist) ? deint_recon4<METHOD> (cur, carry, below, prev, m2_limit)
+                                            : deint_recon4<VFHIP_DEINTERLACE_BOB> (cur, carry, below, prev, m2_limit);
+      deint_store4<PLANAR> (p.out, ko, q, y, carry, rec);
+      carry = below;
+    } else {
+      const Rgb4 cur = deint_row4<PLANAR> (cy, cu, cv, ys, cs, kc, q, y);
+      const Rgb4 kept = deint_row4<PLANAR> (cy, cu, cv, ys, cs, kc, q, y + 1);
+      if (NEED_PREV && hist) prev = deint_row4<PLANAR> (py, pu, pv, pys, pcs, kp, q, y);
+      const Rgb4 rec = (!NEED_PREV || hist) ? deint_recon4<METHOD> (cur, carry, kept, prev, m2_limit)
+                                            : deint_recon4<VFHIP_DEINTERLACE_BOB> (cur, carry, kept, prev, m2_limit);
+      deint_store4<PLANAR> (p.out, ko, q, y, rec, kept);
+      carry = kept;
+    }
+  }
+}
+
 }  // namespace vfhip
 
 struct VfHipDeinterlace {
@@ -186,6 +354,39 @@ struct VfHipDeinterlace {
   int hist_cur = 0;
 };
 
+// smallest float d with sqrtf (d) >= thr: (sqrtf (m2) < thr) == (m2 < d) for every m2 >= 0, because the correctly rounded
+// square root is monotone.  thr <= 0 -> 0 (never below), NaN -> NaN (never below), beyond sqrt (FLT_MAX) -> +inf.
+static float motion2_limit (float thr)
+{
+  if (!(thr > 0.0f)) return thr != thr ? thr : 0.0f;
+  float d = thr * thr;
+  if (std::isinf (d)) return d;
+  while (d > 0.0f && sqrtf (d) >= thr) d = nextafterf (d, 0.0f);
+  while (sqrtf (d) < thr) d = nextafterf (d, INFINITY);
+  return d;
+}
+
+// k_deinterlace_420q's contract: 4:2:0 frame, width % 4 == 0, even height, every plane (and the batch pitches) aligned
+// for the dword / 16-bit accesses it makes
+static bool deint_quad_ok (const VfHipVideoInfo &info, const VfHipFrame *cur, const VfHipFrame *prev, const VfHipFrame *out, size_t in_pitch, size_t out_pitch)
+{
+  static const bool enabled = [] { const char *e = getenv ("VFHIP_DEINT_QUAD"); return !e || atoi (e) != 0; } ();     // test / A-B knob
+  if (!enabled) return false;
+  const bool nv12 = info.format == VFHIP_FORMAT_NV12, i420 = info.format == VFHIP_FORMAT_I420;
+  if (!(nv12 || i420) || (info.width & 3) || (info.height & 1) || info.width < 4 || info.height < 2) return false;
+  if ((in_pitch | out_pitch) & 3) return false;
+  auto ok = [&] (const VfHipFrame *f) {
+    if (!f) return true;
+    if (((uintptr_t) f->data[0] | (uintptr_t) f->stride[0]) & 3) return false;
+    const uintptr_t cm = nv12 ? 3 : 1;
+    if (((uintptr_t) f->data[1] | (uintptr_t) f->stride[1]) & cm) return false;
+    if (i420 && (((uintptr_t) f->data[2] | (uintptr_t) f->stride[2]) & 1)) return false;
+    if (i420 && f->stride[1] != f->stride[2]) return false;       // one chroma offset serves U and V on the input side
+    return true;
+  };
+  return ok (cur) && ok (prev) && ok (out);
+}
+
 static int deint_launch (VfHipDeinterlace *h, const VfHipFrame *cur, const VfHipFrame *prev, VfHipFrame *out,
     const VfHipDeinterlaceParams *prm, hipStream_t s, int n_frames = 1, size_t in_pitch = 0, size_t out_pitch = 0)
 {
@@ -196,7 +397,23 @@ static int deint_launch (VfHipDeinterlace *h, const VfHipFrame *cur, const VfHip
   p.out = metal::make_out (out);
   p.method = prm->method; p.tff = prm->top_field_first != 0; p.threshold = prm->motion_threshold;
   const int bw = (h->info.width + 1) / 2, bh = (h->info.height + 1) / 2;
-  if (h->info.format == VFHIP_FORMAT_NV12 || h->info.format == VFHIP_FORMAT_I420) {
+  if (deint_quad_ok (h->info, cur, prev, out, in_pitch, out_pitch)) {
+    // the whole frame in dwords: k_deinterlace_420q, one instantiation per (layout, field order, method)
+    int method = p.method;
+    if ((method == VFHIP_DEINTERLACE_WEAVE || method == VFHIP_DEINTERLACE_GREEDYH) && !p.prev.p[0] && n_frames == 1) method = VFHIP_DEINTERLACE_BOB;   // no history at all
+    if (method == VFHIP_DEINTERLACE_LINEAR) method = VFHIP_DEINTERLACE_BOB;                    // the reference's linear IS bob (shaders.h:134-148)
+    const int strips = (h->info.height + DEINTQ_ROWS - 1) / DEINTQ_ROWS;
+    dim3 grid ((unsigned) (((size_t) (h->info.width / 4) * strips + 255) / 256), (unsigned) n_frames);
+    const float lim = motion2_limit (p.threshold);
+    const bool planar = h->info.format == VFHIP_FORMAT_I420;
+#define VF_DQ(PL, TF, M) hipLaunchKernelGGL ((k_deinterlace_420q<PL, TF, M>), grid, dim3 (256), 0, s, p, lim)
+#define VF_DQ_M(PL, TF) do { if (method == VFHIP_DEINTERLACE_BOB) VF_DQ (PL, TF, VFHIP_DEINTERLACE_BOB); else if (method == VFHIP_DEINTERLACE_WEAVE) VF_DQ (PL, TF, VFHIP_DEINTERLACE_WEAVE); \
+                              else VF_DQ (PL, TF, VFHIP_DEINTERLACE_GREEDYH); } while (0)
+    if (planar) { if (p.tff) VF_DQ_M (true, true); else VF_DQ_M (true, false); }
+    else { if (p.tff) VF_DQ_M (false, true); else VF_DQ_M (false, false); }
+#undef VF_DQ_M
+#undef VF_DQ
+  } else if (h->info.format == VFHIP_FORMAT_NV12 || h->info.format == VFHIP_FORMAT_I420) {
     const int strips = (h->info.height + DEINT_ROWS - 1) / DEINT_ROWS;
     dim3 grid ((unsigned) (((size_t) bw * strips + 255) / 256), (unsigned) n_frames);
     if (h->info.format == VFHIP_FORMAT_I420) hipLaunchKernelGGL (k_deinterlace_420<true>, grid, dim3 (256), 0, s, p);

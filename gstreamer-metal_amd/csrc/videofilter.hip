@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <string>
+#include <vector>
 
 using namespace vfhip;
 
@@ -154,22 +155,29 @@ __device__ __forceinline__ F4 color_adjust (F4 c, const VfHipVideoFilterParams &
   return o;
 }
 
-// trilinear 3D LUT, coordinate c*(N-1)/N + .5/N (metalvideofilter_shaders.h:188-194); memory index (b*N+g)*N+r.
-// 32-bit entry indices (N <= 64): no 64-bit multiplies in the address arithmetic of the 8 gathers.
-__device__ __forceinline__ void lut_sample (const float4 *lut, int N, F4 &c)
+// trilinear 3D LUT, coordinate c*(N-1)/N + .5/N (metalvideofilter_shaders.h:188-194).  The table is re-laid at upload
+// (vf_upload_lut) CELL-MAJOR: entry (b, g, r) holds all eight corners of the cell whose low corner it is — per channel k
+// two float4 { L(r,g,b), L(r+1,g,b), L(r,g+1,b), L(r+1,g+1,b) }.k for blue levels b and b+1, the +1 indices clamped like the
+// sampler's second tap — 96 contiguous bytes.  With the plain [b][g][r] table the eight corners of a pixel sit on eight
+// different cache lines, random colours pull ~1 KB of lines per pixel through L1 for 96 useful bytes, and that traffic —
+// not arithmetic, not HBM — bounded the stage (42 of 49 us per 1080p frame, profiles/r02d_vf_ablation.jsonl); cell-major
+// it is one or two lines.  Same values, same interpolation order as the plain table.
+constexpr int VF_LUT_CELL = 6;          // float4 per cell
+__device__ __forceinline__ void lut_sample (const float4 *cells, int N, F4 &c)
 {
   const float scale = (float) (N - 1) / (float) N, offset = 0.5f / (float) N;
   const metal::Taps tx = metal::lin_taps (N, fmaf (c.r, scale, offset)), ty = metal::lin_taps (N, fmaf (c.g, scale, offset)),
                     tz = metal::lin_taps (N, fmaf (c.b, scale, offset));
-  const uint32_t n = (uint32_t) N, z0 = (uint32_t) tz.i0 * n, z1 = (uint32_t) tz.i1 * n;
-  const uint32_t r00 = (z0 + (uint32_t) ty.i0) * n, r10 = (z0 + (uint32_t) ty.i1) * n, r01 = (z1 + (uint32_t) ty.i0) * n, r11 = (z1 + (uint32_t) ty.i1) * n;
-  const uint32_t x0 = (uint32_t) tx.i0, x1 = (uint32_t) tx.i1;
-  const float4 a000 = lut[r00 + x0], a100 = lut[r00 + x1], a010 = lut[r10 + x0], a110 = lut[r10 + x1];
-  const float4 a001 = lut[r01 + x0], a101 = lut[r01 + x1], a011 = lut[r11 + x0], a111 = lut[r11 + x1];
+  const uint32_t n = (uint32_t) N;
+  const float4 *cell = cells + (((uint32_t) tz.i0 * n + (uint32_t) ty.i0) * n + (uint32_t) tx.i0) * (uint32_t) VF_LUT_CELL;
   using metal::lerp2;
-  c.r = lerp2 (lerp2 (lerp2 (a000.x, a100.x, tx.f), lerp2 (a010.x, a110.x, tx.f), ty.f), lerp2 (lerp2 (a001.x, a101.x, tx.f), lerp2 (a011.x, a111.x, tx.f), ty.f), tz.f);
-  c.g = lerp2 (lerp2 (lerp2 (a000.y, a100.y, tx.f), lerp2 (a010.y, a110.y, tx.f), ty.f), lerp2 (lerp2 (a001.y, a101.y, tx.f), lerp2 (a011.y, a111.y, tx.f), ty.f), tz.f);
-  c.b = lerp2 (lerp2 (lerp2 (a000.z, a100.z, tx.f), lerp2 (a010.z, a110.z, tx.f), ty.f), lerp2 (lerp2 (a001.z, a101.z, tx.f), lerp2 (a011.z, a111.z, tx.f), ty.f), tz.f);
+  float o[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float4 lo = cell[2 * k], hi = cell[2 * k + 1];
+    o[k] = lerp2 (lerp2 (lerp2 (lo.x, lo.y, tx.f), lerp2 (lo.z, lo.w, tx.f), ty.f), lerp2 (lerp2 (hi.x, hi.y, tx.f), lerp2 (hi.z, hi.w, tx.f), ty.f), tz.f);
+  }
+  c.r = o[0]; c.g = o[1]; c.b = o[2];
 }
 
 // pass 1 of the reference for one pixel: sample (exact texel, linear chroma) -> adjustments -> LUT -> 8-bit target
@@ -366,10 +374,26 @@ static int vf_upload_lut (VfHipVideoFilter *h, const float *rgba, int size)
 {
   if (size < 2 || size > 64) return set_error (VFHIP_ERR_INVALID, "LUT size %d outside 2..64", size);
   VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
-  const size_t bytes = (size_t) size * size * size * sizeof (float4);
+  // cell-major layout (lut_sample): N^3 cells x 3 channels x 2 blue levels x { (r,g), (r+1,g), (r,g+1), (r+1,g+1) }, +1 clamped
+  const size_t n = (size_t) size;
+  std::vector<float> faces (n * n * n * VF_LUT_CELL * 4);
+  for (size_t b = 0; b < n; b++)
+    for (size_t g = 0; g < n; g++)
+      for (size_t r = 0; r < n; r++) {
+        const size_t r1 = r + 1 < n ? r + 1 : r, g1 = g + 1 < n ? g + 1 : g, b1 = b + 1 < n ? b + 1 : b;
+        float *d = &faces[((b * n + g) * n + r) * VF_LUT_CELL * 4];
+        for (size_t k = 0; k < 3; k++)
+          for (size_t z = 0; z < 2; z++) {
+            const size_t bb = z ? b1 : b;
+            float *e = d + (2 * k + z) * 4;
+            e[0] = rgba[((bb * n + g) * n + r) * 4 + k]; e[1] = rgba[((bb * n + g) * n + r1) * 4 + k];
+            e[2] = rgba[((bb * n + g1) * n + r) * 4 + k]; e[3] = rgba[((bb * n + g1) * n + r1) * 4 + k];
+          }
+      }
+  const size_t bytes = faces.size () * sizeof (float);
   float4 *d = nullptr;
   VFHIP_CHECK_HIP (hipMalloc (&d, bytes));
-  hipError_t e = hipMemcpy (d, rgba, bytes, hipMemcpyHostToDevice);
+  hipError_t e = hipMemcpy (d, faces.data (), bytes, hipMemcpyHostToDevice);
   if (e != hipSuccess) { (void) hipFree (d); return set_error (VFHIP_ERR_HIP, "LUT upload failed: %s", hipGetErrorString (e)); }
   // swap after the device is idle for this handle's streams: a frame in flight may still read the old table
   (void) hipStreamSynchronize (h->st.s_compute);

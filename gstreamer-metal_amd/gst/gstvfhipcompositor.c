@@ -1,543 +1,29 @@
 /* gst/gstvfhipcompositor.c — `vfhipcompositor`: N-input alpha / z-order compositor on an MI355X.
  *
  * Drop-in for the reference's vfmetalcompositor (compositor/gstvfmetalcompositor.{h,m}, gstvfmetalcompositorpad.m):
- * GstVideoAggregator + GstChildProxy, rank PRIMARY + 2 (:177-178), request pads sink_%u { BGRA, RGBA, NV12, I420 }
- * and the same src template (:65-78), element properties background {checker, black, white, transparent} and
- * zero-size-is-unscaled (:1035-1051), pad properties xpos, ypos, width, height, alpha, operator {source, over, add},
- * sizing-policy {none, keep-aspect-ratio} (gstvfmetalcompositorpad.m:282-315; zorder is GstVideoAggregatorPad's own).
+ * GstChildProxy, rank PRIMARY + 2 (:177-178), request pads sink_%u { BGRA, RGBA, NV12, I420 } and the same src template
+ * (:65-78), element properties background {checker, black, white, transparent} and zero-size-is-unscaled (:1035-1051),
+ * pad properties xpos, ypos, width, height, alpha, operator {source, over, add}, sizing-policy {none, keep-aspect-ratio}
+ * (gstvfmetalcompositorpad.m:282-315) plus GstVideoAggregatorPad's own zorder and repeat-after-eos.
  * Inputs keep their own sizes (update_caps does not intersect pad sizes, :394-458); the output size is the bounding
  * box of the positioned pads, BGRA preferred, highest input frame rate (:460-540).
  *
- * Two variants in this file: against GStreamer >= 1.16 the element is a GstVideoAggregator like the reference (that
- * variant cannot be compile-checked here: this container only has 1.14 headers); against 1.14 it is built directly on
- * GstAggregator (frame-synchronous; compiled and pipeline-tested on the GPU box).  Not carried over from the reference:
- * navigation-event forwarding and the obscured-pad culling optimisation (output is identical without it). */
+ * ONE implementation, on every GStreamer version: the element sits directly on GstAggregator (gst-plugins-base 1.14 has
+ * no GstVideoAggregator) and carries the part of GstVideoAggregator the reference relies on (:171-174, :574-684) itself
+ * — see comp_fill_queues (): output frames are cut on the OUTPUT frame rate from the src segment position; every pad
+ * contributes the buffer whose running-time interval covers the output frame, a slower pad's buffer is held and shown
+ * again, buffers that end before the output frame are dropped, a pad that reached EOS disappears once its last buffer
+ * has run out (or stays with repeat-after-eos), EOS goes downstream when every pad is done.  Pads of different frame
+ * rates therefore composite like in the reference.  Obscured-pad culling (gstvfmetalcompositorpad.m:180-255), pointer
+ * navigation (:706-787), async-depth and memory:HIPMemory are part of the same code. */
 #ifdef HAVE_CONFIG_H
 #include "config.h"
 #endif
 #include "gstvfhip.h"
 
-#define GST_CAT_DEFAULT gst_vfhip_debug
+GST_DEBUG_CATEGORY_STATIC (gst_vfhip_compositor_debug);
+#define GST_CAT_DEFAULT gst_vfhip_compositor_debug
 
-/* -DVFHIP_COMPOSITOR_PLAIN_AGGREGATOR selects the GstAggregator variant (the one this repository compiles and tests) on any
- * GStreamer version */
-#if GST_CHECK_VERSION (1, 16, 0) && !defined (VFHIP_COMPOSITOR_PLAIN_AGGREGATOR)
-#include <gst/video/gstvideoaggregator.h>
-
-#define VFHIP_COMP_FORMATS "{ BGRA, RGBA, NV12, I420 }"
-enum { SIZING_NONE = 0, SIZING_KEEP_ASPECT = 1 };
-
-/* ---- pad ------------------------------------------------------------------------------------------------ */
-typedef struct
-{
-  GstVideoAggregatorPad parent;
-  gint xpos, ypos, width, height;
-  gdouble alpha;
-  gint op, sizing_policy;
-} GstVfHipCompositorPad;
-typedef struct
-{
-  GstVideoAggregatorPadClass parent_class;
-} GstVfHipCompositorPadClass;
-
-enum { PAD_PROP_0, PAD_PROP_XPOS, PAD_PROP_YPOS, PAD_PROP_WIDTH, PAD_PROP_HEIGHT, PAD_PROP_ALPHA, PAD_PROP_OPERATOR, PAD_PROP_SIZING_POLICY };
-
-static GType
-comp_operator_type (void)
-{
-  static gsize t = 0;
-  static const GEnumValue v[] = {
-    {VFHIP_BLEND_SOURCE, "Source", "source"}, {VFHIP_BLEND_OVER, "Over", "over"}, {VFHIP_BLEND_ADD, "Add", "add"}, {0, NULL, NULL}
-  };
-  if (g_once_init_enter (&t))
-    g_once_init_leave (&t, g_enum_register_static ("GstVfHipCompositorOperator", v));
-  return (GType) t;
-}
-
-static GType
-comp_sizing_type (void)
-{
-  static gsize t = 0;
-  static const GEnumValue v[] = {
-    {SIZING_NONE, "None: image is scaled to fill configured destination rectangle without padding or keeping the aspect ratio", "none"},
-    {SIZING_KEEP_ASPECT, "Keep Aspect Ratio: image is scaled to fit destination rectangle with preserved aspect ratio", "keep-aspect-ratio"},
-    {0, NULL, NULL}
-  };
-  if (g_once_init_enter (&t))
-    g_once_init_leave (&t, g_enum_register_static ("GstVfHipCompositorSizingPolicy", v));
-  return (GType) t;
-}
-
-static GType
-comp_background_type (void)
-{
-  static gsize t = 0;
-  static const GEnumValue v[] = {
-    {VFHIP_BG_CHECKER, "Checker pattern", "checker"}, {VFHIP_BG_BLACK, "Black", "black"}, {VFHIP_BG_WHITE, "White", "white"},
-    {VFHIP_BG_TRANSPARENT, "Transparent Background to enable further compositing", "transparent"}, {0, NULL, NULL}
-  };
-  if (g_once_init_enter (&t))
-    g_once_init_leave (&t, g_enum_register_static ("GstVfHipCompositorBackground", v));
-  return (GType) t;
-}
-
-G_DEFINE_TYPE (GstVfHipCompositorPad, gst_vfhip_compositor_pad, GST_TYPE_VIDEO_AGGREGATOR_PAD);
-#define CPAD(o) ((GstVfHipCompositorPad *) (o))
-
-static void
-cpad_set_property (GObject * object, guint id, const GValue * value, GParamSpec * pspec)
-{
-  GstVfHipCompositorPad *pad = CPAD (object);
-  GST_OBJECT_LOCK (pad);
-  switch (id) {
-    case PAD_PROP_XPOS: pad->xpos = g_value_get_int (value); break;
-    case PAD_PROP_YPOS: pad->ypos = g_value_get_int (value); break;
-    case PAD_PROP_WIDTH: pad->width = g_value_get_int (value); break;
-    case PAD_PROP_HEIGHT: pad->height = g_value_get_int (value); break;
-    case PAD_PROP_ALPHA: pad->alpha = g_value_get_double (value); break;
-    case PAD_PROP_OPERATOR: pad->op = g_value_get_enum (value); break;
-    case PAD_PROP_SIZING_POLICY: pad->sizing_policy = g_value_get_enum (value); break;
-    default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
-  }
-  GST_OBJECT_UNLOCK (pad);
-  if (id == PAD_PROP_WIDTH || id == PAD_PROP_HEIGHT || id == PAD_PROP_XPOS || id == PAD_PROP_YPOS || id == PAD_PROP_SIZING_POLICY) {
-    GstObject *agg = gst_object_get_parent (GST_OBJECT (pad));
-    if (agg) {
-      gst_pad_mark_reconfigure (GST_AGGREGATOR (agg)->srcpad);      /* the output bounding box may have changed */
-      gst_object_unref (agg);
-    }
-  }
-}
-
-static void
-cpad_get_property (GObject * object, guint id, GValue * value, GParamSpec * pspec)
-{
-  GstVfHipCompositorPad *pad = CPAD (object);
-  GST_OBJECT_LOCK (pad);
-  switch (id) {
-    case PAD_PROP_XPOS: g_value_set_int (value, pad->xpos); break;
-    case PAD_PROP_YPOS: g_value_set_int (value, pad->ypos); break;
-    case PAD_PROP_WIDTH: g_value_set_int (value, pad->width); break;
-    case PAD_PROP_HEIGHT: g_value_set_int (value, pad->height); break;
-    case PAD_PROP_ALPHA: g_value_set_double (value, pad->alpha); break;
-    case PAD_PROP_OPERATOR: g_value_set_enum (value, pad->op); break;
-    case PAD_PROP_SIZING_POLICY: g_value_set_enum (value, pad->sizing_policy); break;
-    default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
-  }
-  GST_OBJECT_UNLOCK (pad);
-}
-
-static void
-gst_vfhip_compositor_pad_class_init (GstVfHipCompositorPadClass * klass)
-{
-  GObjectClass *oc = G_OBJECT_CLASS (klass);
-  const GParamFlags f = (GParamFlags) (G_PARAM_READWRITE | GST_PARAM_CONTROLLABLE | G_PARAM_STATIC_STRINGS);
-  oc->set_property = cpad_set_property;
-  oc->get_property = cpad_get_property;
-  g_object_class_install_property (oc, PAD_PROP_XPOS, g_param_spec_int ("xpos", "X Position", "X Position of the picture", G_MININT, G_MAXINT, 0, f));
-  g_object_class_install_property (oc, PAD_PROP_YPOS, g_param_spec_int ("ypos", "Y Position", "Y Position of the picture", G_MININT, G_MAXINT, 0, f));
-  g_object_class_install_property (oc, PAD_PROP_WIDTH, g_param_spec_int ("width", "Width", "Width of the picture", G_MININT, G_MAXINT, -1, f));
-  g_object_class_install_property (oc, PAD_PROP_HEIGHT, g_param_spec_int ("height", "Height", "Height of the picture", G_MININT, G_MAXINT, -1, f));
-  g_object_class_install_property (oc, PAD_PROP_ALPHA, g_param_spec_double ("alpha", "Alpha", "Alpha of the picture", 0.0, 1.0, 1.0, f));
-  g_object_class_install_property (oc, PAD_PROP_OPERATOR, g_param_spec_enum ("operator", "Operator",
-          "Blending operator to use for blending this pad over the previous ones", comp_operator_type (), VFHIP_BLEND_OVER, f));
-  g_object_class_install_property (oc, PAD_PROP_SIZING_POLICY, g_param_spec_enum ("sizing-policy", "Sizing policy",
-          "Sizing policy to use for image scaling", comp_sizing_type (), SIZING_NONE, f));
-}
-
-static void
-gst_vfhip_compositor_pad_init (GstVfHipCompositorPad * pad)
-{
-  pad->xpos = pad->ypos = 0;
-  pad->width = pad->height = -1;
-  pad->alpha = 1.0;
-  pad->op = VFHIP_BLEND_OVER;
-  pad->sizing_policy = SIZING_NONE;
-}
-
-/* ---- element --------------------------------------------------------------------------------------------- */
-typedef struct
-{
-  GstVideoAggregator parent;
-  VfHipCompositor *renderer;
-  gint device_id, background;
-  gboolean zero_size_is_unscaled;
-} GstVfHipCompositor;
-typedef struct
-{
-  GstVideoAggregatorClass parent_class;
-} GstVfHipCompositorClass;
-
-enum { PROP_0, PROP_BACKGROUND, PROP_ZERO_SIZE_IS_UNSCALED, PROP_DEVICE_ID };
-
-static GstStaticPadTemplate comp_src_template = GST_STATIC_PAD_TEMPLATE ("src", GST_PAD_SRC, GST_PAD_ALWAYS,
-    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE (VFHIP_COMP_FORMATS)));
-static GstStaticPadTemplate comp_sink_template = GST_STATIC_PAD_TEMPLATE ("sink_%u", GST_PAD_SINK, GST_PAD_REQUEST,
-    GST_STATIC_CAPS (GST_VIDEO_CAPS_MAKE (VFHIP_COMP_FORMATS)));
-
-static void comp_child_proxy_init (gpointer g_iface, gpointer iface_data);
-G_DEFINE_TYPE_WITH_CODE (GstVfHipCompositor, gst_vfhip_compositor, GST_TYPE_VIDEO_AGGREGATOR,
-    G_IMPLEMENT_INTERFACE (GST_TYPE_CHILD_PROXY, comp_child_proxy_init));
-#define COMP(o) ((GstVfHipCompositor *) (o))
-
-/* where a pad lands in the output: its configured (or native) size, corrected for the pixel aspect ratios, and for
- * keep-aspect-ratio the centred sub-rectangle that preserves the input's display aspect ratio */
-static void
-comp_pad_rect (GstVfHipCompositor * self, GstVfHipCompositorPad * cpad, gint out_par_n, gint out_par_d,
-    gint * w, gint * h, gint * xoff, gint * yoff)
-{
-  GstVideoAggregatorPad *vpad = GST_VIDEO_AGGREGATOR_PAD (cpad);
-  gint pw, ph;
-  guint dn, dd;
-  *w = *h = *xoff = *yoff = 0;
-  if (!vpad->info.finfo || GST_VIDEO_INFO_FORMAT (&vpad->info) == GST_VIDEO_FORMAT_UNKNOWN)
-    return;
-  if (self->zero_size_is_unscaled) {
-    pw = cpad->width <= 0 ? GST_VIDEO_INFO_WIDTH (&vpad->info) : cpad->width;
-    ph = cpad->height <= 0 ? GST_VIDEO_INFO_HEIGHT (&vpad->info) : cpad->height;
-  } else {
-    pw = cpad->width < 0 ? GST_VIDEO_INFO_WIDTH (&vpad->info) : cpad->width;
-    ph = cpad->height < 0 ? GST_VIDEO_INFO_HEIGHT (&vpad->info) : cpad->height;
-  }
-  if (pw == 0 || ph == 0)
-    return;
-  if (!gst_video_calculate_display_ratio (&dn, &dd, pw, ph, GST_VIDEO_INFO_PAR_N (&vpad->info), GST_VIDEO_INFO_PAR_D (&vpad->info), out_par_n, out_par_d))
-    return;
-  if (cpad->sizing_policy == SIZING_NONE) {
-    if (ph % dn == 0) pw = gst_util_uint64_scale_int (ph, dn, dd);
-    else if (pw % dd == 0) ph = gst_util_uint64_scale_int (pw, dd, dn);
-    else pw = gst_util_uint64_scale_int (ph, dn, dd);
-  } else {
-    gint fn, fd, tn, td, num, den;
-    if (!gst_util_fraction_multiply (GST_VIDEO_INFO_WIDTH (&vpad->info), GST_VIDEO_INFO_HEIGHT (&vpad->info),
-            GST_VIDEO_INFO_PAR_N (&vpad->info), GST_VIDEO_INFO_PAR_D (&vpad->info), &fn, &fd)) fn = fd = -1;
-    if (!gst_util_fraction_multiply (pw, ph, out_par_n, out_par_d, &tn, &td)) tn = td = -1;
-    if (fn != tn || fd != td) {
-      GstVideoRectangle src, dst, res;
-      if (fn == -1 || !gst_util_fraction_multiply (fn, fd, out_par_d, out_par_n, &num, &den))
-        return;
-      src.x = src.y = 0; src.w = pw; src.h = gst_util_uint64_scale_int (pw, den, num);
-      if (src.h == 0)
-        return;
-      dst.x = dst.y = 0; dst.w = pw; dst.h = ph;
-      gst_video_sink_center_rect (src, dst, &res, TRUE);
-      *xoff = res.x; *yoff = res.y; pw = res.w; ph = res.h;
-    }
-  }
-  *w = pw; *h = ph;
-}
-
-static GstCaps *
-comp_update_caps (GstVideoAggregator * vagg, GstCaps * caps)
-{
-  gint bw = -1, bh = -1;
-  GList *l;
-  GstCaps *ret, *tmpl, *tmp;
-  GST_OBJECT_LOCK (vagg);
-  for (l = GST_ELEMENT (vagg)->sinkpads; l; l = l->next) {
-    GstVideoAggregatorPad *vpad = l->data;
-    GstVfHipCompositorPad *cpad = CPAD (vpad);
-    gint w, h;
-    if (!vpad->info.finfo)
-      continue;
-    w = (cpad->width > 0 ? cpad->width : GST_VIDEO_INFO_WIDTH (&vpad->info)) + MAX (cpad->xpos, 0);
-    h = (cpad->height > 0 ? cpad->height : GST_VIDEO_INFO_HEIGHT (&vpad->info)) + MAX (cpad->ypos, 0);
-    bw = MAX (bw, w); bh = MAX (bh, h);
-  }
-  GST_OBJECT_UNLOCK (vagg);
-  if (bw <= 0 || bh <= 0)
-    return gst_caps_ref (caps);
-  ret = gst_caps_new_simple ("video/x-raw", "width", G_TYPE_INT, bw, "height", G_TYPE_INT, bh, NULL);
-  tmpl = gst_static_pad_template_get_caps (&comp_src_template);
-  tmp = gst_caps_intersect (ret, tmpl);
-  gst_caps_unref (ret); gst_caps_unref (tmpl);
-  ret = tmp;
-  if (caps) {
-    tmp = gst_caps_intersect (ret, caps);
-    gst_caps_unref (ret);
-    ret = tmp;
-  }
-  return ret;
-}
-
-static GstCaps *
-comp_fixate_src_caps (GstAggregator * agg, GstCaps * caps)
-{
-  GstVideoAggregator *vagg = GST_VIDEO_AGGREGATOR (agg);
-  GstCaps *ret = gst_caps_make_writable (caps);
-  GstStructure *s = gst_caps_get_structure (ret, 0);
-  gint bw = -1, bh = -1, fn = -1, fd = -1, par_n = 1, par_d = 1;
-  gdouble best = 0.0;
-  GList *l;
-  if (gst_structure_has_field (s, "pixel-aspect-ratio")) {
-    gst_structure_fixate_field_nearest_fraction (s, "pixel-aspect-ratio", 1, 1);
-    gst_structure_get_fraction (s, "pixel-aspect-ratio", &par_n, &par_d);
-  }
-  GST_OBJECT_LOCK (vagg);
-  for (l = GST_ELEMENT (vagg)->sinkpads; l; l = l->next) {
-    GstVideoAggregatorPad *vpad = l->data;
-    GstVfHipCompositorPad *cpad = CPAD (vpad);
-    gint w, h, xo, yo;
-    gdouble fps = 0.0;
-    comp_pad_rect (COMP (vagg), cpad, par_n, par_d, &w, &h, &xo, &yo);
-    if (w == 0 || h == 0)
-      continue;
-    bw = MAX (bw, w + MAX (cpad->xpos + 2 * xo, 0));
-    bh = MAX (bh, h + MAX (cpad->ypos + 2 * yo, 0));
-    if (GST_VIDEO_INFO_FPS_D (&vpad->info) != 0)
-      gst_util_fraction_to_double (GST_VIDEO_INFO_FPS_N (&vpad->info), GST_VIDEO_INFO_FPS_D (&vpad->info), &fps);
-    if (fps > best) { best = fps; fn = GST_VIDEO_INFO_FPS_N (&vpad->info); fd = GST_VIDEO_INFO_FPS_D (&vpad->info); }
-  }
-  GST_OBJECT_UNLOCK (vagg);
-  if (fn <= 0 || fd <= 0) { fn = 25; fd = 1; }
-  gst_structure_fixate_field_string (s, "format", "BGRA");
-  gst_structure_fixate_field_nearest_int (s, "width", bw);
-  gst_structure_fixate_field_nearest_int (s, "height", bh);
-  gst_structure_fixate_field_nearest_fraction (s, "framerate", fn, fd);
-  return gst_caps_fixate (ret);
-}
-
-static gboolean
-comp_negotiated_src_caps (GstAggregator * agg, GstCaps * caps)
-{
-  GstVfHipCompositor *self = COMP (agg);
-  GstVideoInfo gi;
-  VfHipVideoInfo out;
-  if (!gst_video_info_from_caps (&gi, caps))
-    return FALSE;
-  if (!self->renderer && !(self->renderer = vfhip_compositor_new (self->device_id))) {
-    GST_ERROR_OBJECT (self, "no HIP renderer: %s", vfhip_last_error_string ());
-    return FALSE;
-  }
-  gst_vfhip_info (&gi, &out);
-  if (vfhip_compositor_configure (self->renderer, &out) != VFHIP_OK) {
-    GST_ERROR_OBJECT (self, "configure failed: %s", vfhip_last_error_string ());
-    return FALSE;
-  }
-  return GST_AGGREGATOR_CLASS (gst_vfhip_compositor_parent_class)->negotiated_src_caps (agg, caps);
-}
-
-static GstFlowReturn
-comp_aggregate_frames (GstVideoAggregator * vagg, GstBuffer * outbuf)
-{
-  GstVfHipCompositor *self = COMP (vagg);
-  GstVideoFrame out;
-  VfHipFrame vout;
-  VfHipPadInput *pads;
-  guint n = 0, i = 0;
-  gboolean covered = FALSE;
-  gint bg, rc;
-  GList *l;
-  if (!self->renderer)
-    return GST_FLOW_ERROR;
-  if (!gst_video_frame_map (&out, &vagg->info, outbuf, GST_MAP_WRITE))
-    return GST_FLOW_ERROR;
-  GST_OBJECT_LOCK (vagg);
-  for (l = GST_ELEMENT (vagg)->sinkpads; l; l = l->next)
-    if (gst_video_aggregator_pad_get_prepared_frame (GST_VIDEO_AGGREGATOR_PAD (l->data)))
-      n++;
-  pads = g_new0 (VfHipPadInput, MAX (n, 1));
-  for (l = GST_ELEMENT (vagg)->sinkpads; l; l = l->next) {      /* sinkpads is kept in zorder by the base class */
-    GstVideoAggregatorPad *vpad = l->data;
-    GstVfHipCompositorPad *cpad = CPAD (vpad);
-    GstVideoFrame *f = gst_video_aggregator_pad_get_prepared_frame (vpad);
-    gint w, h, xo, yo;
-    if (!f)
-      continue;
-    comp_pad_rect (self, cpad, GST_VIDEO_INFO_PAR_N (&vagg->info), GST_VIDEO_INFO_PAR_D (&vagg->info), &w, &h, &xo, &yo);
-    gst_vfhip_frame (f, &pads[i].frame);
-    pads[i].xpos = cpad->xpos + xo; pads[i].ypos = cpad->ypos + yo; pads[i].width = w; pads[i].height = h;
-    pads[i].alpha = cpad->alpha; pads[i].blend_mode = cpad->op;
-    /* an opaque pad over the whole frame makes the background invisible: pass TRANSPARENT like the reference (:649-651) */
-    if (cpad->alpha == 1.0 && !GST_VIDEO_INFO_HAS_ALPHA (&vpad->info) && pads[i].xpos <= 0 && pads[i].ypos <= 0 &&
-        pads[i].xpos + w >= GST_VIDEO_INFO_WIDTH (&vagg->info) && pads[i].ypos + h >= GST_VIDEO_INFO_HEIGHT (&vagg->info))
-      covered = TRUE;
-    i++;
-  }
-  GST_OBJECT_UNLOCK (vagg);
-  bg = (covered && n > 0) ? VFHIP_BG_TRANSPARENT : self->background;
-  gst_vfhip_frame (&out, &vout);
-  rc = vfhip_compositor_composite (self->renderer, pads, (int) i, bg, &vout);
-  gst_video_frame_unmap (&out);
-  g_free (pads);
-  if (rc != VFHIP_OK) {
-    GST_ERROR_OBJECT (self, "HIP compositing failed: %s", vfhip_last_error_string ());
-    return GST_FLOW_ERROR;
-  }
-  return GST_FLOW_OK;
-}
-
-static gboolean
-comp_stop (GstAggregator * agg)
-{
-  GstVfHipCompositor *self = COMP (agg);
-  if (self->renderer)
-    vfhip_compositor_cleanup (self->renderer);
-  return GST_AGGREGATOR_CLASS (gst_vfhip_compositor_parent_class)->stop (agg);
-}
-
-/* every sink pad may carry its own size: answer caps queries with the template, not the negotiated output */
-static gboolean
-comp_sink_query (GstAggregator * agg, GstAggregatorPad * pad, GstQuery * query)
-{
-  if (GST_QUERY_TYPE (query) == GST_QUERY_CAPS) {
-    GstCaps *filter, *tmpl = gst_pad_get_pad_template_caps (GST_PAD (pad)), *res;
-    gst_query_parse_caps (query, &filter);
-    res = filter ? gst_caps_intersect_full (filter, tmpl, GST_CAPS_INTERSECT_FIRST) : gst_caps_ref (tmpl);
-    gst_query_set_caps_result (query, res);
-    gst_caps_unref (res); gst_caps_unref (tmpl);
-    return TRUE;
-  }
-  if (GST_QUERY_TYPE (query) == GST_QUERY_ACCEPT_CAPS) {
-    GstCaps *caps, *tmpl = gst_pad_get_pad_template_caps (GST_PAD (pad));
-    gst_query_parse_accept_caps (query, &caps);
-    gst_query_set_accept_caps_result (query, gst_caps_is_subset (caps, tmpl));
-    gst_caps_unref (tmpl);
-    return TRUE;
-  }
-  return GST_AGGREGATOR_CLASS (gst_vfhip_compositor_parent_class)->sink_query (agg, pad, query);
-}
-
-static void
-comp_set_property (GObject * object, guint id, const GValue * value, GParamSpec * pspec)
-{
-  GstVfHipCompositor *self = COMP (object);
-  switch (id) {
-    case PROP_BACKGROUND: self->background = g_value_get_enum (value); break;
-    case PROP_ZERO_SIZE_IS_UNSCALED: self->zero_size_is_unscaled = g_value_get_boolean (value); break;
-    case PROP_DEVICE_ID: self->device_id = g_value_get_int (value); break;
-    default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
-  }
-}
-
-static void
-comp_get_property (GObject * object, guint id, GValue * value, GParamSpec * pspec)
-{
-  GstVfHipCompositor *self = COMP (object);
-  switch (id) {
-    case PROP_BACKGROUND: g_value_set_enum (value, self->background); break;
-    case PROP_ZERO_SIZE_IS_UNSCALED: g_value_set_boolean (value, self->zero_size_is_unscaled); break;
-    case PROP_DEVICE_ID: g_value_set_int (value, self->device_id); break;
-    default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
-  }
-}
-
-static void
-comp_finalize (GObject * object)
-{
-  GstVfHipCompositor *self = COMP (object);
-  if (self->renderer)
-    vfhip_compositor_free (self->renderer);
-  self->renderer = NULL;
-  G_OBJECT_CLASS (gst_vfhip_compositor_parent_class)->finalize (object);
-}
-
-/* GstChildProxy: lets gst-launch address pads as sink_0::xpos=... */
-static GObject *
-comp_child_by_index (GstChildProxy * proxy, guint index)
-{
-  GObject *obj;
-  GST_OBJECT_LOCK (proxy);
-  obj = g_list_nth_data (GST_ELEMENT_CAST (proxy)->sinkpads, index);
-  if (obj)
-    gst_object_ref (obj);
-  GST_OBJECT_UNLOCK (proxy);
-  return obj;
-}
-
-static guint
-comp_children_count (GstChildProxy * proxy)
-{
-  guint n;
-  GST_OBJECT_LOCK (proxy);
-  n = GST_ELEMENT_CAST (proxy)->numsinkpads;
-  GST_OBJECT_UNLOCK (proxy);
-  return n;
-}
-
-static void
-comp_child_proxy_init (gpointer g_iface, gpointer iface_data)
-{
-  GstChildProxyInterface *iface = g_iface;
-  (void) iface_data;
-  iface->get_child_by_index = comp_child_by_index;
-  iface->get_children_count = comp_children_count;
-}
-
-static GstPad *
-comp_request_new_pad (GstElement * element, GstPadTemplate * templ, const gchar * name, const GstCaps * caps)
-{
-  GstPad *pad = GST_ELEMENT_CLASS (gst_vfhip_compositor_parent_class)->request_new_pad (element, templ, name, caps);
-  if (pad)
-    gst_child_proxy_child_added (GST_CHILD_PROXY (element), G_OBJECT (pad), GST_OBJECT_NAME (pad));
-  return pad;
-}
-
-static void
-comp_release_pad (GstElement * element, GstPad * pad)
-{
-  gst_child_proxy_child_removed (GST_CHILD_PROXY (element), G_OBJECT (pad), GST_OBJECT_NAME (pad));
-  GST_ELEMENT_CLASS (gst_vfhip_compositor_parent_class)->release_pad (element, pad);
-}
-
-static void
-gst_vfhip_compositor_class_init (GstVfHipCompositorClass * klass)
-{
-  GObjectClass *oc = G_OBJECT_CLASS (klass);
-  GstElementClass *ec = GST_ELEMENT_CLASS (klass);
-  GstAggregatorClass *ac = GST_AGGREGATOR_CLASS (klass);
-  GstVideoAggregatorClass *vc = GST_VIDEO_AGGREGATOR_CLASS (klass);
-  oc->set_property = comp_set_property;
-  oc->get_property = comp_get_property;
-  oc->finalize = comp_finalize;
-  ec->request_new_pad = GST_DEBUG_FUNCPTR (comp_request_new_pad);
-  ec->release_pad = GST_DEBUG_FUNCPTR (comp_release_pad);
-  ac->sink_query = GST_DEBUG_FUNCPTR (comp_sink_query);
-  ac->fixate_src_caps = GST_DEBUG_FUNCPTR (comp_fixate_src_caps);
-  ac->negotiated_src_caps = GST_DEBUG_FUNCPTR (comp_negotiated_src_caps);
-  ac->stop = GST_DEBUG_FUNCPTR (comp_stop);
-  vc->update_caps = GST_DEBUG_FUNCPTR (comp_update_caps);
-  vc->aggregate_frames = GST_DEBUG_FUNCPTR (comp_aggregate_frames);
-
-  g_object_class_install_property (oc, PROP_BACKGROUND, g_param_spec_enum ("background", "Background", "Background type",
-          comp_background_type (), VFHIP_BG_CHECKER, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
-  g_object_class_install_property (oc, PROP_ZERO_SIZE_IS_UNSCALED, g_param_spec_boolean ("zero-size-is-unscaled", "Zero size is unscaled",
-          "If TRUE, then input video is unscaled in that dimension if width or height is 0 (for backwards compatibility)", TRUE,
-          G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
-  g_object_class_install_property (oc, PROP_DEVICE_ID, g_param_spec_int ("device-id", "Device ID",
-          "GPU ordinal to run on (-1: $VFHIP_DEVICE, else 0)", -1, 63, GST_VFHIP_DEFAULT_DEVICE_ID, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
-
-  gst_element_class_add_static_pad_template_with_gtype (ec, &comp_src_template, GST_TYPE_AGGREGATOR_PAD);
-  gst_element_class_add_static_pad_template_with_gtype (ec, &comp_sink_template, gst_vfhip_compositor_pad_get_type ());
-  gst_element_class_set_static_metadata (ec, "HIP Compositor", "Filter/Editor/Video/Compositor",
-      "MI355X-accelerated compositing of multiple video streams", "vfhip");
-}
-
-static void
-gst_vfhip_compositor_init (GstVfHipCompositor * self)
-{
-  self->background = VFHIP_BG_CHECKER;
-  self->zero_size_is_unscaled = TRUE;
-  self->device_id = GST_VFHIP_DEFAULT_DEVICE_ID;
-}
-
-gboolean
-gst_vfhip_compositor_register (GstPlugin * plugin)
-{
-  gboolean ok = gst_element_register (plugin, "vfhipcompositor", GST_RANK_PRIMARY + 2, gst_vfhip_compositor_get_type ());
-#ifdef VFHIP_REGISTER_VFMETAL_NAMES
-  ok &= gst_element_register (plugin, "vfmetalcompositor", GST_RANK_PRIMARY + 2, gst_vfhip_compositor_get_type ());
-#endif
-  return ok;
-}
-
-#else /* GStreamer < 1.16 (no GstVideoAggregator in gst-plugins-base), or VFHIP_COMPOSITOR_PLAIN_AGGREGATOR */
-
-/* A frame-synchronous compositor directly on GstAggregator (which IS in gst-plugins-base 1.14): every aggregate() takes
- * the next buffer of each sink pad, composites them in zorder and pushes one output frame.  Same element name, pad
- * template, element / pad properties and caps rules as above; what it lacks against GstVideoAggregator is frame-rate
- * conversion between inputs of different rates (the reference's smoke tests use equal rates).  This is the variant
- * that is compiled and exercised by tests/test_gst_plugin_gpu.py in this environment. */
 #include <gst/base/gstaggregator.h>
 #include <stdlib.h>
 
@@ -553,13 +39,17 @@ typedef struct
   gdouble alpha;
   gint op, sizing_policy;
   guint zorder;
+  gboolean repeat_after_eos;
+  /* the buffer this pad currently shows and its running-time interval (GstVideoAggregatorPad's buffer / start_time / end_time) */
+  GstBuffer *cur;
+  GstClockTime cur_start, cur_end;
 } GstVfHipCompositorPad;
 typedef struct
 {
   GstAggregatorPadClass parent_class;
 } GstVfHipCompositorPadClass;
 
-enum { PAD_PROP_0, PAD_PROP_XPOS, PAD_PROP_YPOS, PAD_PROP_WIDTH, PAD_PROP_HEIGHT, PAD_PROP_ALPHA, PAD_PROP_OPERATOR, PAD_PROP_SIZING_POLICY, PAD_PROP_ZORDER };
+enum { PAD_PROP_0, PAD_PROP_XPOS, PAD_PROP_YPOS, PAD_PROP_WIDTH, PAD_PROP_HEIGHT, PAD_PROP_ALPHA, PAD_PROP_OPERATOR, PAD_PROP_SIZING_POLICY, PAD_PROP_ZORDER, PAD_PROP_REPEAT_AFTER_EOS };
 
 static GType
 comp_enum (const gchar * name, const GEnumValue * v, gsize * once)
@@ -618,10 +108,11 @@ cpad_set_property (GObject * object, guint id, const GValue * value, GParamSpec 
     case PAD_PROP_OPERATOR: pad->op = g_value_get_enum (value); break;
     case PAD_PROP_SIZING_POLICY: pad->sizing_policy = g_value_get_enum (value); break;
     case PAD_PROP_ZORDER: pad->zorder = g_value_get_uint (value); break;
+    case PAD_PROP_REPEAT_AFTER_EOS: pad->repeat_after_eos = g_value_get_boolean (value); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
   }
   GST_OBJECT_UNLOCK (pad);
-  if (id != PAD_PROP_ALPHA && id != PAD_PROP_OPERATOR && id != PAD_PROP_ZORDER && (agg = gst_object_get_parent (GST_OBJECT (pad)))) {
+  if (id != PAD_PROP_ALPHA && id != PAD_PROP_OPERATOR && id != PAD_PROP_ZORDER && id != PAD_PROP_REPEAT_AFTER_EOS && (agg = gst_object_get_parent (GST_OBJECT (pad)))) {
     gst_pad_mark_reconfigure (GST_AGGREGATOR (agg)->srcpad);          /* the output bounding box may have changed */
     gst_object_unref (agg);
   }
@@ -641,9 +132,17 @@ cpad_get_property (GObject * object, guint id, GValue * value, GParamSpec * pspe
     case PAD_PROP_OPERATOR: g_value_set_enum (value, pad->op); break;
     case PAD_PROP_SIZING_POLICY: g_value_set_enum (value, pad->sizing_policy); break;
     case PAD_PROP_ZORDER: g_value_set_uint (value, pad->zorder); break;
+    case PAD_PROP_REPEAT_AFTER_EOS: g_value_set_boolean (value, pad->repeat_after_eos); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
   }
   GST_OBJECT_UNLOCK (pad);
+}
+
+static void
+cpad_finalize (GObject * object)
+{
+  gst_buffer_replace (&CPAD (object)->cur, NULL);
+  G_OBJECT_CLASS (gst_vfhip_compositor_pad_parent_class)->finalize (object);
 }
 
 static void
@@ -653,6 +152,7 @@ gst_vfhip_compositor_pad_class_init (GstVfHipCompositorPadClass * klass)
   const GParamFlags f = (GParamFlags) (G_PARAM_READWRITE | GST_PARAM_CONTROLLABLE | G_PARAM_STATIC_STRINGS);
   oc->set_property = cpad_set_property;
   oc->get_property = cpad_get_property;
+  oc->finalize = cpad_finalize;
   g_object_class_install_property (oc, PAD_PROP_XPOS, g_param_spec_int ("xpos", "X Position", "X Position of the picture", G_MININT, G_MAXINT, 0, f));
   g_object_class_install_property (oc, PAD_PROP_YPOS, g_param_spec_int ("ypos", "Y Position", "Y Position of the picture", G_MININT, G_MAXINT, 0, f));
   g_object_class_install_property (oc, PAD_PROP_WIDTH, g_param_spec_int ("width", "Width", "Width of the picture", G_MININT, G_MAXINT, -1, f));
@@ -663,6 +163,8 @@ gst_vfhip_compositor_pad_class_init (GstVfHipCompositorPadClass * klass)
   g_object_class_install_property (oc, PAD_PROP_SIZING_POLICY, g_param_spec_enum ("sizing-policy", "Sizing policy",
           "Sizing policy to use for image scaling", comp_sizing_type (), SIZING_NONE, f));
   g_object_class_install_property (oc, PAD_PROP_ZORDER, g_param_spec_uint ("zorder", "Z-Order", "Z Order of the picture", 0, G_MAXUINT, 0, f));
+  g_object_class_install_property (oc, PAD_PROP_REPEAT_AFTER_EOS, g_param_spec_boolean ("repeat-after-eos", "Repeat After EOS",
+          "Repeat the last frame after EOS until all pads are EOS", FALSE, f));
 }
 
 static void
@@ -672,6 +174,7 @@ gst_vfhip_compositor_pad_init (GstVfHipCompositorPad * pad)
   pad->alpha = 1.0;
   pad->op = VFHIP_BLEND_OVER;
   pad->sizing_policy = SIZING_NONE;
+  pad->cur_start = pad->cur_end = GST_CLOCK_TIME_NONE;
   gst_video_info_init (&pad->info);
 }
 
@@ -683,7 +186,8 @@ typedef struct
   gboolean zero_size_is_unscaled;
   GstVideoInfo out_info;
   gboolean have_out_info, out_is_device;
-  guint64 n_frames;
+  guint64 n_frames;                             /* output frames since the last (re)start of the time line */
+  GstClockTime ts_offset;                       /* segment time of output frame 0: frame k ends at ts_offset + (k + 1) / fps, no drift */
   GstVfHipPinStats pin;                         /* recurring pageable input memories are page-locked in place */
   /* async-depth=1: the composite submitted last (vfhip_compositor_submit); its input buffers and its output buffer stay
    * mapped until the next aggregate() has submitted its own and waits for this one */
@@ -915,12 +419,128 @@ comp_finish_pending (GstVfHipCompositor * self, gboolean push)
   return flow;
 }
 
+/* Which buffer does every pad show during the output frame [out_start, out_end) (running time)?  GstVideoAggregator's
+ * gst_video_aggregator_fill_queues restated on GstAggregator 1.14 (the reference inherits it: gstvfmetalcompositor.m:171-174):
+ *   - a queued buffer that overlaps the output frame becomes the pad's current buffer and leaves the queue;
+ *   - one that starts at or after the end of the output frame stays queued, the current buffer is shown again
+ *     (a pad slower than the output);
+ *   - one that ended before the output frame is dropped and the pad is asked for more (a pad faster than the output);
+ *   - a pad at EOS keeps its last buffer while that still runs, then disappears (unless repeat-after-eos);
+ * -> GST_FLOW_OK, GST_AGGREGATOR_FLOW_NEED_DATA (wait for the pads that were asked for more) or GST_FLOW_EOS (all done). */
+static GstFlowReturn
+comp_fill_queues (GstVfHipCompositor * self, PadRef * refs, guint n, GstClockTime out_start, GstClockTime out_end, GstClockTime out_dur)
+{
+  gboolean eos = TRUE, need_more = FALSE;
+  guint i;
+  for (i = 0; i < n; i++) {
+    GstVfHipCompositorPad *cpad = refs[i].pad;
+    GstAggregatorPad *apad = GST_AGGREGATOR_PAD (cpad);
+    for (;;) {
+      GstBuffer *buf = gst_aggregator_pad_peek_buffer (apad);
+      GstClockTime start, end, dur;
+      if (!buf) {
+        if (gst_aggregator_pad_is_eos (apad)) {
+          if (cpad->cur && GST_CLOCK_TIME_IS_VALID (cpad->cur_end) && cpad->cur_end > out_start)
+            eos = FALSE;                                   /* its last buffer still covers this frame */
+          else if (!(cpad->cur && cpad->repeat_after_eos)) {
+            gst_buffer_replace (&cpad->cur, NULL);
+            cpad->cur_start = cpad->cur_end = GST_CLOCK_TIME_NONE;
+          }
+        } else
+          eos = FALSE;                                     /* nothing queued yet (timeout / just asked for more) */
+        break;
+      }
+      start = GST_BUFFER_PTS_IS_VALID (buf) ? GST_BUFFER_PTS (buf) : GST_BUFFER_DTS (buf);
+      if (!GST_CLOCK_TIME_IS_VALID (start)) {              /* untimed buffer: shown from now on */
+        gst_buffer_replace (&cpad->cur, buf);
+        cpad->cur_start = cpad->cur_end = GST_CLOCK_TIME_NONE;
+        gst_buffer_unref (buf);
+        gst_aggregator_pad_drop_buffer (apad);
+        eos = FALSE;
+        break;
+      }
+      if (GST_BUFFER_DURATION_IS_VALID (buf))
+        dur = GST_BUFFER_DURATION (buf);
+      else if (cpad->have_info && GST_VIDEO_INFO_FPS_N (&cpad->info) > 0)
+        dur = gst_util_uint64_scale (GST_SECOND, GST_VIDEO_INFO_FPS_D (&cpad->info), GST_VIDEO_INFO_FPS_N (&cpad->info));
+      else
+        dur = out_dur;
+      end = start + dur;
+      if (apad->segment.format == GST_FORMAT_TIME) {
+        guint64 cs, ce;
+        if (!gst_segment_clip (&apad->segment, GST_FORMAT_TIME, start, end, &cs, &ce)) {
+          GST_DEBUG_OBJECT (cpad, "buffer outside of its segment: dropped");
+          gst_buffer_unref (buf);
+          gst_aggregator_pad_drop_buffer (apad);
+          need_more = TRUE;
+          continue;
+        }
+        start = gst_segment_to_running_time (&apad->segment, GST_FORMAT_TIME, cs);
+        end = gst_segment_to_running_time (&apad->segment, GST_FORMAT_TIME, ce);
+      }
+      if (cpad->cur && GST_CLOCK_TIME_IS_VALID (cpad->cur_end) && cpad->cur_end > end) {
+        GST_DEBUG_OBJECT (cpad, "buffer from the past: dropped");
+        gst_buffer_unref (buf);
+        gst_aggregator_pad_drop_buffer (apad);
+        need_more = TRUE;
+        continue;
+      }
+      if (end >= out_start && start < out_end) {           /* this frame's buffer */
+        GST_LOG_OBJECT (cpad, "taking buffer %" GST_TIME_FORMAT " - %" GST_TIME_FORMAT " for output %" GST_TIME_FORMAT, GST_TIME_ARGS (start), GST_TIME_ARGS (end), GST_TIME_ARGS (out_start));
+        gst_buffer_replace (&cpad->cur, buf);
+        cpad->cur_start = start; cpad->cur_end = end;
+        gst_buffer_unref (buf);
+        gst_aggregator_pad_drop_buffer (apad);
+        eos = FALSE;
+        break;
+      }
+      if (start >= out_end) {                              /* for a later output frame: stays queued, the current buffer repeats */
+        GST_LOG_OBJECT (cpad, "keeping buffer %" GST_TIME_FORMAT " for later, repeating the current one", GST_TIME_ARGS (start));
+        gst_buffer_unref (buf);
+        eos = FALSE;
+        break;
+      }
+      GST_DEBUG_OBJECT (cpad, "buffer %" GST_TIME_FORMAT " - %" GST_TIME_FORMAT " is too old for output %" GST_TIME_FORMAT ": dropped", GST_TIME_ARGS (start), GST_TIME_ARGS (end), GST_TIME_ARGS (out_start));
+      gst_buffer_unref (buf);
+      gst_aggregator_pad_drop_buffer (apad);
+      need_more = TRUE;
+    }
+  }
+  (void) self;
+  if (need_more)
+    return GST_AGGREGATOR_FLOW_NEED_DATA;
+  return eos ? GST_FLOW_EOS : GST_FLOW_OK;
+}
+
+static void
+comp_drop_current_buffers (GstVfHipCompositor * self)
+{
+  GList *l, *pads = NULL;
+  GST_OBJECT_LOCK (self);
+  for (l = GST_ELEMENT (self)->sinkpads; l; l = l->next)
+    pads = g_list_prepend (pads, gst_object_ref (l->data));
+  GST_OBJECT_UNLOCK (self);
+  for (l = pads; l; l = l->next) {
+    GstVfHipCompositorPad *cpad = CPAD (l->data);
+    gst_buffer_replace (&cpad->cur, NULL);
+    cpad->cur_start = cpad->cur_end = GST_CLOCK_TIME_NONE;
+    gst_object_unref (l->data);
+  }
+  g_list_free (pads);
+  self->n_frames = 0;
+  self->ts_offset = GST_CLOCK_TIME_NONE;
+}
+
 static GstFlowReturn
 comp_aggregate (GstAggregator * agg, gboolean timeout)
 {
   GstVfHipCompositor *self = COMP (agg);
   GList *l;
-  guint n = 0, i, used = 0, n_eos = 0;
+  guint n = 0, i, used = 0;
+  GstClockTime out_start, out_end, out_start_rt, out_end_rt, out_dur;
+  gint fps_n, fps_d;
+  GstFlowReturn sel;
+  GstSegment *seg = &GST_AGGREGATOR_PAD (agg->srcpad)->segment;      /* the output segment lives on the src pad since 1.14 */
   PadRef *refs;
   GstBuffer **bufs, *outbuf;
   GstVideoFrame *frames, out;
@@ -944,11 +564,33 @@ comp_aggregate (GstAggregator * agg, gboolean timeout)
   bufs = g_new0 (GstBuffer *, MAX (n, 1));
   frames = g_new0 (GstVideoFrame, MAX (n, 1));
   pads = g_new0 (VfHipPadInput, MAX (n, 1));
-  for (i = 0; i < n; i++) {                                /* take this frame's buffer of every pad */
-    GstVfHipCompositorPad *cpad = refs[i].pad;
-    if (gst_aggregator_pad_is_eos (GST_AGGREGATOR_PAD (cpad))) { n_eos++; continue; }
-    bufs[i] = gst_aggregator_pad_pop_buffer (GST_AGGREGATOR_PAD (cpad));
+  /* this output frame: [position, ts_offset + (n_frames + 1) / fps) of the src segment — cut on the OUTPUT frame rate, whatever
+   * the inputs run at (GstVideoAggregator's time line: gst_video_aggregator_aggregate) */
+  fps_n = GST_VIDEO_INFO_FPS_N (&self->out_info); fps_d = GST_VIDEO_INFO_FPS_D (&self->out_info);
+  if (fps_n <= 0 || fps_d <= 0) { fps_n = 25; fps_d = 1; }
+  if (!GST_CLOCK_TIME_IS_VALID (seg->position) || seg->position < seg->start)
+    seg->position = seg->start;
+  out_start = seg->position;
+  if (self->n_frames == 0 || !GST_CLOCK_TIME_IS_VALID (self->ts_offset))
+    self->ts_offset = out_start;
+  out_end = self->ts_offset + gst_util_uint64_scale_round (self->n_frames + 1, GST_SECOND * fps_d, fps_n);
+  if (GST_CLOCK_TIME_IS_VALID (seg->stop))
+    out_end = MIN (out_end, seg->stop);
+  out_dur = gst_util_uint64_scale_round (1, GST_SECOND * fps_d, fps_n);
+  out_start_rt = gst_segment_to_running_time (seg, GST_FORMAT_TIME, out_start);
+  out_end_rt = gst_segment_to_running_time (seg, GST_FORMAT_TIME, out_end);
+  sel = (out_end <= out_start && GST_CLOCK_TIME_IS_VALID (seg->stop)) ? GST_FLOW_EOS :
+      comp_fill_queues (self, refs, n, out_start_rt, out_end_rt, out_dur);
+  if (sel != GST_FLOW_OK) {
+    if (sel == GST_FLOW_EOS) {
+      rc = comp_finish_pending (self, TRUE);               /* the last frame of an async-depth=1 stream */
+      if (rc == GST_FLOW_OK) rc = GST_FLOW_EOS;
+    } else
+      rc = sel;                                            /* GST_AGGREGATOR_FLOW_NEED_DATA: aggregate () runs again when the pads have data */
+    goto done;
   }
+  for (i = 0; i < n; i++)                                  /* this composite holds its own reference (it may stay in flight: async-depth) */
+    bufs[i] = refs[i].pad->cur ? gst_buffer_ref (refs[i].pad->cur) : NULL;
   for (i = 0; i < n; i++) {
     GstVfHipCompositorPad *cpad = refs[i].pad;
     gint w, h, xo, yo;
@@ -985,11 +627,6 @@ comp_aggregate (GstAggregator * agg, gboolean timeout)
       covered = TRUE;                                      /* background invisible: TRANSPARENT like the reference (:649-651) */
     used++;
   }
-  if (n > 0 && n_eos == n) {
-    rc = comp_finish_pending (self, TRUE);                 /* the last frame of an async-depth=1 stream */
-    if (rc == GST_FLOW_OK) rc = GST_FLOW_EOS;
-    goto done;
-  }
   alloc = self->out_is_device ? gst_vfhip_device_allocator_get (gst_vfhip_element_device (self)) : gst_vfhip_pinned_allocator_get ();
   outbuf = gst_buffer_new_allocate (alloc, GST_VIDEO_INFO_SIZE (&self->out_info), NULL);
   gst_object_unref (alloc);
@@ -1009,10 +646,9 @@ comp_aggregate (GstAggregator * agg, gboolean timeout)
       rc = GST_FLOW_ERROR;
       goto done;
     }
-    if (GST_VIDEO_INFO_FPS_N (&self->out_info) > 0) {
-      GST_BUFFER_PTS (outbuf) = gst_util_uint64_scale (self->n_frames, GST_SECOND * GST_VIDEO_INFO_FPS_D (&self->out_info), GST_VIDEO_INFO_FPS_N (&self->out_info));
-      GST_BUFFER_DURATION (outbuf) = gst_util_uint64_scale (1, GST_SECOND * GST_VIDEO_INFO_FPS_D (&self->out_info), GST_VIDEO_INFO_FPS_N (&self->out_info));
-    }
+    GST_BUFFER_PTS (outbuf) = out_start;
+    GST_BUFFER_DURATION (outbuf) = out_end - out_start;
+    seg->position = out_end;
     self->n_frames++;
     rc = comp_finish_pending (self, TRUE);
     self->pending.outbuf = outbuf; self->pending.out = out; self->pending.n = n; self->pending.bufs = bufs; self->pending.frames = frames;
@@ -1028,10 +664,9 @@ comp_aggregate (GstAggregator * agg, gboolean timeout)
     rc = GST_FLOW_ERROR;
     goto done;
   }
-  if (GST_VIDEO_INFO_FPS_N (&self->out_info) > 0) {
-    GST_BUFFER_PTS (outbuf) = gst_util_uint64_scale (self->n_frames, GST_SECOND * GST_VIDEO_INFO_FPS_D (&self->out_info), GST_VIDEO_INFO_FPS_N (&self->out_info));
-    GST_BUFFER_DURATION (outbuf) = gst_util_uint64_scale (1, GST_SECOND * GST_VIDEO_INFO_FPS_D (&self->out_info), GST_VIDEO_INFO_FPS_N (&self->out_info));
-  }
+  GST_BUFFER_PTS (outbuf) = out_start;
+  GST_BUFFER_DURATION (outbuf) = out_end - out_start;
+  seg->position = out_end;
   self->n_frames++;
   rc = gst_aggregator_finish_buffer (agg, outbuf);
 done:
@@ -1109,6 +744,7 @@ static GstFlowReturn
 comp_flush (GstAggregator * agg)
 {
   (void) comp_finish_pending (COMP (agg), FALSE);          /* a flushed frame is completed and dropped */
+  comp_drop_current_buffers (COMP (agg));                  /* the time line restarts at the new segment */
   return GST_FLOW_OK;
 }
 
@@ -1119,7 +755,7 @@ comp_stop (GstAggregator * agg)
   (void) comp_finish_pending (self, FALSE);
   if (self->renderer)
     vfhip_compositor_cleanup (self->renderer);
-  self->n_frames = 0;
+  comp_drop_current_buffers (self);
   self->have_out_info = FALSE;
   return TRUE;
 }
@@ -1242,6 +878,7 @@ gst_vfhip_compositor_class_init (GstVfHipCompositorClass * klass)
   gst_element_class_add_static_pad_template_with_gtype (ec, &comp_sink_template, gst_vfhip_compositor_pad_get_type ());
   gst_element_class_set_static_metadata (ec, "HIP Compositor", "Filter/Editor/Video/Compositor",
       "MI355X-accelerated compositing of multiple video streams", "vfhip");
+  GST_DEBUG_CATEGORY_INIT (gst_vfhip_compositor_debug, "vfhipcompositor", 0, "vfhip compositor (reference: gstvfmetalcompositor.m:1068-1069)");
 }
 
 static void
@@ -1250,6 +887,7 @@ gst_vfhip_compositor_init (GstVfHipCompositor * self)
   self->background = VFHIP_BG_CHECKER;
   self->zero_size_is_unscaled = TRUE;
   self->device_id = GST_VFHIP_DEFAULT_DEVICE_ID;
+  self->ts_offset = GST_CLOCK_TIME_NONE;
   gst_video_info_init (&self->out_info);
 }
 
@@ -1263,4 +901,3 @@ gst_vfhip_compositor_register (GstPlugin * plugin)
   return ok;
 }
 
-#endif

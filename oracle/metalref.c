@@ -503,7 +503,7 @@ int metalref_compositor (const MrPad *pads, int n, int background, const MrImg *
         F4 o;
         if (pd->blend == MR_BLEND_SOURCE) o = s;
         else if (pd->blend == MR_BLEND_ADD) { o.r = s.r + d.r; o.g = s.g + d.g; o.b = s.b + d.b; o.a = s.a + d.a; }
-        else { const float k1 = 1.0f - s.a; o.r = s.r + d.r * k1; o.g = s.g + d.g * k1; o.b = s.b + d.b * k1; o.a = s.a + d.a * k1; }
+        else { const float k1 = 1.0f - s.a; o.r = fmaf (d.r, k1, s.r); o.g = fmaf (d.g, k1, s.g); o.b = fmaf (d.b, k1, s.b); o.a = fmaf (d.a, k1, s.a); }
         q[(size_t) y * w + x] = quant_rgba8 (o);
       }
   }

@@ -3,7 +3,7 @@
 set -o pipefail
 TAG=${1:-pmce}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
-B="python tools/bench_elements.py ${2:-main}"
+B="python3 tools/bench_elements.py ${2:-main}"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pmc_stats -- $B > $OUT/stats.jsonl 2> $OUT/stats.err || { tail $OUT/stats.err; exit 1; }
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B > $OUT/pmc_fetch.jsonl 2> $OUT/pmc_fetch.err || { tail $OUT/pmc_fetch.err; exit 1; }
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B > $OUT/pmc_write.jsonl 2> $OUT/pmc_write.err || { tail $OUT/pmc_write.err; exit 1; }
@@ -28,5 +28,8 @@ for k, c in d.items():
         line.append(f"write {g['WRITE_SIZE'] * 1024 / 1e6:.1f} MB")
     if "GRBM_GUI_ACTIVE" in g:
         line.append(f"gui_active {g['GRBM_GUI_ACTIVE']:.0f}")
+    if "GRBM_GUI_ACTIVE" in g and "SQ_ACTIVE_INST_VALU" in g:
+        # SQ_* count quad-cycles summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs' busy cycles (MI355X_MICROARCH.md)
+        line.append(f"valu_busy {g['SQ_ACTIVE_INST_VALU'] * 4 / (g['GRBM_GUI_ACTIVE'] / 8 * 1024):.2f}")
     print("  ".join(line))
 PY
