@@ -1,17 +1,10 @@
 // csrc/vfhip_internal.h — shared internals of libvfhip (device singleton, errors, staging).
 #pragma once
 #include <hip/hip_runtime.h>
-#include <cstdarg>
-#include <cstdint>
-#include <cstdio>
-#include <cstring>
 #include <mutex>
-#include <vector>
-#include "../../include/vfhip.h"
+#include "vfhip_host.h"
 
 namespace vfhip {
-
-int set_error (int code, const char *fmt, ...) __attribute__ ((format (printf, 2, 3)));
 
 #define VFHIP_CHECK_HIP(expr)                                                                   \
   do {                                                                                            \
@@ -115,8 +108,6 @@ static inline void flights_abandon (Staging &st, Flights &fl)
 }  // namespace vfhip
 
 namespace vfhip {
-// PNG -> straight RGBA8 (image_png.hip; host code, zlib)
-int decode_png (const char *path, std::vector<uint8_t> &rgba, int *width, int *height);
 // shared argument checks of the element entry points
 int check_frame (const VfHipFrame *f, const VfHipVideoInfo *want, const char *what);
 }  // namespace vfhip

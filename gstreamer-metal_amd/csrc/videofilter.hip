@@ -107,7 +107,7 @@ __device__ __forceinline__ float vf_powf (float x, float y)
   float q = 1.98412698e-4f;
   q = fmaf (q, f, 1.38888889e-3f); q = fmaf (q, f, 8.33333333e-3f); q = fmaf (q, f, 4.16666667e-2f); q = fmaf (q, f, 0.16666667f);
   q = fmaf (q, f, 0.5f); q = fmaf (q, f, 1.0f); q = fmaf (q, f, 1.0f);
-  return __uint_as_float (__float_as_uint (q) + (uint32_t) ((int) zi << 23));
+  return __uint_as_float (__float_as_uint (q) + ((uint32_t) (int) zi << 23));
 }
 
 // applyColorAdjustments (metalvideofilter_shaders.h:92-155), fixed order.  Every `if` tests a wave-uniform parameter:
@@ -501,74 +501,19 @@ int vfhip_videofilter_set_lut (VfHipVideoFilter *h, const float *rgba, int size)
   return vf_upload_lut (h, rgba, size);
 }
 
-// .cube parser: LUT_3D_SIZE 2..64, RGB triplets with R fastest; TITLE / DOMAIN_* / LUT_1D_SIZE lines are skipped
-// (same acceptance rules as the reference's parse_cube_lut, videofilter/metalvideofilterrenderer.m:68-162).
-// PNG LUTs go through csrc/image_png.hip.
+// .cube and .png LUT files: parsed on the host (host_parsers.hip), uploaded like vfhip_videofilter_set_lut
 int vfhip_videofilter_load_lut (VfHipVideoFilter *h, const char *path)
 {
   if (!h || !path) return set_error (VFHIP_ERR_INVALID, "null argument");
   const size_t n = strlen (path);
-  if (n >= 4 && strcasecmp (path + n - 4, ".png") == 0) {
-    // PNG LUT (reference parse_png_lut, videofilter/metalvideofilterrenderer.m:166-305): N^3 == width * height, slices of
-    // N x N pixels (r across, g down) laid out left to right, top to bottom, width / N per row; value / 255, alpha 1.
-    // The 3D texture limit of vf_upload_lut (64) applies.
-    std::vector<uint8_t> px;
-    int w = 0, hh = 0;
-    int rc = decode_png (path, px, &w, &hh);
-    if (rc) return rc;
-    int size = 0;
-    for (int s = 2; s <= 256; s++) if ((long) s * s * s == (long) w * hh) { size = s; break; }
-    if (size == 0) return set_error (VFHIP_ERR_IO, "cannot determine the LUT size from a %dx%d PNG (%s)", w, hh, path);
-    const int per_row = w / size;
-    if (per_row == 0 || ((size + per_row - 1) / per_row) * size > hh) return set_error (VFHIP_ERR_IO, "LUT PNG %s: %dx%d does not hold %d slices of %dx%d", path, w, hh, size, size, size);
-    std::vector<float> lut ((size_t) size * size * size * 4, 1.0f);
-    for (int b = 0; b < size; b++)
-      for (int g = 0; g < size; g++)
-        for (int r = 0; r < size; r++) {
-          const uint8_t *s8 = &px[((size_t) ((b / per_row) * size + g) * w + (size_t) (b % per_row) * size + r) * 4];
-          float *d = &lut[(((size_t) b * size + g) * size + r) * 4];
-          // CoreGraphics hands the reference PREMULTIPLIED bytes (kCGImageAlphaPremultipliedLast): identical for the opaque
-          // PNGs LUTs are; for a translucent one its exact rounding is unpinned — (c * a + 127) / 255 here
-          const unsigned a = s8[3];
-          d[0] = (float) ((s8[0] * a + 127) / 255) / 255.0f; d[1] = (float) ((s8[1] * a + 127) / 255) / 255.0f; d[2] = (float) ((s8[2] * a + 127) / 255) / 255.0f;
-        }
-    std::lock_guard<std::mutex> lk (h->mu);
-    return vf_upload_lut (h, lut.data (), size);
-  }
-  if (n < 5 || strcasecmp (path + n - 5, ".cube") != 0)
-    return set_error (VFHIP_ERR_UNSUPPORTED, "LUT files must be .cube or .png (got %s)", path);
-  FILE *fp = fopen (path, "r");
-  if (!fp) return set_error (VFHIP_ERR_IO, "cannot open LUT file %s", path);
-  int size = 0;
-  std::vector<float> data;
-  size_t count = 0, want = 0;
-  char line[512];
-  int rc = VFHIP_OK;
-  while (fgets (line, sizeof (line), fp)) {
-    const char *p = line;
-    while (*p && isspace ((unsigned char) *p)) p++;
-    if (*p == '#' || *p == '\0') continue;
-    if (strncmp (p, "LUT_3D_SIZE", 11) == 0) {
-      size = atoi (p + 11);
-      if (size < 2 || size > 64) { rc = set_error (VFHIP_ERR_IO, "invalid LUT_3D_SIZE %d in %s", size, path); break; }
-      want = (size_t) size * size * size;
-      data.assign (want * 4, 1.0f);
-      count = 0;
-      continue;
-    }
-    if (strncmp (p, "TITLE", 5) == 0 || strncmp (p, "DOMAIN_MIN", 10) == 0 || strncmp (p, "DOMAIN_MAX", 10) == 0 || strncmp (p, "LUT_1D_SIZE", 11) == 0)
-      continue;
-    float r, g, b;
-    if (size > 0 && count < want && sscanf (p, "%f %f %f", &r, &g, &b) == 3) {
-      data[count * 4 + 0] = r; data[count * 4 + 1] = g; data[count * 4 + 2] = b; data[count * 4 + 3] = 1.0f;
-      count++;
-    }
-  }
-  fclose (fp);
+  std::vector<float> lut;
+  int size = 0, rc;
+  if (n >= 4 && strcasecmp (path + n - 4, ".png") == 0) rc = parse_png_lut (path, lut, &size);
+  else if (n >= 5 && strcasecmp (path + n - 5, ".cube") == 0) rc = parse_cube_lut (path, lut, &size);
+  else return set_error (VFHIP_ERR_UNSUPPORTED, "LUT files must be .cube or .png (got %s)", path);
   if (rc) return rc;
-  if (size == 0 || count != want) return set_error (VFHIP_ERR_IO, "incomplete .cube LUT %s: expected %zu entries, got %zu", path, want, count);
   std::lock_guard<std::mutex> lk (h->mu);
-  return vf_upload_lut (h, data.data (), size);
+  return vf_upload_lut (h, lut.data (), size);
 }
 
 void vfhip_videofilter_clear_lut (VfHipVideoFilter *h)

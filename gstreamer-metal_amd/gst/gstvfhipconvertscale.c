@@ -15,7 +15,9 @@
 #include <gst/base/gstbasetransform.h>
 #include "gstvfhip.h"
 
-#define GST_CAT_DEFAULT gst_vfhip_debug
+/* the element's own debug category, like the reference's (convertscale/gstvfmetalconvertscale.m:538-539); shared helpers log to `vfhip` */
+GST_DEBUG_CATEGORY_STATIC (gst_vfhip_convertscale_debug);
+#define GST_CAT_DEFAULT gst_vfhip_convertscale_debug
 #define VFHIP_CS_FORMATS "{ BGRA, RGBA, NV12, I420, UYVY, YUY2 }"
 
 typedef struct
@@ -468,6 +470,7 @@ gst_vfhip_convertscale_class_init (GstVfHipConvertScaleClass * klass)
   gst_element_class_add_static_pad_template (ec, &cs_src_template);
   gst_element_class_set_static_metadata (ec, "HIP Video Convert and Scale", "Filter/Converter/Video/Scaler",
       "MI355X-accelerated video format conversion and scaling", "vfhip");
+  GST_DEBUG_CATEGORY_INIT (gst_vfhip_convertscale_debug, "vfhipconvertscale", 0, "vfhipconvertscale element");
 }
 
 static void

@@ -11,7 +11,9 @@
 #include <gst/video/gstvideofilter.h>
 #include "gstvfhip.h"
 
-#define GST_CAT_DEFAULT gst_vfhip_debug
+/* the element's own debug category, like the reference's (deinterlace/gstvfmetaldeinterlace.m:351-352); shared helpers log to `vfhip` */
+GST_DEBUG_CATEGORY_STATIC (gst_vfhip_deinterlace_debug);
+#define GST_CAT_DEFAULT gst_vfhip_deinterlace_debug
 #define VFHIP_DI_FORMATS "{ BGRA, RGBA, NV12, I420 }"
 
 typedef struct
@@ -76,6 +78,7 @@ di_set_info (GstVideoFilter * filter, GstCaps * incaps, GstVideoInfo * in_info, 
   GstVfHipDeinterlace *self = DI (filter);
   VfHipVideoInfo info;
   (void) incaps; (void) outcaps; (void) out_info;
+  GST_DEBUG_OBJECT (filter, "caps %" GST_PTR_FORMAT " -> %" GST_PTR_FORMAT, incaps, outcaps);
   if (!self->renderer && !(self->renderer = vfhip_deinterlace_new (self->device_id))) {
     GST_ERROR_OBJECT (self, "no HIP renderer: %s", vfhip_last_error_string ());
     return FALSE;
@@ -261,6 +264,7 @@ gst_vfhip_deinterlace_class_init (GstVfHipDeinterlaceClass * klass)
   gst_element_class_add_static_pad_template (ec, &di_src_template);
   gst_element_class_set_static_metadata (ec, "HIP Video Deinterlace", "Filter/Effect/Video/Deinterlace",
       "MI355X-accelerated deinterlacing (bob, weave, linear, greedy-H)", "vfhip");
+  GST_DEBUG_CATEGORY_INIT (gst_vfhip_deinterlace_debug, "vfhipdeinterlace", 0, "vfhipdeinterlace element");
 }
 
 static void

@@ -81,8 +81,11 @@ device_map_full (GstMemory * mem, GstMapInfo * info, gsize maxsize)
     return m->dev;
   g_mutex_lock (&m->lock);
   if (!m->shadow)
-    m->shadow = g_malloc (maxsize);
-  if ((info->flags & GST_MAP_READ) && vfhip_memcpy_d2h (m->device, m->shadow, m->dev, maxsize) != VFHIP_OK) {
+    m->shadow = g_malloc0 (maxsize);
+  /* ALWAYS bring the device contents into the shadow, also for a write-only mapping: unmap (WRITE) uploads the whole shadow,
+   * so any byte the mapper does not write (a partial write, the padding of a stride) must hold what the device holds — an
+   * uninitialised or stale shadow would overwrite valid frame data in HBM */
+  if (vfhip_memcpy_d2h (m->device, m->shadow, m->dev, maxsize) != VFHIP_OK) {
     GST_ERROR ("download for a CPU mapping failed: %s", vfhip_last_error_string ());
     g_mutex_unlock (&m->lock);
     return NULL;

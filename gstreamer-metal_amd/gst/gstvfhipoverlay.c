@@ -12,7 +12,9 @@
 #include <gst/video/gstvideofilter.h>
 #include "gstvfhip.h"
 
-#define GST_CAT_DEFAULT gst_vfhip_debug
+/* the element's own debug category, like the reference's (overlay/gstvfmetaloverlay.m); shared helpers log to `vfhip` */
+GST_DEBUG_CATEGORY_STATIC (gst_vfhip_overlay_debug);
+#define GST_CAT_DEFAULT gst_vfhip_overlay_debug
 #define VFHIP_OV_FORMATS "{ BGRA, RGBA, NV12, I420 }"
 
 typedef struct
@@ -82,6 +84,7 @@ ov_set_info (GstVideoFilter * filter, GstCaps * incaps, GstVideoInfo * in_info, 
   GstVfHipOverlay *self = OV (filter);
   VfHipVideoInfo in, out;
   (void) incaps; (void) outcaps;
+  GST_DEBUG_OBJECT (filter, "caps %" GST_PTR_FORMAT " -> %" GST_PTR_FORMAT, incaps, outcaps);
   if (!ov_ensure_renderer (self))
     return FALSE;
   gst_vfhip_info (in_info, &in);
@@ -308,6 +311,7 @@ gst_vfhip_overlay_class_init (GstVfHipOverlayClass * klass)
   gst_element_class_add_static_pad_template (ec, &ov_src_template);
   gst_element_class_set_static_metadata (ec, "HIP Video Overlay", "Filter/Effect/Video",
       "MI355X-accelerated image overlay (logo / watermark) on video", "vfhip");
+  GST_DEBUG_CATEGORY_INIT (gst_vfhip_overlay_debug, "vfhipoverlay", 0, "vfhipoverlay element");
 }
 
 static void

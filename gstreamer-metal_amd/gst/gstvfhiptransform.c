@@ -10,7 +10,9 @@
 #include <gst/video/gstvideofilter.h>
 #include "gstvfhip.h"
 
-#define GST_CAT_DEFAULT gst_vfhip_debug
+/* the element's own debug category, like the reference's (transform/gstvfmetaltransform.m); shared helpers log to `vfhip` */
+GST_DEBUG_CATEGORY_STATIC (gst_vfhip_transform_debug);
+#define GST_CAT_DEFAULT gst_vfhip_transform_debug
 #define VFHIP_TR_FORMATS "{ BGRA, RGBA, NV12, I420 }"
 
 typedef struct
@@ -71,6 +73,7 @@ tr_set_info (GstVideoFilter * filter, GstCaps * incaps, GstVideoInfo * in_info, 
   GstVfHipTransform *self = TR (filter);
   VfHipVideoInfo in, out;
   (void) incaps; (void) outcaps;
+  GST_DEBUG_OBJECT (filter, "caps %" GST_PTR_FORMAT " -> %" GST_PTR_FORMAT, incaps, outcaps);
   if (!self->renderer && !(self->renderer = vfhip_transform_new (self->device_id))) {
     GST_ERROR_OBJECT (self, "no HIP renderer: %s", vfhip_last_error_string ());
     return FALSE;
@@ -269,6 +272,7 @@ gst_vfhip_transform_class_init (GstVfHipTransformClass * klass)
   gst_element_class_add_static_pad_template (ec, &tr_src_template);
   gst_element_class_set_static_metadata (ec, "HIP Video Transform", "Filter/Effect/Video",
       "MI355X-accelerated video flip, rotation and crop", "vfhip");
+  GST_DEBUG_CATEGORY_INIT (gst_vfhip_transform_debug, "vfhiptransform", 0, "vfhiptransform element");
 }
 
 static void

@@ -12,7 +12,9 @@
 #include <gst/video/gstvideofilter.h>
 #include "gstvfhip.h"
 
-#define GST_CAT_DEFAULT gst_vfhip_debug
+/* the element's own debug category, like the reference's (videofilter/gstvfmetalvideofilter.m:546-547); shared helpers log to `vfhip` */
+GST_DEBUG_CATEGORY_STATIC (gst_vfhip_videofilter_debug);
+#define GST_CAT_DEFAULT gst_vfhip_videofilter_debug
 #define VFHIP_VF_FORMATS "{ BGRA, RGBA, NV12, I420 }"
 
 typedef struct
@@ -83,6 +85,7 @@ vf_set_info (GstVideoFilter * filter, GstCaps * incaps, GstVideoInfo * in_info, 
   GstVfHipVideoFilter *self = VF (filter);
   VfHipVideoInfo in, out;
   (void) incaps; (void) outcaps;
+  GST_DEBUG_OBJECT (filter, "caps %" GST_PTR_FORMAT " -> %" GST_PTR_FORMAT, incaps, outcaps);
   if (!vf_ensure_renderer (self))
     return FALSE;
   gst_vfhip_info (in_info, &in);
@@ -351,6 +354,7 @@ gst_vfhip_videofilter_class_init (GstVfHipVideoFilterClass * klass)
   gst_element_class_add_static_pad_template (ec, &vf_src_template);
   gst_element_class_set_static_metadata (ec, "HIP Video Filter", "Filter/Effect/Video",
       "MI355X-accelerated single-pass colour adjustments, sharpen/blur, chroma key, vignette, grain and 3D LUT", "vfhip");
+  GST_DEBUG_CATEGORY_INIT (gst_vfhip_videofilter_debug, "vfhipvideofilter", 0, "vfhipvideofilter element");
 }
 
 static void

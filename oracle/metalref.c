@@ -346,7 +346,7 @@ static inline float vf_powf (float x, float y)
   q = fmaf (q, f, 1.38888889e-3f); q = fmaf (q, f, 8.33333333e-3f); q = fmaf (q, f, 4.16666667e-2f); q = fmaf (q, f, 0.16666667f);
   q = fmaf (q, f, 0.5f); q = fmaf (q, f, 1.0f); q = fmaf (q, f, 1.0f);
   uint32_t uq; memcpy (&uq, &q, 4);
-  uq += (uint32_t) ((int) zi << 23);
+  uq += (uint32_t) (int32_t) zi << 23;              /* unsigned shift: zi is negative for x < 1 */
   float r; memcpy (&r, &uq, 4);
   return r;
 }

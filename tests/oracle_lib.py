@@ -9,7 +9,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB = os.path.join(ORACLE_DIR, "libvfhip_oracle.so")
+LIB = os.environ.get("VFHIP_ORACLE_LIB") or os.path.join(ORACLE_DIR, "libvfhip_oracle.so")   # override: the sanitizer build (tests/test_parsers_asan.py)
 MATRIX = {"bt601": 0, "bt709": 1, "bt2020": 2}
 
 

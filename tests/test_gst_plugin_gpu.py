@@ -435,11 +435,11 @@ def test_compositor_skips_obscured_pads(tmp_path):
                            f"videotestsrc num-buffers=2 pattern=smpte ! {caps('NV12', 320, 240)} ! c.sink_{1 if with_lower else 0}", timeout=60, debug=debug)
         assert r.returncode == 0, r.stderr
         return np.fromfile(path, np.uint8), r.stderr
-    both, log = run("over", True, debug="vfhip:7")
+    both, log = run("over", True, debug="vfhip*:7")
     only, _ = run("over", False)
     assert both.size == only.size == 2 * 320 * 240 * 4 and np.array_equal(both, only)
     assert "obscured by a later opaque pad" in log
-    added, log = run("add", True, debug="vfhip:7")
+    added, log = run("add", True, debug="vfhip*:7")
     assert "obscured by a later opaque pad" not in log and not np.array_equal(added, only)
 
 
@@ -463,3 +463,59 @@ def test_compositor_forwards_pointer_events_to_the_pads_under_them(tmp_path):
     assert both["a"] == (240.0, 130.0) and both["b"] == ((240 - 200) * 80 / 160, (130 - 100) * 120 / 60)
     assert seen(340, 120) == {"b": ((340 - 200) * 80 / 160, (120 - 100) * 120 / 60)}   # right of pad a's 320 columns
     assert seen(340, 200) == {}                                                   # background only
+
+
+def test_compositor_mixed_frame_rates(tmp_path):
+    """a 30 fps and a 15 fps input into one 30 fps output (the reference is a GstVideoAggregator: per-pad buffer selection by
+    running time, gstvfmetalcompositor.m:171-174; its tests/test-compositor.sh mixes sources freely): the output runs at the
+    faster rate for as long as the inputs last, the fast pad contributes every one of its frames in order, the slow pad's
+    frames are each shown for two consecutive output frames (one either way at the 1 ns rounding of the frame times)."""
+    a, b, o = tmp_path / "a.raw", tmp_path / "b.raw", tmp_path / "o.raw"
+    r = gst_env.launch(f"vfhipcompositor name=c background=black sink_1::xpos=320 ! {caps('BGRA', 640, 240)},framerate=30/1 ! filesink location={o} "
+                       f"videotestsrc num-buffers=12 pattern=ball ! {caps('BGRA', 320, 240)},framerate=30/1 ! tee name=ta ta. ! queue ! c.sink_0 ta. ! queue ! filesink location={a} "
+                       f"videotestsrc num-buffers=6 pattern=ball ! {caps('BGRA', 320, 240)},framerate=15/1 ! tee name=tb tb. ! queue ! c.sink_1 tb. ! queue ! filesink location={b}", timeout=120)
+    assert r.returncode == 0, r.stderr
+    fa, fb, fo = np.fromfile(a, np.uint8).reshape(-1, 240, 320, 4), np.fromfile(b, np.uint8).reshape(-1, 240, 320, 4), np.fromfile(o, np.uint8).reshape(-1, 240, 640, 4)
+    assert len(fa) == 12 and len(fb) == 6
+    assert len(fo) == 12, f"{len(fo)} output frames: 0.4 s of input at 30 fps is 12"
+    assert all(not np.array_equal(fb[j], fb[j + 1]) for j in range(5)), "the slow source must change from frame to frame for this test to see repeats"
+    shown = []
+    for k in range(12):
+        assert np.array_equal(fo[k][:, :320], fa[k]), f"output frame {k}: the 30 fps pad must show its frame {k}"
+        match = [j for j in range(6) if np.array_equal(fo[k][:, 320:], fb[j])]
+        assert match, f"output frame {k}: the right half is none of the 15 fps pad's frames"
+        assert match[0] in (k // 2, (k + 1) // 2), f"output frame {k} shows slow frame {match[0]}"
+        shown.append(match[0])
+    assert shown == sorted(shown) and set(shown) == set(range(6)), shown        # in order, none skipped, each repeated
+    assert max(shown.count(j) for j in range(6)) <= 3
+
+
+def test_compositor_drops_frames_of_a_faster_pad_and_repeats_after_eos(tmp_path):
+    """a 60 fps pad into a 30 fps output is decimated (old buffers dropped, never queued up: the output stays 0.2 s long), and a
+    pad with repeat-after-eos keeps its last frame on screen while the other pad runs on"""
+    o = tmp_path / "o.raw"
+    r = gst_env.launch(f"vfhipcompositor name=c background=black sink_1::xpos=160 ! {caps('BGRA', 320, 120)},framerate=30/1 ! filesink location={o} "
+                       f"videotestsrc num-buffers=6 pattern=ball ! {caps('BGRA', 160, 120)},framerate=30/1 ! c.sink_0 "
+                       f"videotestsrc num-buffers=12 pattern=ball ! {caps('BGRA', 160, 120)},framerate=60/1 ! c.sink_1", timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert np.fromfile(o, np.uint8).size == 6 * 320 * 120 * 4
+    r = gst_env.launch(f"vfhipcompositor name=c background=black sink_0::repeat-after-eos=true sink_1::xpos=160 ! {caps('BGRA', 320, 120)},framerate=30/1 ! filesink location={o} "
+                       f"videotestsrc num-buffers=2 pattern=smpte ! {caps('BGRA', 160, 120)},framerate=30/1 ! c.sink_0 "
+                       f"videotestsrc num-buffers=6 pattern=ball ! {caps('BGRA', 160, 120)},framerate=30/1 ! c.sink_1", timeout=120)
+    assert r.returncode == 0, r.stderr
+    fo = np.fromfile(o, np.uint8).reshape(-1, 120, 320, 4)
+    assert len(fo) == 6
+    assert all(np.array_equal(fo[k][:, :160], fo[1][:, :160]) for k in range(1, 6)) and fo[5][:, :160].any()      # the ended pad's last frame stays
+
+
+@pytest.mark.parametrize("element,chain", [("vfhipconvertscale", "vfhipconvertscale ! video/x-raw,format=BGRA,width=160,height=120"), ("vfhipvideofilter", "vfhipvideofilter brightness=0.1"),
+                                           ("vfhipdeinterlace", "vfhipdeinterlace"), ("vfhiptransform", "vfhiptransform method=clockwise"), ("vfhipoverlay", "vfhipoverlay"),
+                                           ("vfhipcompositor", "vfhipcompositor")])
+def test_every_element_has_its_own_debug_category(element, chain):
+    """GST_DEBUG=<element>:6 selects that element's log lines only (the reference registers one category per element, e.g.
+    convertscale/gstvfmetalconvertscale.m:538-539); the shared helpers stay on `vfhip`"""
+    r = gst_env.launch(f"{SRC} ! {caps('NV12', 320, 240)} ! {chain} ! fakesink", debug=f"{element}:6")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stderr.splitlines() if " vfhip" in ln]
+    assert lines, "no log line at level 6 from the element"
+    assert all(f" {element} " in ln for ln in lines), [ln for ln in lines if f" {element} " not in ln][:3]
