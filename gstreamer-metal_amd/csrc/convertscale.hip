@@ -15,6 +15,13 @@
 using namespace vfhip;
 
 // videoconvert's RGB -> YUV 8-bit integer matrices (oracle/gst114.c RGB2YUV, pinned against the real element)
+// videoconvert's 8-bit YUV -> YUV matrices, [matrix in][matrix out][row (Y, U, V) x (a, b, c, d)]: out = clamp8 (((a Y + b U + c V) >> 8) + d)
+// (probed on the real element: oracle/gst114.c YUV2YUV)
+static const int kYuv2Yuv[3][3][12] = {
+  { { 0 }, { 256, -30, -53, 41,   0, 261, 29, -18,   0, 19, 262, -13 }, { 256, -32, -29, 30,   0, 259, 16, -10,   0, 22, 264, -15 } },
+  { { 256, 25, 49, -38,   0, 253, -28, 15,   0, -19, 252, 11 }, { 0 }, { 256, -4, 24, -10,   0, 255, -13, 7,   0, 3, 257, -2 } },
+  { { 256, 30, 26, -28,   0, 255, -15, 8,   0, -22, 250, 13 }, { 256, 5, -24, 9,   0, 257, 13, -8,   0, -3, 255, 1 }, { 0 } },
+};
 static const int kRgb2Yuv[3][9] = {
   {  66, 129,  25,  -38,  -74, 112,  112,  -94, -18 },   // bt601
   {  47, 157,  16,  -26,  -87, 112,  112, -102, -10 },   // bt709
@@ -53,6 +60,7 @@ struct VfHipConvertScale {
   PlaneCfg plane[3];
   int n_out_planes = 0;
   bool need_convert = false, need_scale = false;
+  bool remat = false;               // stage 1 is videoconvert's generic YUV -> YUV path (matrix and / or siting change): k_yuv_to_yuv
   bool lb = false;                                    // staged path with borders: the planes are written through a sub-rectangle view
   void *nt_tmp = nullptr; size_t nt_tmp_bytes = 0;    // intermediate plane of the two-pass n-tap path (YUV outputs, method=bicubic)
   void *mid = nullptr; size_t mid_bytes = 0; int mid_frames = 0;   // mid_bytes: one intermediate frame; mid holds mid_frames of them
@@ -394,14 +402,16 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
   // chroma-sample boundaries (even x / width; even y / height as well for 4:2:0); otherwise metal arithmetic
   const bool lb = h->add_borders && (h->rw != out->width || h->rh != out->height);
   const bool lb_ok = !lb || (!((h->rx | h->rw) & 1) && (out_packed || !((h->ry | h->rh) & 1)));
+  // YUV -> YUV with a matrix change (any of the four YUV formats either side), or NV12 <-> I420 with a siting change: stage 1 is
+  // videoconvert's generic path (k_yuv_to_yuv).  With one matrix the siting may differ where GStreamer either ignores it (the same
+  // format on both sides: videoconvert passes through; I420 <-> packed fast paths; the UYVY <-> YUY2 swizzle) or resamples with
+  // both (NV12 <-> packed: the conversion kernels take both).
+  const bool remat = numerics == VFHIP_NUMERICS_GST_EXACT && any_yuv_in && (out_420 || out_packed) &&
+                     (in->color_matrix != out->color_matrix || (in_yuv && out_420 && in->format != out->format && in->chroma_site != out->chroma_site));
+  h->remat = false;
   const bool staged = numerics == VFHIP_NUMERICS_GST_EXACT && lb_ok &&
                       ((in_420_or_rgb && out_420) || out_packed || (in_packed && out_420)) &&
-                      !(out_packed && in->width == 2 && h->rw != 2) &&
-                      (!any_yuv_in || (in->color_matrix == out->color_matrix &&
-                                       // the siting may differ where GStreamer either ignores it (the same format on both sides: videoconvert
-                                       // passes through; I420 <-> packed fast paths; the UYVY <-> YUY2 swizzle) or resamples with both (NV12 <->
-                                       // packed, the kernels take both); NV12 <-> I420 with a siting change is a resampling that is not restated
-                                       (in->chroma_site == out->chroma_site || in->format == out->format || !(in_yuv && out_420))));
+                      !(out_packed && in->width == 2 && h->rw != 2);
   if (method == VFHIP_SCALE_BICUBIC && !staged) {
     const int iw = in->width, ih = in->height, ow = h->rw, oh = h->rh;      // the destination rectangle (= the frame without borders)
     if (numerics != VFHIP_NUMERICS_GST_EXACT || !(in_420_or_rgb || in_packed) || !out_rgb)
@@ -446,7 +456,8 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
   if (staged) {
     const int iw = in->width, ih = in->height, ow = h->rw, oh = h->rh;      // the destination rectangle (= the frame without borders)
     h->lb = lb;
-    h->need_convert = in->format != out->format;
+    h->remat = remat;
+    h->need_convert = in->format != out->format || remat;
     h->need_scale = iw != ow || ih != oh;
     h->n_out_planes = out->format == VFHIP_FORMAT_NV12 ? 2 : 3;
     if (out_packed) {
@@ -619,7 +630,28 @@ static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
   const int cw = (iw + 1) / 2, chh = (ih + 1) / 2;
   if (h->need_convert) {
     dim3 grid ((unsigned) ((cw + 63) / 64), (unsigned) (((out_packed ? ih : chh) + 3) / 4), nz);
-    if (out_packed) {
+    if (h->remat) {
+      YuvRematParams p {};
+      p.in_pitch = in_pitch; p.out_pitch = mid_pitch;
+      auto spec = [] (const VfHipFrame &f, int fmt, const uint8_t **y, const uint8_t **u, const uint8_t **v, int *ys, int *ystep, int *cs, int *cstep, int *is420) {
+        const uint8_t *b0 = (const uint8_t *) f.data[0];
+        if (fmt == VFHIP_FORMAT_NV12) { *y = b0; *ys = f.stride[0]; *ystep = 1; *u = (const uint8_t *) f.data[1]; *v = *u + 1; *cs = f.stride[1]; *cstep = 2; *is420 = 1; }
+        else if (fmt == VFHIP_FORMAT_I420) { *y = b0; *ys = f.stride[0]; *ystep = 1; *u = (const uint8_t *) f.data[1]; *v = (const uint8_t *) f.data[2]; *cs = f.stride[1]; *cstep = 1; *is420 = 1; }
+        else { const int yuy2 = fmt == VFHIP_FORMAT_YUY2; *y = b0 + (yuy2 ? 0 : 1); *u = b0 + (yuy2 ? 1 : 0); *v = b0 + (yuy2 ? 3 : 2); *ys = *cs = f.stride[0]; *ystep = 2; *cstep = 4; *is420 = 0; }
+      };
+      const uint8_t *oy, *ou, *ov;
+      spec (*in, h->in.format, &p.iy, &p.iu, &p.iv, &p.iys, &p.iystep, &p.ics, &p.icstep, &p.in420);
+      spec (mid, h->out.format, &oy, &ou, &ov, &p.oys, &p.oystep, &p.ocs, &p.ocstep, &p.out420);
+      if (h->in.format == VFHIP_FORMAT_I420 && in->stride[2] != in->stride[1]) return set_error (VFHIP_ERR_UNSUPPORTED, "I420 input with different U and V strides");
+      if (h->out.format == VFHIP_FORMAT_I420 && mid.stride[2] != mid.stride[1]) return set_error (VFHIP_ERR_UNSUPPORTED, "I420 output with different U and V strides");
+      p.oy = const_cast<uint8_t *> (oy); p.ou = const_cast<uint8_t *> (ou); p.ov = const_cast<uint8_t *> (ov);
+      p.w = iw; p.h = ih;
+      p.cos_in = h->in.chroma_site == VFHIP_CHROMA_SITE_H_COSITED; p.cos_out = h->out.chroma_site == VFHIP_CHROMA_SITE_H_COSITED;
+      p.remat = h->in.color_matrix != h->out.color_matrix;
+      p.same = p.cos_in == p.cos_out && p.in420 == p.out420;
+      for (int k = 0; k < 12; k++) p.t[k] = kYuv2Yuv[h->in.color_matrix][h->out.color_matrix][k];
+      hipLaunchKernelGGL (k_yuv_to_yuv, grid, dim3 (64, 4), 0, s, p);
+    } else if (out_packed) {
       ToPackedParams p {};
       p.in_pitch = in_pitch; p.out_pitch = mid_pitch;
       for (int k = 0; k < 3; k++) { p.in[k] = (const uint8_t *) in->data[k]; p.is[k] = in->stride[k]; }

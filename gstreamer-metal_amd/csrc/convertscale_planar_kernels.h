@@ -166,6 +166,85 @@ __global__ __launch_bounds__ (256) void k_repack_420 (const RepackParams p0)
     }
 }
 
+// ---- stage 1 for YUV -> YUV with a MATRIX change (NV12 / I420 / UYVY / YUY2 either side) or NV12 <-> I420 with a SITING change ----
+// videoconvert's generic path (oracle/gst114.c gst114_yuv_to_yuv; 50 real-pipeline vectors, tests/golden/convertscale_gst114_remat.npz):
+//   same siting and the same subsampling on both sides: every luma sample is matrixed with its nearest chroma sample, every output
+//     chroma sample is the matrixed input chroma sample;
+//   otherwise: chroma up-sampled to 4:4:4 with the input siting (horizontal, then — 4:2:0 only — vertical 3:1 over an even number
+//     of lines), the 8-bit matrix out = clamp8 (((a Y + b U + c V) >> 8) + d) per sample, chroma down-sampled with the output
+//     siting (vertical pair average for 4:2:0, then horizontal).
+// One lane = one OUTPUT chroma sample and the luma samples under it.  A rare cell: written for exactness, not for bandwidth.
+struct YuvRematParams {
+  size_t in_pitch, out_pitch;
+  const uint8_t *iy, *iu, *iv; int iys, iystep, ics, icstep, in420;      // luma x of row y: iy[y * iys + x * iystep]; chroma k of row j: iu[j * ics + k * icstep]
+  uint8_t *oy, *ou, *ov; int oys, oystep, ocs, ocstep, out420;
+  int w, h, cos_in, cos_out, remat, same;
+  int t[12];                                                             // rows Y, U, V x (a, b, c, d)
+};
+
+__device__ __forceinline__ int remat_row (const int *r, int y, int u, int v) { return min (max (((r[0] * y + r[1] * u + r[2] * v) >> 8) + r[3], 0), 255); }
+
+__global__ __launch_bounds__ (256) void k_yuv_to_yuv (const YuvRematParams p0)
+{
+  YuvRematParams p = p0;
+  p.iy += (size_t) blockIdx.z * p.in_pitch; p.iu += (size_t) blockIdx.z * p.in_pitch; p.iv += (size_t) blockIdx.z * p.in_pitch;
+  p.oy += (size_t) blockIdx.z * p.out_pitch; p.ou += (size_t) blockIdx.z * p.out_pitch; p.ov += (size_t) blockIdx.z * p.out_pitch;
+  const int k = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+  const int w = p.w, h = p.h, cw = (w + 1) >> 1;
+  const int ich = p.in420 ? (h + 1) >> 1 : h, och = p.out420 ? (h + 1) >> 1 : h;
+  if (k >= cw || j >= och) return;
+  const int rows = p.out420 ? 2 : 1, y0 = p.out420 ? 2 * j : j;
+  if (p.same) {
+    const int U = p.iu[(size_t) j * p.ics + k * p.icstep], V = p.iv[(size_t) j * p.ics + k * p.icstep];
+    for (int d = 0; d < rows; d++)
+      for (int e = 0; e < 2; e++) {
+        const int x = 2 * k + e, y = y0 + d;
+        if (x < w && y < h) { const int Y = p.iy[(size_t) y * p.iys + x * p.iystep]; p.oy[(size_t) y * p.oys + x * p.oystep] = (uint8_t) (p.remat ? remat_row (p.t, Y, U, V) : Y); }
+      }
+    p.ou[(size_t) j * p.ocs + k * p.ocstep] = (uint8_t) (p.remat ? remat_row (p.t + 4, 0, U, V) : U);
+    p.ov[(size_t) j * p.ocs + k * p.ocstep] = (uint8_t) (p.remat ? remat_row (p.t + 8, 0, U, V) : V);
+    return;
+  }
+  // horizontally up-sampled input chroma of chroma row jj at full-resolution column x (GStreamer's rule for the input siting)
+  auto hup = [&] (const uint8_t *c, int jj, int x) {
+    const int kk = x >> 1;
+    const uint8_t *row = c + (size_t) jj * p.ics;
+    const int c0 = row[kk * p.icstep], cm = row[max (kk - 1, 0) * p.icstep], cp = row[min (kk + 1, cw - 1) * p.icstep];
+    if (p.cos_in) return (x & 1) ? (c0 + cp + 1) >> 1 : c0;
+    return (x & 1) ? (3 * c0 + cp + 2) >> 2 : (3 * c0 + cm + 2) >> 2;
+  };
+  // 4:4:4 chroma at (x, y); y may be the phantom line h of an odd 4:2:0 frame
+  auto up = [&] (const uint8_t *c, int x, int y) {
+    if (!p.in420) return hup (c, min (y, h - 1), x);
+    const int jj = y >> 1, jn = (y & 1) ? min (jj + 1, ich - 1) : max (jj - 1, 0);
+    return (3 * hup (c, jj, x) + hup (c, jn, x) + 2) >> 2;
+  };
+  // columns the output chroma sample taps: co-sited (l, 2k, r) with weights 1 2 1, else (2k, 2k + 1) averaged
+  const int xc = 2 * k, xl = max (xc - 1, 0), xr = p.cos_out ? ((k == cw - 1 && k > 0) ? xc : min (xc + 1, w - 1)) : min (xc + 1, w - 1);
+  int fu[3], fv[3];                                     // vertically reduced matrixed chroma at columns l, c, r
+  for (int q = 0; q < 3; q++) {
+    if (q == 0 && !p.cos_out) { fu[0] = fv[0] = 0; continue; }
+    const int x = q == 0 ? xl : (q == 1 ? xc : xr);
+    int su = 0, sv = 0;
+    for (int d = 0; d < rows; d++) {
+      const int U = up (p.iu, x, y0 + d), V = up (p.iv, x, y0 + d);
+      su += p.remat ? remat_row (p.t + 4, 0, U, V) : U; sv += p.remat ? remat_row (p.t + 8, 0, U, V) : V;
+    }
+    fu[q] = p.out420 ? (su + 1) >> 1 : su; fv[q] = p.out420 ? (sv + 1) >> 1 : sv;
+  }
+  const int U = p.cos_out ? (fu[0] + 2 * fu[1] + fu[2] + 2) >> 2 : (fu[1] + fu[2] + 1) >> 1;
+  const int V = p.cos_out ? (fv[0] + 2 * fv[1] + fv[2] + 2) >> 2 : (fv[1] + fv[2] + 1) >> 1;
+  p.ou[(size_t) j * p.ocs + k * p.ocstep] = (uint8_t) U;
+  p.ov[(size_t) j * p.ocs + k * p.ocstep] = (uint8_t) V;
+  for (int d = 0; d < rows; d++)
+    for (int e = 0; e < 2; e++) {
+      const int x = 2 * k + e, y = y0 + d;
+      if (x >= w || y >= h) continue;
+      const int Y = p.iy[(size_t) y * p.iys + x * p.iystep];
+      p.oy[(size_t) y * p.oys + x * p.oystep] = (uint8_t) (p.remat ? remat_row (p.t, Y, up (p.iu, x, y), up (p.iv, x, y)) : Y);
+    }
+}
+
 // one plane of n interleaved u8 components
 struct PlaneScaleParams {
   const uint8_t *in; int is;

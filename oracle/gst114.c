@@ -449,6 +449,91 @@ int gst114_rgb_to_yuv420 (const uint8_t *in, int is, int in_format, int w, int h
   return 0;
 }
 
+static void down_h_row (const int *c, int w, int cosited, int *out);
+
+/* ---- videoconvert YUV -> YUV when the colour matrix and / or the chroma siting change (NV12 / I420 / UYVY / YUY2) ------------
+ * Pinned by probing the real element (flat-colour cubes for the matrix, random frames of every parity for the resampling;
+ * tests/golden/convertscale_gst114_remat.npz):
+ *   matrix: GstVideoConverter's 8-bit path, out = clamp8 (((a Y + b U + c V) >> 8) + d) per sample with the integer rows
+ *     below (coefficient = rint (256 m) of the combined limited-range matrix, d = floor of its offset);
+ *   same siting on both sides: no chroma resampling at all — each luma sample is matrixed with its nearest-replicated
+ *     chroma sample, each output chroma sample is the matrixed input chroma sample (the luma coefficient of the chroma rows is 0);
+ *   siting change: chroma is up-sampled to 4:4:4 with the INPUT siting (horizontal, then vertical 3:1 — over an EVEN number
+ *     of lines: an odd frame's phantom last line is filtered too), matrixed per sample (or left alone when only the siting
+ *     changes: NV12 <-> I420), and down-sampled with the OUTPUT siting (vertical pair average, then horizontal). */
+static const int YUV2YUV[3][3][12] = {           /* [matrix in][matrix out][row (Y, U, V) x (a, b, c, d)] */
+  { { 0 }, { 256, -30, -53, 41,   0, 261, 29, -18,   0, 19, 262, -13 }, { 256, -32, -29, 30,   0, 259, 16, -10,   0, 22, 264, -15 } },   /* bt601 -> */
+  { { 256, 25, 49, -38,   0, 253, -28, 15,   0, -19, 252, 11 }, { 0 }, { 256, -4, 24, -10,   0, 255, -13, 7,   0, 3, 257, -2 } },        /* bt709 -> */
+  { { 256, 30, 26, -28,   0, 255, -15, 8,   0, -22, 250, 13 }, { 256, 5, -24, 9,   0, 257, 13, -8,   0, -3, 255, 1 }, { 0 } },           /* bt2020 -> */
+};
+static inline int mat8 (const int *r, int y, int u, int v) { return clampi (((r[0] * y + r[1] * u + r[2] * v) >> 8) + r[3], 0, 255); }
+
+/* Any of NV12 / I420 / UYVY / YUY2 on either side, one size.  Sample addressing: luma sample x of row y at yp[y * ys + x * ystep],
+ * chroma sample k of chroma row j at up / vp[j * cs + k * cstep] (NV12: cstep 2; I420: 1; packed: ystep 2, cstep 4, cs == ys, chroma row
+ * == luma row); `in420` / `out420` say whether chroma is vertically subsampled.
+ * The same rules hold for the packed formats (probed: 45 random packed <-> packed / 4:2:0 frames with a matrix change, 0 differing
+ * bytes): "same siting, no resampling" needs the same subsampling on both sides as well; everything else takes the up-sample ->
+ * matrix -> down-sample path, 4:2:2 chroma having no vertical step. */
+int gst114_yuv_to_yuv (const uint8_t *yp, int ys, int ystep, const uint8_t *up, const uint8_t *vp, int cs, int cstep, int in420, int w, int h,
+    int matrix_in, int cosited_in, int matrix_out, int cosited_out,
+    uint8_t *oy, int oys, int oystep, uint8_t *ou, uint8_t *ov, int ocs, int ocstep, int out420)
+{
+  if (w <= 0 || h <= 0 || matrix_in < 0 || matrix_in > 2 || matrix_out < 0 || matrix_out > 2) return -1;
+  const int cw = (w + 1) / 2, ch = in420 ? (h + 1) / 2 : h, och = out420 ? (h + 1) / 2 : h;
+  const int hp = in420 ? 2 * ch : (out420 ? 2 * och : h);       /* full-resolution chroma lines, an even number when either side is 4:2:0 */
+  const int remat = matrix_in != matrix_out;
+  const int *t = YUV2YUV[matrix_in][matrix_out];
+  if (cosited_in == cosited_out && !in420 == !out420) {
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++) {
+        const int j = in420 ? y >> 1 : y;
+        const int Y = yp[(size_t) y * ys + x * ystep], U = up[(size_t) j * cs + (x >> 1) * cstep], V = vp[(size_t) j * cs + (x >> 1) * cstep];
+        oy[(size_t) y * oys + x * oystep] = (uint8_t) (remat ? mat8 (t, Y, U, V) : Y);
+      }
+    for (int j = 0; j < ch; j++)
+      for (int k = 0; k < cw; k++) {
+        const int U = up[(size_t) j * cs + k * cstep], V = vp[(size_t) j * cs + k * cstep];
+        ou[(size_t) j * ocs + k * ocstep] = (uint8_t) (remat ? mat8 (t + 4, 0, U, V) : U);
+        ov[(size_t) j * ocs + k * ocstep] = (uint8_t) (remat ? mat8 (t + 8, 0, U, V) : V);
+      }
+    return 0;
+  }
+  uint8_t *hu = malloc ((size_t) ch * w), *hv = malloc ((size_t) ch * w);
+  int *fu = malloc ((size_t) hp * w * sizeof (int)), *fv = malloc ((size_t) hp * w * sizeof (int));
+  int *du = malloc ((size_t) cw * sizeof (int)), *dv = malloc ((size_t) cw * sizeof (int)), *vu = malloc ((size_t) w * sizeof (int)), *vv = malloc ((size_t) w * sizeof (int));
+  if (!hu || !hv || !fu || !fv || !du || !dv || !vu || !vv) { free (hu); free (hv); free (fu); free (fv); free (du); free (dv); free (vu); free (vv); return -2; }
+  for (int j = 0; j < ch; j++) {
+    upsample_h (up + (size_t) j * cs, cstep, cw, w, cosited_in, hu + (size_t) j * w);
+    upsample_h (vp + (size_t) j * cs, cstep, cw, w, cosited_in, hv + (size_t) j * w);
+  }
+  for (int y = 0; y < hp; y++) {                       /* 4:4:4 chroma of every line, the phantom line of an odd height included */
+    const int yl = y < h ? y : h - 1;
+    for (int x = 0; x < w; x++) {
+      int U, V;
+      if (in420) {
+        const int j = y >> 1, jn = (y & 1) ? clampi (j + 1, 0, ch - 1) : clampi (j - 1, 0, ch - 1);
+        U = (3 * hu[(size_t) j * w + x] + hu[(size_t) jn * w + x] + 2) >> 2; V = (3 * hv[(size_t) j * w + x] + hv[(size_t) jn * w + x] + 2) >> 2;
+      } else { U = hu[(size_t) yl * w + x]; V = hv[(size_t) yl * w + x]; }
+      const int Y = yp[(size_t) yl * ys + x * ystep];
+      if (y < h) oy[(size_t) y * oys + x * oystep] = (uint8_t) (remat ? mat8 (t, Y, U, V) : Y);
+      fu[(size_t) y * w + x] = remat ? mat8 (t + 4, 0, U, V) : U;
+      fv[(size_t) y * w + x] = remat ? mat8 (t + 8, 0, U, V) : V;
+    }
+  }
+  for (int j = 0; j < och; j++) {
+    for (int x = 0; x < w; x++) {
+      if (out420) {
+        vu[x] = (fu[(size_t) (2 * j) * w + x] + fu[(size_t) (2 * j + 1) * w + x] + 1) >> 1;
+        vv[x] = (fv[(size_t) (2 * j) * w + x] + fv[(size_t) (2 * j + 1) * w + x] + 1) >> 1;
+      } else { vu[x] = fu[(size_t) j * w + x]; vv[x] = fv[(size_t) j * w + x]; }
+    }
+    down_h_row (vu, w, cosited_out, du); down_h_row (vv, w, cosited_out, dv);
+    for (int k = 0; k < cw; k++) { ou[(size_t) j * ocs + k * ocstep] = (uint8_t) du[k]; ov[(size_t) j * ocs + k * ocstep] = (uint8_t) dv[k]; }
+  }
+  free (hu); free (hv); free (fu); free (fv); free (du); free (dv); free (vu); free (vv);
+  return 0;
+}
+
 /* ---- videoscale on planar 8-bit data (NV12 / I420 -> same format), pinned by probing the real element:
  *   vertical: the same 8-bit centre-aligned 2-tap as for 4 x u8;
  *   horizontal, 1 x u8 planes (Y, I420 chroma): the edge-aligned 16.16 path of the 4 x u8 case, EXCEPT when the plane is

@@ -39,6 +39,10 @@ int gst114_linear_ntaps (int in, int out, int *idx, int *taps, int max_entries);
 int gst114_scale_packed422_cubic (const uint8_t *in, int is, int yuy2, int w, int h, uint8_t *out, int os, int ow, int oh);
 int gst114_scale_plane_nearest (const uint8_t *in, int is, int w, int h, int n, uint8_t *out, int os, int ow, int oh);
 int gst114_scale_packed422_nearest (const uint8_t *in, int is, int yuy2, int w, int h, uint8_t *out, int os, int ow, int oh);
+/* videoconvert YUV -> YUV at one size when the matrix and / or the chroma siting change (sample addressing: gst114.c) */
+int gst114_yuv_to_yuv (const uint8_t *yp, int ys, int ystep, const uint8_t *up, const uint8_t *vp, int cs, int cstep, int in420, int w, int h,
+    int matrix_in, int cosited_in, int matrix_out, int cosited_out,
+    uint8_t *oy, int oys, int oystep, uint8_t *ou, uint8_t *ov, int ocs, int ocstep, int out420);
 int gst114_default_matrix (int height);
 int gst114_default_cosited (int height);
 int gst114_convertscale_yuv420 (const uint8_t *yp, int ys, const uint8_t *up, int us, const uint8_t *vp, int vs,

@@ -58,9 +58,30 @@ class Oracle:
     def _p(a, off=0):
         return C.c_void_p(a.ctypes.data + off)
 
-    def convertscale(self, fmt, w, h, raw, colorimetry, chroma_site, method, out_format, ow, oh, out_chroma_site=None):
+    def _yuv_spec(self, fmt, w, h, arr):
+        """sample addressing of a YUV frame in GstVideoInfo default layout for gst114_yuv_to_yuv: (y, ys, ystep, u, v, cs, cstep, is420)"""
+        lay, _ = raw_layout(fmt, w, h)
+        if fmt == "NV12":
+            return self._p(arr, lay[0][0]), lay[0][1], 1, self._p(arr, lay[1][0]), self._p(arr, lay[1][0] + 1), lay[1][1], 2, 1
+        if fmt == "I420":
+            return self._p(arr, lay[0][0]), lay[0][1], 1, self._p(arr, lay[1][0]), self._p(arr, lay[2][0]), lay[1][1], 1, 1
+        yo, uo, vo = (0, 1, 3) if fmt == "YUY2" else (1, 0, 2)
+        return self._p(arr, yo), lay[0][1], 2, self._p(arr, uo), self._p(arr, vo), lay[0][1], 4, 0
+
+    def yuv_to_yuv(self, fmt, w, h, raw, mat, cos, out_format, mat_out, cos_out):
+        """videoconvert YUV -> YUV at one size with a matrix and / or siting change (gst114_yuv_to_yuv): the raw output frame"""
+        raw = np.ascontiguousarray(raw, np.uint8)
+        out = np.zeros(raw_layout(out_format, w, h)[1], np.uint8)
+        i, o = self._yuv_spec(fmt, w, h, raw), self._yuv_spec(out_format, w, h, out)
+        rc = self.lib.gst114_yuv_to_yuv(i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], w, h, mat, cos, mat_out, cos_out,
+                                        o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7])
+        if rc != 0:
+            raise RuntimeError(f"oracle rc={rc}")
+        return out
+
+    def convertscale(self, fmt, w, h, raw, colorimetry, chroma_site, method, out_format, ow, oh, out_chroma_site=None, out_colorimetry=None):
         """GStreamer 1.14 `videoconvert ! videoscale` on one frame in GstVideoInfo default layout, any of
-        {NV12, I420, BGRA, RGBA} -> any of them.  RGB outputs return (oh, ow, 4); YUV outputs the raw output frame."""
+        {NV12, I420, BGRA, RGBA, UYVY, YUY2} -> any of them.  RGB outputs return (oh, ow, 4); YUV outputs the raw output frame."""
         if colorimetry is None:
             colorimetry, chroma_site = default_colorimetry(h)
         raw = np.ascontiguousarray(np.frombuffer(raw, np.uint8) if isinstance(raw, (bytes, bytearray)) else raw, dtype=np.uint8)
@@ -95,6 +116,15 @@ class Oracle:
             return out
         near = method == "nearest"
         sfx = {"bilinear": "", "nearest": "_nearest", "bicubic": "_cubic"}[method]
+        # YUV -> YUV with a matrix change (any formats), or NV12 <-> I420 with a siting change: videoconvert's generic path at the
+        # input size (gst114_yuv_to_yuv), then the usual videoscale stage on the converted frame
+        mat_out = mat if out_colorimetry is None else MATRIX[out_colorimetry]
+        any_yuv_in = fmt in ("NV12", "I420", "UYVY", "YUY2")
+        if any_yuv_in and (mat_out != mat or (yuv_in and yuv_out and fmt != out_format and cos != cos_out)):
+            mid = self.yuv_to_yuv(fmt, w, h, raw, mat, cos, out_format, mat_out, cos_out)
+            if (ow, oh) == (w, h):
+                return mid
+            return self.convertscale(out_format, w, h, mid, {v: k for k, v in MATRIX.items()}[mat_out], "mpeg2" if cos_out else "jpeg", method, out_format, ow, oh)
         if out_format in ("UYVY", "YUY2"):
             # videoconvert at the input size -> packed frame of the output format, then videoscale on the packed frame
             ms, yuy2 = r4(2 * w), int(out_format == "YUY2")

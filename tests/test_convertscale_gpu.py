@@ -703,8 +703,49 @@ def test_golden_gstreamer_vectors_mixed_sitings(vfhip, oracle, case):
     assert np.array_equal(a, b)
 
 
-def test_nv12_i420_with_a_siting_change_is_not_gst_exact(vfhip):
+from test_oracle_golden import MANIFEST_RM, ZRM  # noqa: E402
+
+
+@pytest.mark.parametrize("case", MANIFEST_RM, ids=[c["name"] for c in MANIFEST_RM])
+def test_golden_gstreamer_vectors_matrix_and_siting_changes(vfhip, oracle, case):
+    """YUV -> YUV with a colour-matrix change (NV12 / I420 / UYVY / YUY2 either side) and NV12 <-> I420 with a siting change:
+    videoconvert's generic path (k_yuv_to_yuv) + the usual scale stage, byte for byte against the real GStreamer 1.14 pipeline"""
+    c = case
     cs = vfhip.ConvertScale(0)
-    cs.configure("NV12", 64, 36, "I420", 64, 36, chroma_site="jpeg", out_chroma_site="mpeg2")
-    assert cs.kernel_name == "k_cs_metal"
+    cs.configure(c["in_format"], c["w"], c["h"], c["out_format"], c["ow"], c["oh"], colorimetry=c["colorimetry"], chroma_site=c["chroma_site"],
+                 out_chroma_site=c["out_chroma_site"], out_colorimetry=c["out_colorimetry"], numerics="gst-exact-strict")
+    assert cs.kernel_name.startswith("k_cs_staged") and cs.numerics_in_effect == "gst-exact"
+    got = cs.process(ZRM[c["name"] + "_in"])
+    cs.close()
+    fr = gst_undefined_packed(oracle, c, [got, ZRM[c["name"] + "_out"]])
+    if fr is None:
+        pytest.skip("GStreamer 1.14 emits out-of-line garbage for this packed frame")
+    a, b = (meaningful(c["out_format"], c["ow"], c["oh"], f) for f in fr)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("ifmt,ofmt,w,h,ow,oh,method", [("NV12", "NV12", 1920, 1080, 1280, 720, "bilinear"), ("I420", "NV12", 1280, 720, 1280, 720, "bilinear"),
+                                                        ("UYVY", "I420", 642, 361, 320, 181, "nearest"), ("NV12", "YUY2", 640, 360, 960, 540, "bicubic")])
+def test_matrix_change_hd_vs_oracle_and_batch(vfhip, oracle, ifmt, ofmt, w, h, ow, oh, method):
+    """bigger frames, the other scale methods and the batched device entry point (2 frames) of the matrix-change cells vs the oracle"""
+    import torch
+    rng = np.random.default_rng(w + h)
+    isz, osz = oracle_lib.raw_layout(ifmt, w, h)[1], oracle_lib.raw_layout(ofmt, ow, oh)[1]
+    frames = [rng.integers(0, 256, isz, dtype=np.uint8) for _ in range(2)]
+    cs = vfhip.ConvertScale(0)
+    cs.configure(ifmt, w, h, ofmt, ow, oh, method=method, colorimetry="bt709", chroma_site="mpeg2", out_colorimetry="bt601", out_chroma_site="jpeg", numerics="gst-exact-strict")
+    ip, op = (isz + 255) // 256 * 256, (osz + 255) // 256 * 256
+    din = torch.zeros((2, ip), dtype=torch.uint8, device="cuda")
+    for k in range(2):
+        din[k, :isz] = torch.from_numpy(frames[k]).cuda()
+    dout = torch.zeros((2, op), dtype=torch.uint8, device="cuda")
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    cs.process_device(din.data_ptr(), dout.data_ptr(), stream=s.cuda_stream, n_frames=2, in_pitch=ip, out_pitch=op)
+    s.synchronize()
+    out = dout.cpu().numpy()
+    for k in range(2):
+        want = oracle.convertscale(ifmt, w, h, frames[k], "bt709", "mpeg2", method, ofmt, ow, oh, out_chroma_site="jpeg", out_colorimetry="bt601")
+        assert np.array_equal(meaningful(ofmt, ow, oh, out[k, :osz]), meaningful(ofmt, ow, oh, want)), f"frame {k}"
+        assert np.array_equal(meaningful(ofmt, ow, oh, cs.process(frames[k])), meaningful(ofmt, ow, oh, want))
     cs.close()

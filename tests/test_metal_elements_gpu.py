@@ -74,12 +74,11 @@ def test_convertscale_gst_exact_falls_back_to_metal_for_unpinned_cells(vfhip, me
         assert cs.numerics_in_effect == "gst-exact" and cs.kernel_name == "k_cs_nv12_half"
     cs.configure("NV12", 64, 32, "BGRA", 32, 16, numerics="metal")
     assert cs.numerics_in_effect == "metal"
-    # the other unpinned families: YUV -> YUV with a matrix change, NV12 <-> I420 with a siting change
+    # YUV -> YUV with a matrix change and NV12 <-> I420 with a siting change ARE pinned (round 2: k_yuv_to_yuv): exact under both spellings
     for kw in (dict(colorimetry="bt709", out_colorimetry="bt601"), dict(chroma_site="mpeg2", out_chroma_site="jpeg")):
-        cs.configure("NV12", 64, 32, "I420", 64, 32, numerics="gst-exact", **kw)
-        assert cs.numerics_in_effect == "metal", kw
-        with pytest.raises(vfhip.VfHipError):
-            cs.configure("NV12", 64, 32, "I420", 64, 32, numerics="gst-exact-strict", **kw)
+        for num in ("gst-exact", "gst-exact-strict"):
+            cs.configure("NV12", 64, 32, "I420", 64, 32, numerics=num, **kw)
+            assert cs.numerics_in_effect == "gst-exact" and cs.kernel_name == "k_cs_staged_420", kw
     cs.close()
 
 

@@ -398,6 +398,44 @@ def gen_mixed_sites():
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "mixedsite":
     gen_mixed_sites()
     sys.exit(0)
+def gen_remat():
+    """YUV -> YUV with a MATRIX change (all four YUV formats either side) and NV12 <-> I420 with a SITING change, same size and
+    scaled, through the real `videoconvert ! videoscale` -> tests/golden/convertscale_gst114_remat.npz"""
+    cases, arrays = [], {}
+    rng = np.random.default_rng(20261012)
+    cols, sites, fm = ["bt601", "bt709", "bt2020"], ["jpeg", "mpeg2"], ["NV12", "I420", "UYVY", "YUY2"]
+    sizes = [(64, 36, 64, 36), (33, 17, 33, 17), (34, 19, 34, 19), (64, 36, 40, 30), (66, 34, 33, 17), (35, 29, 80, 41), (48, 40, 48, 40), (31, 30, 31, 30),
+             (128, 72, 64, 36), (20, 13, 20, 13)]
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = build_helper(tmp)
+        t = 0
+        for ifmt in fm:
+            for ofmt in fm:
+                for rep in range(4):
+                    w, h, ow, oh = sizes[(t * 3 + rep) % len(sizes)]
+                    ci = cols[t % 3]
+                    co = cols[(t + 1 + rep % 2) % 3] if rep < 3 else ci            # the 4th case of a pair: siting change only
+                    si, so = sites[(t + rep) % 2], sites[(t + rep + (1 if rep in (1, 3) else 0)) % 2]
+                    t += 1
+                    in420, out420 = ifmt in ("NV12", "I420"), ofmt in ("NV12", "I420")
+                    if ci == co and not (in420 and out420 and ifmt != ofmt and si != so):
+                        continue                                                  # covered by the other fixture sets (or passthrough)
+                    size = {"NV12": nv12_layout(w, h)[3], "I420": i420_layout(w, h)[4]}.get(ifmt, r4(2 * w) * h)
+                    raw = rng.integers(0, 256, size, dtype=np.uint8).tobytes()
+                    out = gst_run(exe, tmp, raw, len(raw), f"video/x-raw,format={ifmt},width={w},height={h},framerate=1/1,colorimetry={ci},chroma-site={si}",
+                                  "videoconvert ! videoscale", f"video/x-raw,format={ofmt},width={ow},height={oh},colorimetry={co},chroma-site={so}")
+                    name = f"rm_{ifmt.lower()}_to_{ofmt.lower()}_{len(cases):02d}_{w}x{h}_to_{ow}x{oh}_{ci}_{si}_{co}_{so}"
+                    arrays[name + "_in"], arrays[name + "_out"] = np.frombuffer(raw, np.uint8), np.frombuffer(out, np.uint8)
+                    cases.append(dict(name=name, in_format=ifmt, w=w, h=h, colorimetry=ci, chroma_site=si, out_colorimetry=co, out_chroma_site=so, method="bilinear",
+                                      out_format=ofmt, ow=ow, oh=oh, in_sha256=hashlib.sha256(raw).hexdigest(), out_sha256=hashlib.sha256(out).hexdigest()))
+    arrays["manifest"] = np.frombuffer(json.dumps(cases).encode(), np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "convertscale_gst114_remat.npz"), **arrays)
+    print("wrote", len(cases), "matrix / siting change cases")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "remat":
+    gen_remat()
+    sys.exit(0)
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ties":
     gen_ties()
     sys.exit(0)
