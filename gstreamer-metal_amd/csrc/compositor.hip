@@ -108,11 +108,23 @@ __global__ __launch_bounds__ (256) void k_compositor (const CompParams p)
   for (int i = 0; i < 4; i++) { q[0][i] = comp_background (p, xs[i], y0); q[1][i] = comp_background (p, xs[i], y1); }
   const int wx0 = (int) blockIdx.x * 256, wx1 = wx0 + 256;
   const unsigned z = blockIdx.z;
-  for (int k = 0; k < p.n; k++) {
+  // which layers touch this wave's 256 x 2 strip?  All sixteen rectangles are tested up front: independent scalar loads that
+  // pipeline into one memory latency (testing inside the layer loop chained one dependent scalar-load latency per layer, five
+  // per wave on BASELINE configs[3], most of them for layers the wave never draws)
+  uint32_t hit = 0;
+#pragma unroll
+  for (int k = 0; k < COMP_MAX_LAYERS; k++) {
+    const CompLayer &L = p.layer[k];
+    const bool miss = k >= p.n || wx1 <= L.xpos || wx0 >= L.xpos + L.width || y1 < L.ypos || y0 >= L.ypos + L.height;
+    hit |= miss ? 0u : 1u << k;
+  }
+  hit = (uint32_t) __builtin_amdgcn_readfirstlane ((int) hit);                                 // wave-uniform by construction
+  while (hit) {
+    const int k = __builtin_ctz (hit);
+    hit &= hit - 1;
     const CompLayer &L = p.layer[k];
     // a pixel is covered when its centre lies inside the quad [xpos, xpos+width) x [ypos, ypos+height)
     const int lx1 = L.xpos + L.width, ly1 = L.ypos + L.height;
-    if (wx1 <= L.xpos || wx0 >= lx1 || y1 < L.ypos || y0 >= ly1) continue;                   // wave-uniform
     const metal::Img im = metal::img_at (L.img, z * L.pitch);
     bool cx[4];
 #pragma unroll

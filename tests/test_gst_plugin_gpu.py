@@ -498,7 +498,9 @@ def test_compositor_drops_frames_of_a_faster_pad_and_repeats_after_eos(tmp_path)
                        f"videotestsrc num-buffers=6 pattern=ball ! {caps('BGRA', 160, 120)},framerate=30/1 ! c.sink_0 "
                        f"videotestsrc num-buffers=12 pattern=ball ! {caps('BGRA', 160, 120)},framerate=60/1 ! c.sink_1", timeout=120)
     assert r.returncode == 0, r.stderr
-    assert np.fromfile(o, np.uint8).size == 6 * 320 * 120 * 4
+    # 0.2 s of input: 6 output frames, or 7 when the last 60 fps buffer (which ends exactly where output frame 6 starts: GstVideoAggregator
+    # takes `end >= out_start`) is still queued — never 12: the fast pad is decimated, not queued up
+    assert np.fromfile(o, np.uint8).size in (6 * 320 * 120 * 4, 7 * 320 * 120 * 4)
     r = gst_env.launch(f"vfhipcompositor name=c background=black sink_0::repeat-after-eos=true sink_1::xpos=160 ! {caps('BGRA', 320, 120)},framerate=30/1 ! filesink location={o} "
                        f"videotestsrc num-buffers=2 pattern=smpte ! {caps('BGRA', 160, 120)},framerate=30/1 ! c.sink_0 "
                        f"videotestsrc num-buffers=6 pattern=ball ! {caps('BGRA', 160, 120)},framerate=30/1 ! c.sink_1", timeout=120)
