@@ -73,16 +73,22 @@ __device__ __forceinline__ F4 comp_texel (uint32_t t, bool rgba)
   return o;
 }
 
-// colour s of one layer drawn over the 8-bit target value q
-__device__ __forceinline__ uint32_t comp_blend (const CompLayer &L, F4 s, uint32_t q)
+// colour s of one layer drawn over the target value d (the 8-bit target read back as floats)
+__device__ __forceinline__ uint32_t comp_blend_f (const CompLayer &L, F4 s, const F4 &d)
 {
   s.a *= L.alpha; s.r *= s.a; s.g *= s.a; s.b *= s.a;            // premultiply (compositorFragment, :58-59)
-  const F4 d = metal::unpack_rgba8 (q);
   F4 o;
   if (L.blend == VFHIP_BLEND_SOURCE) o = s;
   else if (L.blend == VFHIP_BLEND_ADD) { o.r = s.r + d.r; o.g = s.g + d.g; o.b = s.b + d.b; o.a = s.a + d.a; }
   else { const float k1 = 1.0f - s.a; o.r = fmaf (d.r, k1, s.r); o.g = fmaf (d.g, k1, s.g); o.b = fmaf (d.b, k1, s.b); o.a = fmaf (d.a, k1, s.a); }
   return metal::quant_rgba8 (o);
+}
+// ... over the 8-bit target value q.  `flat`: wave-uniform, the target still holds the uniform background colour `bgc` under every
+// lane (the first layer a wave draws over a black / white / transparent background): the target's read-back is then a scalar,
+// not eight conversions per pixel
+__device__ __forceinline__ uint32_t comp_blend (const CompLayer &L, const F4 &s, uint32_t q, bool flat, const F4 &bgc)
+{
+  return flat ? comp_blend_f (L, s, bgc) : comp_blend_f (L, s, metal::unpack_rgba8 (q));
 }
 
 typedef uint4 __attribute__ ((aligned (4))) uint4_a4;
@@ -119,7 +125,11 @@ __global__ __launch_bounds__ (256) void k_compositor (const CompParams p)
     hit |= miss ? 0u : 1u << k;
   }
   hit = (uint32_t) __builtin_amdgcn_readfirstlane ((int) hit);                                 // wave-uniform by construction
-  while (hit) {
+  // a uniform background reads back as one scalar colour until the first layer has been drawn
+  bool flat = p.background == VFHIP_BG_BLACK || p.background == VFHIP_BG_WHITE || p.background == VFHIP_BG_TRANSPARENT;
+  F4 bgc;
+  bgc.r = bgc.g = bgc.b = p.background == VFHIP_BG_WHITE ? 1.0f : 0.0f; bgc.a = p.background == VFHIP_BG_TRANSPARENT ? 0.0f : 1.0f;     // un8 (0) / un8 (255)
+  for (; hit; flat = false) {
     const int k = __builtin_ctz (hit);
     hit &= hit - 1;
     const CompLayer &L = p.layer[k];
@@ -140,10 +150,10 @@ __global__ __launch_bounds__ (256) void k_compositor (const CompParams p)
 #pragma unroll
       for (int r = 0; r < 2; r++) {
         if (!(r ? cy1 : cy0)) continue;
-        q[r][0] = comp_blend (L, comp_texel (t[r].x, rgba_in), q[r][0]);
-        q[r][1] = comp_blend (L, comp_texel (t[r].y, rgba_in), q[r][1]);
-        q[r][2] = comp_blend (L, comp_texel (t[r].z, rgba_in), q[r][2]);
-        q[r][3] = comp_blend (L, comp_texel (t[r].w, rgba_in), q[r][3]);
+        q[r][0] = comp_blend (L, comp_texel (t[r].x, rgba_in), q[r][0], flat, bgc);
+        q[r][1] = comp_blend (L, comp_texel (t[r].y, rgba_in), q[r][1], flat, bgc);
+        q[r][2] = comp_blend (L, comp_texel (t[r].z, rgba_in), q[r][2], flat, bgc);
+        q[r][3] = comp_blend (L, comp_texel (t[r].w, rgba_in), q[r][3], flat, bgc);
       }
     } else if (cx[0] && cx[3] && xs[3] == xs[0] + 3 && cy0 && cy1 && y1 == y0 + 1 && (im.fmt == VFHIP_FORMAT_NV12 || im.fmt == VFHIP_FORMAT_I420) &&
                L.width == L.img.w && L.height == L.img.h && !(((xs[0] - L.xpos) | (y0 - L.ypos)) & 1)) {
@@ -186,7 +196,7 @@ __global__ __launch_bounds__ (256) void k_compositor (const CompParams p)
           const float fy = r ? 0.25f : 0.75f;
           const float cb = metal::lerp2 (hu[r], hu[r + 1], fy), cr = metal::lerp2 (hv[r], hv[r + 1], fy);
           const F4 c = metal::yuv_to_rgb (metal::un8 ((Y[r] >> (8 * i)) & 0xffu), cb, cr, im.m709);
-          q[r][i] = comp_blend (L, c, q[r][i]);
+          q[r][i] = comp_blend (L, c, q[r][i], flat, bgc);
         }
       }
     } else {
@@ -201,7 +211,7 @@ __global__ __launch_bounds__ (256) void k_compositor (const CompParams p)
         uint32_t cur = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) cur = i == j ? q[j >> 2][j & 3] : cur;
-        const uint32_t v = comp_blend (L, comp_sample (L, im, xi, r ? y1 : y0), cur);
+        const uint32_t v = comp_blend (L, comp_sample (L, im, xi, r ? y1 : y0), cur, flat, bgc);
 #pragma unroll
         for (int j = 0; j < 8; j++) q[j >> 2][j & 3] = i == j ? v : q[j >> 2][j & 3];
       }

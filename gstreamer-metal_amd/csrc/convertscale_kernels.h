@@ -161,7 +161,7 @@ __device__ __forceinline__ void store_stream16 (uint8_t *dst, const uint32_t v[4
 // average of rows y-1 and y) and the prefetched raw rows of THIS row.  Out: the state for row y+1 and the prefetch of
 // row y+1 (issued before this row's arithmetic: register double buffer).  Called twice per loop trip with the two
 // register sets swapped, so the rotation costs no moves.
-template <bool COSITED, bool RGBA>
+template <bool COSITED, bool RGBA, bool F0>
 __device__ __forceinline__ void half_row (const HalfCtx &k, int y, const CRow &hc, const CRow &mid_up, const CRaw &craw, uint2 yt, uint2 yb,
     CRow &hn, CRow &mid_dn, CRaw &nraw, uint2 &nyt, uint2 &nyb)
 {
@@ -194,12 +194,55 @@ __device__ __forceinline__ void half_row (const HalfCtx &k, int y, const CRow &h
     orc_pair (perm_b32 (0u, ybn, sy), perm_b32 (0u, ben, su), perm_b32 (0u, bon, su), k.c, bias, bbm, gbm, rbm);
     // vertical 2-tap, w = 128: s1 + (((s2-s1)*128+128)>>8) == (s1+s2+1)>>1 on the [even, odd] byte pairs
     const uint32_t vb = avg_rnd_u8 (bt, bbm), vg = avg_rnd_u8 (gt, gbm), vr = avg_rnd_u8 (rt, rbm);
-    // horizontal 2-tap: (e*(256-f) + o*f) >> 8 = (e*(255-f) + o*f + e) >> 8
-    const uint32_t hb = dot4_u8 (vb, k.wgt[n], vb & 0xffu), hg = dot4_u8 (vg, k.wgt[n], vg & 0xffu), hr = dot4_u8 (vr, k.wgt[n], vr & 0xffu);
+    // horizontal 2-tap (e*(256-f) + o*f) >> 8.  256 - f does not fit a byte when f == 0, so in general the weights are
+    // (255 - f, f) and e is added through the accumulator; a wave none of whose lanes has an f == 0 (F0 false: 6 of 7.5 waves
+    // of a 2160p -> 1080p row) multiplies by (256 - f, f) and saves the three masks per pixel
+    const uint32_t hb = dot4_u8 (vb, k.wgt[n], F0 ? vb & 0xffu : 0u), hg = dot4_u8 (vg, k.wgt[n], F0 ? vg & 0xffu : 0u), hr = dot4_u8 (vr, k.wgt[n], F0 ? vr & 0xffu : 0u);
     const uint32_t lo = RGBA ? perm_b32 (hg, hr, 0x0c0c0501u) : perm_b32 (hg, hb, 0x0c0c0501u);      // [X>>8, G>>8, -, -]
     out[n] = perm_b32 (RGBA ? hb : hr, lo, 0x0d050100u);                                               // [X, G, Z, 0xff]
   }
   store_stream16 (k.op + (__umul24 ((uint32_t) y, k.os) + 2u * k.cx), out);
+}
+
+// one lane's strip: set-up, prologue loads and the row loop.  F0: some lane of the wave has a horizontal tap with f == 0
+// (see half_row); the two instantiations are separate paths of the kernel so that each gets its own register allocation.
+template <bool COSITED, bool RGBA, bool F0>
+__device__ __forceinline__ void half_strip (const CsParams &p, int frame, int cg, int cgpr, int y0, int rows)
+{
+  HalfCtx k;
+  k.yp = p.in[0] + (size_t) frame * p.in_pitch;               // wave-uniform plane bases; per-lane parts are 32-bit offsets
+  k.uvp = p.in[1] + (size_t) frame * p.in_pitch;         // (global_load with SGPR base + VGPR offset)
+  k.op = p.out + (size_t) frame * p.out_pitch;
+  k.ys = (uint32_t) p.is[0]; k.cs = (uint32_t) p.is[1]; k.os = (uint32_t) p.os;
+  k.cx = 8u * (uint32_t) cg;
+  k.roff = cg == cgpr - 1 ? 6u : 8u; k.loff = cg == 0 ? 0u : 2u;
+  k.ch = p.out_h;                                              // chroma rows == output rows at 2:1
+  k.yend = min (y0 + rows, p.out_h);
+#pragma unroll
+  for (int i = 0; i < 5; i++) k.c[i] = p.c[i];
+  // horizontal tap weights of this lane's 4 output pixels (row independent): bytes [255-f, f, 0, 0] (+ e through the accumulator),
+  // or [256-f, f, 0, 0] when no lane of the wave has an f == 0
+#pragma unroll
+  for (int n = 0; n < 4; n++) {
+    const uint32_t tt = (uint32_t) (cg * 4 + n) * p.hinc;
+    const uint32_t f = (tt >> 8) & 0xffu;
+    k.wgt[n] = ((F0 ? 255u : 256u) - f) | (f << 8);
+  }
+  CRow hcA, midA, hcB, midB;
+  {
+    const CRow hm = hfilter<COSITED> (load_craw<COSITED> (k.uvp, __umul24 ((uint32_t) max (y0 - 1, 0), k.cs) + k.cx, k.roff, k.loff));
+    hcA = hfilter<COSITED> (load_craw<COSITED> (k.uvp, __umul24 ((uint32_t) y0, k.cs) + k.cx, k.roff, k.loff));
+    // floor-average of chroma rows (j-1, j): the inner half of (3a+b+2)>>2; the (j, j+1) one is reused by the next row
+    midA = { lerp_u8 (hcA.e01, hm.e01, 0u), lerp_u8 (hcA.e23, hm.e23, 0u), lerp_u8 (hcA.o01, hm.o01, 0u), lerp_u8 (hcA.o23, hm.o23, 0u) };
+  }
+  CRaw rawA = load_craw<COSITED> (k.uvp, __umul24 ((uint32_t) min (y0 + 1, k.ch - 1), k.cs) + k.cx, k.roff, k.loff), rawB;
+  uint2 ytA = *reinterpret_cast<const uint2 *> (k.yp + (__umul24 ((uint32_t) (2 * y0), k.ys) + k.cx)), ytB;
+  uint2 ybA = *reinterpret_cast<const uint2 *> (k.yp + (__umul24 ((uint32_t) (2 * y0 + 1), k.ys) + k.cx)), ybB;
+  for (int y = y0; y < k.yend; y += 2) {
+    half_row<COSITED, RGBA, F0> (k, y, hcA, midA, rawA, ytA, ybA, hcB, midB, rawB, ytB, ybB);
+    if (y + 1 >= k.yend) break;                                // odd tail (only when out_h is odd)
+    half_row<COSITED, RGBA, F0> (k, y + 1, hcB, midB, rawB, ytB, ybB, hcA, midA, rawA, ytA, ybA);
+  }
 }
 
 // grid: 1-D, ceil(cgpr * strips / 256) blocks of 256 lanes per frame, frames back to back (cgpr = out_w / 4 column
@@ -216,41 +259,11 @@ __global__ __launch_bounds__ (256, 8) void k_cs_nv12_half (const CsParams p)
   const int t = (b % bpf) * 256 + threadIdx.x;
   if (t >= cgpr * strips) return;
   const int strip = t / cgpr, cg = t - strip * cgpr;
-  const int y0 = strip * rows;
-  HalfCtx k;
-  k.yp = p.in[0] + (size_t) frame * p.in_pitch;               // wave-uniform plane bases; per-lane parts are 32-bit offsets
-  k.uvp = p.in[1] + (size_t) frame * p.in_pitch;         // (global_load with SGPR base + VGPR offset)
-  k.op = p.out + (size_t) frame * p.out_pitch;
-  k.ys = (uint32_t) p.is[0]; k.cs = (uint32_t) p.is[1]; k.os = (uint32_t) p.os;
-  k.cx = 8u * (uint32_t) cg;
-  k.roff = cg == cgpr - 1 ? 6u : 8u; k.loff = cg == 0 ? 0u : 2u;
-  k.ch = p.out_h;                                              // chroma rows == output rows at 2:1
-  k.yend = min (y0 + rows, p.out_h);
+  bool lane_f0 = false;
 #pragma unroll
-  for (int i = 0; i < 5; i++) k.c[i] = p.c[i];
-  // horizontal tap weights of this lane's 4 output pixels (row independent): bytes [255-f, f, 0, 0]
-#pragma unroll
-  for (int n = 0; n < 4; n++) {
-    const uint32_t tt = (uint32_t) (cg * 4 + n) * p.hinc;
-    const uint32_t f = (tt >> 8) & 0xffu;
-    k.wgt[n] = (255u - f) | (f << 8);
-  }
-
-  CRow hcA, midA, hcB, midB;
-  {
-    const CRow hm = hfilter<COSITED> (load_craw<COSITED> (k.uvp, __umul24 ((uint32_t) max (y0 - 1, 0), k.cs) + k.cx, k.roff, k.loff));
-    hcA = hfilter<COSITED> (load_craw<COSITED> (k.uvp, __umul24 ((uint32_t) y0, k.cs) + k.cx, k.roff, k.loff));
-    // floor-average of chroma rows (j-1, j): the inner half of (3a+b+2)>>2; the (j, j+1) one is reused by the next row
-    midA = { lerp_u8 (hcA.e01, hm.e01, 0u), lerp_u8 (hcA.e23, hm.e23, 0u), lerp_u8 (hcA.o01, hm.o01, 0u), lerp_u8 (hcA.o23, hm.o23, 0u) };
-  }
-  CRaw rawA = load_craw<COSITED> (k.uvp, __umul24 ((uint32_t) min (y0 + 1, k.ch - 1), k.cs) + k.cx, k.roff, k.loff), rawB;
-  uint2 ytA = *reinterpret_cast<const uint2 *> (k.yp + (__umul24 ((uint32_t) (2 * y0), k.ys) + k.cx)), ytB;
-  uint2 ybA = *reinterpret_cast<const uint2 *> (k.yp + (__umul24 ((uint32_t) (2 * y0 + 1), k.ys) + k.cx)), ybB;
-  for (int y = y0; y < k.yend; y += 2) {
-    half_row<COSITED, RGBA> (k, y, hcA, midA, rawA, ytA, ybA, hcB, midB, rawB, ytB, ybB);
-    if (y + 1 >= k.yend) break;                                // odd tail (only when out_h is odd)
-    half_row<COSITED, RGBA> (k, y + 1, hcB, midB, rawB, ytB, ybB, hcA, midA, rawA, ytA, ybA);
-  }
+  for (int n = 0; n < 4; n++) lane_f0 |= ((((uint32_t) (cg * 4 + n) * p.hinc) >> 8) & 0xffu) == 0;
+  if (__builtin_amdgcn_ballot_w64 (lane_f0) != 0) half_strip<COSITED, RGBA, true> (p, frame, cg, cgpr, strip * rows, rows);      // wave-uniform
+  else half_strip<COSITED, RGBA, false> (p, frame, cg, cgpr, strip * rows, rows);
 }
 
 // ------------------------------------------------------------------------------------------------

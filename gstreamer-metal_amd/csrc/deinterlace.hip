@@ -200,9 +200,17 @@ __device__ __forceinline__ RgbCoef rgb_coef (int m709)
   return k;
 }
 
-__device__ __forceinline__ float quantf (float x)        // what an 8-bit unorm texel written with x reads back as
+__device__ __forceinline__ float quantf01 (float x)      // what an 8-bit unorm texel written with x in [0, 1] reads back as
 {
-  return __builtin_rintf (metal::clamp01 (x) * 255.0f) * (1.0f / 255.0f);
+  return __builtin_rintf (x * 255.0f) * (1.0f / 255.0f);
+}
+// clamp01 (fmaf (a, b, c)) in ONE instruction: the clamp output modifier of v_fma_f32 saturates the correctly rounded fma result
+// to [0, 1] (the compiler emits fma + v_max ... clamp: a fifth of this kernel's instructions were such clamps)
+__device__ __forceinline__ float fma_sat (float a, float b, float c)
+{
+  float d;
+  asm ("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
 }
 
 template <bool PLANAR>
@@ -225,7 +233,7 @@ __device__ __forceinline__ Rgb4 deint_row4 (const uint8_t *yp, const uint8_t *up
     // metal::yuv_to_rgb with the coefficients in registers (same operations, same order)
     const float ly = 1.164383f * (metal::un8 ((Y4 >> (8 * i)) & 0xffu) - 16.0f / 255.0f);
     const float u = cb[i >> 1] - 128.0f / 255.0f, v = cr[i >> 1] - 128.0f / 255.0f;
-    o.r[i] = quantf (fmaf (k.rv, v, ly)); o.g[i] = quantf (fmaf (k.gv, v, fmaf (k.gu, u, ly))); o.b[i] = quantf (fmaf (k.bu, u, ly));
+    o.r[i] = quantf01 (fma_sat (k.rv, v, ly)); o.g[i] = quantf01 (fma_sat (k.gv, v, fmaf (k.gu, u, ly))); o.b[i] = quantf01 (fma_sat (k.bu, u, ly));
   }
   return o;
 }
@@ -278,7 +286,8 @@ __device__ __forceinline__ Rgb4 deint_recon4 (const Rgb4 &cur, const Rgb4 &above
   Rgb4 o;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const float br = quantf ((above.r[i] + below.r[i]) * 0.5f), bg = quantf ((above.g[i] + below.g[i]) * 0.5f), bb = quantf ((above.b[i] + below.b[i]) * 0.5f);
+    // the mean of two texel values is inside [0, 1]: no clamp
+    const float br = quantf01 ((above.r[i] + below.r[i]) * 0.5f), bg = quantf01 ((above.g[i] + below.g[i]) * 0.5f), bb = quantf01 ((above.b[i] + below.b[i]) * 0.5f);
     bool still = false;                                   // greedy-H: no motion against the previous frame -> weave (selects, no divergent branch)
     if (METHOD == VFHIP_DEINTERLACE_GREEDYH) {
       const float dr = cur.r[i] - prev.r[i], dg = cur.g[i] - prev.g[i], db = cur.b[i] - prev.b[i];
@@ -317,7 +326,8 @@ __global__ __launch_bounds__ (256) void k_deinterlace_420q (const DeintParams pp
   for (int y = y0; y < yend; y += 2) {
     Rgb4 prev {};
     if (TFF) {
-      const Rgb4 cur = deint_row4<PLANAR> (cy, cu, cv, ys, cs, kc, q, y + 1);
+      Rgb4 cur {};
+      if (METHOD == VFHIP_DEINTERLACE_GREEDYH && hist) cur = deint_row4<PLANAR> (cy, cu, cv, ys, cs, kc, q, y + 1);      // only the motion test reads it
       const Rgb4 below = deint_row4<PLANAR> (cy, cu, cv, ys, cs, kc, q, min (y + 2, h - 1));
       if (NEED_PREV && hist) prev = deint_row4<PLANAR> (py, pu, pv, pys, pcs, kp, q, y + 1);
       const Rgb4 rec = (!NEED_PREV || hist) ? deint_recon4<METHOD> (cur, carry, below, prev, m2_limit)
@@ -325,7 +335,8 @@ __global__ __launch_bounds__ (256) void k_deinterlace_420q (const DeintParams pp
       deint_store4<PLANAR> (p.out, ko, q, y, carry, rec);
       carry = below;
     } else {
-      const Rgb4 cur = deint_row4<PLANAR> (cy, cu, cv, ys, cs, kc, q, y);
+      Rgb4 cur {};
+      if (METHOD == VFHIP_DEINTERLACE_GREEDYH && hist) cur = deint_row4<PLANAR> (cy, cu, cv, ys, cs, kc, q, y);
       const Rgb4 kept = deint_row4<PLANAR> (cy, cu, cv, ys, cs, kc, q, y + 1);
       if (NEED_PREV && hist) prev = deint_row4<PLANAR> (py, pu, pv, pys, pcs, kp, q, y);
       const Rgb4 rec = (!NEED_PREV || hist) ? deint_recon4<METHOD> (cur, carry, kept, prev, m2_limit)
