@@ -11,6 +11,7 @@
 // target is kept (it is part of the reference's arithmetic), it just happens in registers.
 #include "vfhip_internal.h"
 #include "metal_common.h"
+#include <cstdlib>
 
 using namespace vfhip;
 
@@ -93,6 +94,7 @@ __device__ __forceinline__ uint32_t comp_blend (const CompLayer &L, const F4 &s,
 
 typedef uint4 __attribute__ ((aligned (4))) uint4_a4;
 
+// k_compositor: the general kernel (any mix of scaled and unscaled pads).
 // Workgroup = 64 x 4 lanes; one lane = a 4 x 2 block of output pixels (two of the store epilogue's 2x2 blocks), so a wave
 // covers a 256 x 2 pixel strip and a lane carries eight independent blend chains (the first versions — one pixel, then
 // a 2x2 block per lane — were latency-bound: ~40 % VALU-busy with one dependent load -> blend chain per layer).
@@ -249,6 +251,193 @@ __global__ __launch_bounds__ (256) void k_compositor (const CompParams p)
   }
 }
 
+
+// k_compositor_unscaled: every pad of the launch is drawn at its own size (the common case: BASELINE configs[3], picture-in-picture,
+// mosaics of equal tiles), so no layer needs the scaling sampler and its registers.
+// Workgroup = 64 x 4 lanes; one lane = a 4 x 4 block of output pixels (COMP_PAIRS = 2 of the store epilogue's row pairs), so a
+// wave covers a 256 x 4 pixel strip and a lane carries sixteen independent blend chains.  History: one pixel, then a 2x2 block
+// per lane were latency-bound (~40 % VALU-busy, one dependent load -> blend chain per layer); 4 x 2 still had only ~40 KB of loads
+// in flight per CU and ran 4 quadrant copies at 4.2 TB/s against the 6.2 TB/s of a plain copy (profiles/r02h_c4_variants.jsonl);
+// 4 x 4 doubles the bytes in flight per wave and halves the per-wave set-up (rectangle tests, layer parameters).
+// Layers are the OUTER loop: a layer's parameters are fetched once per wave (scalar loads) and a layer that misses the wave's
+// strip is never visited.  An unscaled RGBA / BGRA pad that covers all four columns of a lane is fetched as ONE 16-byte load
+// per row, all rows first; RGBA / BGRA outputs leave as one 16-byte non-temporal store per row.
+constexpr int COMP_PAIRS = 2, COMP_ROWS = 2 * COMP_PAIRS;
+
+__global__ __launch_bounds__ (256) void k_compositor_unscaled (const CompParams p)
+{
+  const int bx = blockIdx.x * 64 + threadIdx.x;                                               // 4-pixel column group
+  const int by = __builtin_amdgcn_readfirstlane ((int) (blockIdx.y * 4 + threadIdx.y));      // one row of lanes = one wave
+  if (COMP_ROWS * by >= p.out.h) return;
+  const bool live = 4 * bx < p.out.w;
+  int xs[4], ys[COMP_ROWS];
+#pragma unroll
+  for (int i = 0; i < 4; i++) xs[i] = min (4 * bx + i, p.out.w - 1);
+#pragma unroll
+  for (int r = 0; r < COMP_ROWS; r++) ys[r] = min (COMP_ROWS * by + r, p.out.h - 1);          // edge-clamped duplicates below the frame
+  uint32_t q[COMP_ROWS][4];
+#pragma unroll
+  for (int r = 0; r < COMP_ROWS; r++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[r][i] = comp_background (p, xs[i], ys[r]);
+  const int wx0 = (int) blockIdx.x * 256, wx1 = wx0 + 256, wy0 = ys[0], wy1 = ys[COMP_ROWS - 1];
+  const unsigned z = blockIdx.z;
+  // which layers touch this wave's strip?  All sixteen rectangles are tested up front: independent scalar loads that pipeline
+  // into one memory latency (testing inside the layer loop chained one dependent scalar-load latency per layer)
+  uint32_t hit = 0;
+#pragma unroll
+  for (int k = 0; k < COMP_MAX_LAYERS; k++) {
+    const CompLayer &L = p.layer[k];
+    const bool miss = k >= p.n || wx1 <= L.xpos || wx0 >= L.xpos + L.width || wy1 < L.ypos || wy0 >= L.ypos + L.height;
+    hit |= miss ? 0u : 1u << k;
+  }
+  hit = (uint32_t) __builtin_amdgcn_readfirstlane ((int) hit);                                 // wave-uniform by construction
+  // a uniform background reads back as one scalar colour until the first layer has been drawn
+  bool flat = p.background == VFHIP_BG_BLACK || p.background == VFHIP_BG_WHITE || p.background == VFHIP_BG_TRANSPARENT;
+  F4 bgc;
+  bgc.r = bgc.g = bgc.b = p.background == VFHIP_BG_WHITE ? 1.0f : 0.0f; bgc.a = p.background == VFHIP_BG_TRANSPARENT ? 0.0f : 1.0f;     // un8 (0) / un8 (255)
+  for (; hit; flat = false) {
+    const int k = __builtin_ctz (hit);
+    hit &= hit - 1;
+    const CompLayer &L = p.layer[k];
+    // a pixel is covered when its centre lies inside the quad [xpos, xpos+width) x [ypos, ypos+height)
+    const int lx1 = L.xpos + L.width, ly1 = L.ypos + L.height;
+    const metal::Img im = metal::img_at (L.img, z * L.pitch);
+    bool cx[4], cy[COMP_ROWS];
+#pragma unroll
+    for (int i = 0; i < 4; i++) cx[i] = xs[i] >= L.xpos && xs[i] < lx1;
+#pragma unroll
+    for (int r = 0; r < COMP_ROWS; r++) cy[r] = ys[r] >= L.ypos && ys[r] < ly1;
+    const bool rgba_in = im.fmt == VFHIP_FORMAT_RGBA;
+    const bool unscaled = true, full_x = cx[0] && cx[3] && xs[3] == xs[0] + 3;       // the host checked every layer (comp_launch)
+    if (full_x && unscaled && (rgba_in || im.fmt == VFHIP_FORMAT_BGRA)) {
+      uint4 t[COMP_ROWS];
+#pragma unroll
+      for (int r = 0; r < COMP_ROWS; r++)                 // every row's load first, then the blends
+        if (cy[r]) t[r] = *reinterpret_cast<const uint4_a4 *> (im.p[0] + (size_t) (ys[r] - L.ypos) * im.s[0] + 4 * (xs[0] - L.xpos));
+#pragma unroll
+      for (int r = 0; r < COMP_ROWS; r++) {
+        if (!cy[r]) continue;
+        q[r][0] = comp_blend (L, comp_texel (t[r].x, rgba_in), q[r][0], flat, bgc);
+        q[r][1] = comp_blend (L, comp_texel (t[r].y, rgba_in), q[r][1], flat, bgc);
+        q[r][2] = comp_blend (L, comp_texel (t[r].z, rgba_in), q[r][2], flat, bgc);
+        q[r][3] = comp_blend (L, comp_texel (t[r].w, rgba_in), q[r][3], flat, bgc);
+      }
+      continue;
+    }
+    const bool yuv420 = im.fmt == VFHIP_FORMAT_NV12 || im.fmt == VFHIP_FORMAT_I420;
+#pragma unroll 1
+    for (int pr = 0; pr < COMP_PAIRS; pr++) {
+      // row pair (r0, r0 + 1) of the lane's block; the register-indexed selects below keep q in registers with a rolled loop
+      const int r0 = 2 * pr;
+      const int y0 = pr ? ys[2] : ys[0], y1 = pr ? ys[3] : ys[1];
+      const bool cy0 = pr ? cy[2] : cy[0], cy1 = pr ? cy[3] : cy[1];
+      uint32_t qa[2][4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) { qa[0][i] = pr ? q[2][i] : q[0][i]; qa[1][i] = pr ? q[3][i] : q[1][i]; }
+      if (full_x && unscaled && yuv420 && cy0 && cy1 && y1 == y0 + 1 && !(((xs[0] - L.xpos) | (y0 - L.ypos)) & 1)) {
+        // unscaled 4:2:0 pad whose chroma grid is aligned with the 4 x 2 block: the 8 pixels share 3 chroma rows x 4 chroma columns.
+        // fetch_1to1's bilinear chroma (phases .25 / .75) from 12 (U, V) fetches + 2 luma dwords instead of 72 byte loads, the
+        // horizontal interpolation of the middle chroma row shared by both pixel rows.  Same operations per value as
+        // metal::fetch_1to1 / plane_taps, so the result is bit-identical to the general path.
+        const int px = xs[0] - L.xpos, py = y0 - L.ypos, j = px >> 1, m = py >> 1;
+        const int cw = (im.w + 1) >> 1, chh = (im.h + 1) >> 1;
+        typedef uint32_t __attribute__ ((aligned (1))) u32_any;
+        typedef uint16_t __attribute__ ((aligned (1))) u16_any;
+        uint32_t Y[2];
+        Y[0] = *reinterpret_cast<const u32_any *> (im.p[0] + (size_t) py * im.s[0] + px);
+        Y[1] = *reinterpret_cast<const u32_any *> (im.p[0] + (size_t) (py + 1) * im.s[0] + px);
+        float cu[3][4], cv[3][4];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          const int row = metal::iclamp (m - 1 + r, 0, chh - 1);
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            const int col = metal::iclamp (j - 1 + c, 0, cw - 1);
+            if (im.fmt == VFHIP_FORMAT_NV12) {
+              const uint32_t uv = *reinterpret_cast<const u16_any *> (im.p[1] + (size_t) row * im.s[1] + 2 * col);
+              cu[r][c] = metal::un8 (uv & 0xffu); cv[r][c] = metal::un8 (uv >> 8);
+            } else {
+              cu[r][c] = metal::un8 (im.p[1][(size_t) row * im.s[1] + col]); cv[r][c] = metal::un8 (im.p[2][(size_t) row * im.s[2] + col]);
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          // pixel px + i samples chroma at 0.5 (px + i) - 0.25: weight .75 for even i, .25 for odd i
+          const int a = (i + 1) >> 1;                        // index of the first tap in cu[][0..3]: i = 0 -> 0, 1 -> 1, 2 -> 1, 3 -> 2
+          const float fx = (i & 1) ? 0.25f : 0.75f;
+          float hu[3], hv[3];
+#pragma unroll
+          for (int r = 0; r < 3; r++) { hu[r] = metal::lerp2 (cu[r][a], cu[r][a + 1], fx); hv[r] = metal::lerp2 (cv[r][a], cv[r][a + 1], fx); }
+#pragma unroll
+          for (int r = 0; r < 2; r++) {
+            const float fy = r ? 0.25f : 0.75f;
+            const float cb = metal::lerp2 (hu[r], hu[r + 1], fy), cr = metal::lerp2 (hv[r], hv[r + 1], fy);
+            const F4 c = metal::yuv_to_rgb (metal::un8 ((Y[r] >> (8 * i)) & 0xffu), cb, cr, im.m709);
+            qa[r][i] = comp_blend (L, c, qa[r][i], flat, bgc);
+          }
+        }
+      } else {
+        // lane blocks cut by the pad's edge, 4:2:0 pads off the chroma grid: exact-texel fetch pixel by pixel (ONE rolled instance)
+#pragma unroll 1
+        for (int i = 0; i < 8; i++) {
+          const int c = i & 3, r = i >> 2;
+          const bool cxi = c == 0 ? cx[0] : (c == 1 ? cx[1] : (c == 2 ? cx[2] : cx[3]));
+          if (!(cxi && (r ? cy1 : cy0))) continue;
+          const int xi = c == 0 ? xs[0] : (c == 1 ? xs[1] : (c == 2 ? xs[2] : xs[3]));
+          uint32_t cur = 0;
+#pragma unroll
+          for (int j = 0; j < 8; j++) cur = i == j ? qa[j >> 2][j & 3] : cur;
+          const uint32_t v = comp_blend (L, metal::fetch_1to1 (im, xi - L.xpos, (r ? y1 : y0) - L.ypos, true), cur, flat, bgc);
+#pragma unroll
+          for (int j = 0; j < 8; j++) qa[j >> 2][j & 3] = i == j ? v : qa[j >> 2][j & 3];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        q[0][i] = pr ? q[0][i] : qa[0][i]; q[1][i] = pr ? q[1][i] : qa[1][i];
+        q[2][i] = pr ? qa[0][i] : q[2][i]; q[3][i] = pr ? qa[1][i] : q[3][i];
+      }
+      (void) r0;
+    }
+  }
+  if (!live) return;
+  if (p.scratch) {
+#pragma unroll
+    for (int dy = 0; dy < COMP_ROWS; dy++)
+#pragma unroll
+      for (int dx = 0; dx < 4; dx++)
+        if (4 * bx + dx < p.out.w && COMP_ROWS * by + dy < p.out.h) p.scratch[(size_t) (COMP_ROWS * by + dy) * p.scratch_stride + 4 * bx + dx] = q[dy][dx];
+    return;
+  }
+  const metal::OutImg o = metal::out_at (p.out, z * p.out_pitch);
+  if ((o.fmt == VFHIP_FORMAT_BGRA || o.fmt == VFHIP_FORMAT_RGBA) && 4 * bx + 3 < o.w && !(((uintptr_t) o.p[0] | (uintptr_t) o.s[0]) & 15)) {
+    typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
+#pragma unroll
+    for (int dy = 0; dy < COMP_ROWS; dy++) {
+      if (COMP_ROWS * by + dy >= o.h) break;
+      v4u v = { q[dy][0], q[dy][1], q[dy][2], q[dy][3] };
+      if (o.fmt == VFHIP_FORMAT_BGRA) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = __builtin_amdgcn_perm (0u, v[i], 0x03000102u);     // swap bytes 0 and 2
+      }
+      __builtin_nontemporal_store (v, reinterpret_cast<v4u *> (o.p[0] + (size_t) (COMP_ROWS * by + dy) * o.s[0]) + bx);
+    }
+    return;
+  }
+#pragma unroll
+  for (int pr = 0; pr < COMP_PAIRS; pr++) {
+    if (2 * (COMP_PAIRS * by + pr) >= o.h) break;
+    const uint32_t qa[2][2] = { { q[2 * pr][0], q[2 * pr][1] }, { q[2 * pr + 1][0], q[2 * pr + 1][1] } };
+    metal::store_block (o, 2 * bx, COMP_PAIRS * by + pr, qa);
+    if (4 * bx + 2 < o.w) {
+      const uint32_t qb[2][2] = { { q[2 * pr][2], q[2 * pr][3] }, { q[2 * pr + 1][2], q[2 * pr + 1][3] } };
+      metal::store_block (o, 2 * bx + 1, COMP_PAIRS * by + pr, qb);
+    }
+  }
+}
+
 }  // namespace vfhip
 
 struct VfHipCompositor {
@@ -265,7 +454,12 @@ static int comp_launch (VfHipCompositor *h, const VfHipPadInput *pads, int count
     int n_frames = 1, const size_t *pad_pitch = nullptr, size_t out_pitch = 0)
 {
   const int w = h->out.width, hh = h->out.height;
-  const int bw = (w + 3) / 4, bh = (hh + 1) / 2;             // lanes: 4 x 2 pixel blocks
+  // every pad at its own size -> k_compositor_unscaled (4 x 4 pixel blocks per lane); otherwise the general kernel (4 x 2)
+  bool unscaled = getenv ("VFHIP_COMP_GENERAL") == nullptr;       // test knob: force the general kernel
+  for (int k = 0; k < count && unscaled; k++)
+    if (pads[k].width > 0 && pads[k].height > 0 && (pads[k].width != pads[k].frame.info.width || pads[k].height != pads[k].frame.info.height)) unscaled = false;
+  const int rows = unscaled ? COMP_ROWS : 2;
+  const int bw = (w + 3) / 4, bh = (hh + rows - 1) / rows;
   dim3 grid ((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4), (unsigned) n_frames);
   const int passes = count <= COMP_MAX_LAYERS ? 1 : (count + COMP_MAX_LAYERS - 1) / COMP_MAX_LAYERS;
   if (passes > 1)
@@ -288,7 +482,8 @@ static int comp_launch (VfHipCompositor *h, const VfHipPadInput *pads, int count
     p.prev = pass == 0 ? nullptr : h->scratch[(pass - 1) & 1]; p.prev_stride = w;
     p.out = metal::make_out (out); p.out_pitch = out_pitch;
     p.scratch = pass == passes - 1 ? nullptr : h->scratch[pass & 1]; p.scratch_stride = w;
-    hipLaunchKernelGGL (k_compositor, grid, dim3 (64, 4), 0, s, p);
+    if (unscaled) hipLaunchKernelGGL (k_compositor_unscaled, grid, dim3 (64, 4), 0, s, p);
+    else hipLaunchKernelGGL (k_compositor, grid, dim3 (64, 4), 0, s, p);
     VFHIP_CHECK_HIP (hipGetLastError ());
   }
   return VFHIP_OK;

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""tools/bench_c4_variants.py — where does BASELINE configs[3] (compositor 4 x BGRA 1080p + NV12 720p -> BGRA 2160p) spend its time?
+The full configuration next to stripped ones (kernel-only, device-resident, batches of 8 output frames)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gstreamer-metal_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch  # noqa: E402
+import vfhip  # noqa: E402
+from bench_elements import ring, timed  # noqa: E402
+
+s = torch.cuda.Stream()
+ow, oh, NC = 3840, 2160, 32
+quads = [ring(NC, 4 * 1920 * 1080, 10 + k) for k in range(4)]
+nvs = vfhip.plane_layout("NV12", 1280, 720)[1]
+nv = ring(NC, nvs, 20)
+out = torch.empty((NC, 4 * ow * oh), dtype=torch.uint8, device="cuda")
+comp = vfhip.Compositor(0)
+comp.configure("BGRA", ow, oh)
+qp = [comp.pad("BGRA", 1920, 1080, quads[k].data_ptr(), (k % 2) * 1920, (k // 2) * 1080, 1920, 1080, 0.9, "over") for k in range(4)]
+qsrc = [comp.pad("BGRA", 1920, 1080, quads[k].data_ptr(), (k % 2) * 1920, (k // 2) * 1080, 1920, 1080, 1.0, "source") for k in range(4)]
+nvp = comp.pad("NV12", 1280, 720, nv.data_ptr(), (ow - 1280) // 2, (oh - 720) // 2, 1280, 720, 0.7, "over", colorimetry="bt709")
+nvodd = comp.pad("NV12", 1280, 720, nv.data_ptr(), (ow - 1280) // 2 + 1, (oh - 720) // 2 + 1, 1280, 720, 0.7, "over", colorimetry="bt709")
+cases = [("C4 full: 4 quadrants (over, .9) + NV12 720p centred", qp + [nvp], [quads[0].shape[1]] * 4 + [nv.shape[1]], "black"),
+         ("4 quadrants only (over, .9)", qp, [quads[0].shape[1]] * 4, "black"),
+         ("4 quadrants, operator source, alpha 1", qsrc, [quads[0].shape[1]] * 4, "black"),
+         ("4 quadrants over a checker background", qp, [quads[0].shape[1]] * 4, "checker"),
+         ("no pads: background only", [], [], "black"),
+         ("C4 with the NV12 pad one pixel off the chroma grid (general sampler path)", qp + [nvodd], [quads[0].shape[1]] * 4 + [nv.shape[1]], "black")]
+for name, pads, pitches, bg in cases:
+    def run():
+        comp.composite_device(pads, out.data_ptr(), background=bg, stream=s.cuda_stream, n_frames=NC, pad_pitches=pitches, out_pitch=out.shape[1])
+    ms = timed(run, s, 10) / NC
+    print(json.dumps({"case": name, "us_per_frame": round(ms * 1e3, 2), "frames_per_s": round(1e3 / ms, 1)}), flush=True)
+comp.close()

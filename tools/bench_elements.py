@@ -107,7 +107,7 @@ def main():
 
     # C4: compositor 4 x BGRA 1080p (alpha .9, over) + NV12 720p centred (alpha .7) -> BGRA 2160p, black background
     ow, oh = 3840, 2160
-    NC = 8
+    NC = 32
     quads = [ring(NC, 4 * 1920 * 1080, 10 + k) for k in range(4)]
     nv = ring(NC, vfhip.plane_layout("NV12", 1280, 720)[1], 20)
     out = ring(NC, 4 * ow * oh, 21)
