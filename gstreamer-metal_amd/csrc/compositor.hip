@@ -12,12 +12,14 @@
 #include "vfhip_internal.h"
 #include "metal_common.h"
 #include <cstdlib>
+#include <algorithm>
 
 using namespace vfhip;
 
 namespace vfhip {
 
 constexpr int COMP_MAX_LAYERS = 16;     // per launch; more pads chain through an RGBA8 scratch target
+constexpr int COMP_BG_IN_PLACE = -2;
 
 struct CompLayer {
   metal::Img img;
@@ -29,8 +31,10 @@ struct CompLayer {
 struct CompParams {
   CompLayer layer[COMP_MAX_LAYERS];
   int n;
-  int background;                       // VfHipBackground, or -1: start from `prev` (logical RGBA8 of an earlier pass)
+  int background;                       // VfHipBackground; -1: start from `prev` (logical RGBA8 of an earlier pass); COMP_BG_IN_PLACE:
+                                        // start from what `out` (RGBA / BGRA) already holds — a later draw over part of the frame
   const uint32_t *prev; int prev_stride;
+  int bx0, by0;                         // the launch's first lane block (region launches; 0 for a full frame)
   metal::OutImg out;
   uint32_t *scratch; int scratch_stride;   // != nullptr: write logical RGBA8 here instead of `out`
   size_t out_pitch;                     // batch: output frame z at base + z * out_pitch (single-pass launches only)
@@ -38,18 +42,24 @@ struct CompParams {
 
 using metal::F4;
 
-__device__ __forceinline__ uint32_t comp_background (const CompParams &p, int x, int y)
+// TARGET ORDER: the running colour q of a pixel is kept in the byte order of the output when that is RGBA or BGRA (logical RGBA
+// for the planar outputs), so it is loaded from and stored to such an output as it is; the blend treats R, G and B alike, the
+// backgrounds have R = B, and only a layer's own colour is brought into target order: a texel by the byte permute that unpacks
+// it anyway, a sampled colour by exchanging two registers.
+__device__ __forceinline__ uint32_t comp_swap_rb (uint32_t v, bool swap) { return __builtin_amdgcn_perm (0u, v, swap ? 0x03000102u : 0x03020100u); }
+__device__ __forceinline__ F4 comp_order (F4 c, bool bgra_target) { if (bgra_target) { const float t = c.r; c.r = c.b; c.b = t; } return c; }
+
+__device__ __forceinline__ uint32_t comp_background (const CompParams &p, const metal::OutImg &o, int x, int y)
 {
+  if (p.background == COMP_BG_IN_PLACE) return *reinterpret_cast<const uint32_t *> (o.p[0] + (size_t) y * o.s[0] + 4 * x);       // already in target order
   if (p.background < 0) return p.prev[(size_t) y * p.prev_stride + x];
   if (p.background == VFHIP_BG_BLACK) return 0xff000000u;
   if (p.background == VFHIP_BG_WHITE) return 0xffffffffu;
   if (p.background == VFHIP_BG_TRANSPARENT) return 0u;
-  // checker: pos = int2(texcoord * size), 8x8 cells, grey 0.75 / 0.5 (metalcomprenderer.m:113-121)
-  const float tu = ((float) x + 0.5f) / (float) p.out.w, tv = ((float) y + 0.5f) / (float) p.out.h;
-  const int px = (int) (tu * (float) p.out.w), py = (int) (tv * (float) p.out.h);
-  const float gray = ((px / 8) + (py / 8)) % 2 ? 0.75f : 0.5f;
-  F4 c; c.r = c.g = c.b = gray; c.a = 1.0f;
-  return metal::quant_rgba8 (c);
+  // checker: pos = int2 (texcoord * size) with texcoord = (x + .5) / size, 8x8 cells, grey 0.75 / 0.5 (metalcomprenderer.m:113-121).
+  // int ((x + .5) / w * w) == x for every frame size the API admits (two roundings of 2^-24 relative on a value < 32768.5 cannot
+  // reach the .5 distance to the next integer), so the cell parity comes from the integer coordinates; unorm8 (.75) = 191, (.5) = 128.
+  return ((x >> 3) + (y >> 3)) & 1 ? 0xffbfbfbfu : 0xff808080u;
 }
 
 // the layer's colour at output pixel (x, y); the caller has checked coverage
@@ -65,28 +75,27 @@ __device__ __forceinline__ F4 comp_sample (const CompLayer &L, const metal::Img 
   return metal::sample_rgba (im, tu, tv, true);
 }
 
-__device__ __forceinline__ F4 comp_texel (uint32_t t, bool rgba)
+__device__ __forceinline__ F4 comp_texel (uint32_t t, bool in_order)
 {
-  F4 o;
-  o.g = metal::un8 ((t >> 8) & 0xff); o.a = metal::un8 (t >> 24);
-  if (rgba) { o.r = metal::un8 (t & 0xff); o.b = metal::un8 ((t >> 16) & 0xff); }
-  else { o.b = metal::un8 (t & 0xff); o.r = metal::un8 ((t >> 16) & 0xff); }
-  return o;
+  // one byte permute (wave-uniform selector) puts a texel of the other byte order into target order, instead of two copies of the conversions
+  return metal::unpack_rgba8 (comp_swap_rb (t, !in_order));
 }
 
-// colour s of one layer drawn over the target value d (the 8-bit target read back as floats)
+// colour s of one layer drawn over the target value d (the 8-bit target read back as floats).
+// One expression serves the three operators: out = d * k + s with k = 0 (source), 1 (add), 1 - s.a (over).  fmaf (d, 0, s) = s and
+// fmaf (d, 1, s) = s + d exactly for the finite non-negative values here, so this is compositorFragment's arithmetic
+// (oracle/metalref.c comp_blend) bit for bit, in a third of the code.
 __device__ __forceinline__ uint32_t comp_blend_f (const CompLayer &L, F4 s, const F4 &d)
 {
   s.a *= L.alpha; s.r *= s.a; s.g *= s.a; s.b *= s.a;            // premultiply (compositorFragment, :58-59)
+  const float k = L.blend == VFHIP_BLEND_SOURCE ? 0.0f : (L.blend == VFHIP_BLEND_ADD ? 1.0f : 1.0f - s.a);
   F4 o;
-  if (L.blend == VFHIP_BLEND_SOURCE) o = s;
-  else if (L.blend == VFHIP_BLEND_ADD) { o.r = s.r + d.r; o.g = s.g + d.g; o.b = s.b + d.b; o.a = s.a + d.a; }
-  else { const float k1 = 1.0f - s.a; o.r = fmaf (d.r, k1, s.r); o.g = fmaf (d.g, k1, s.g); o.b = fmaf (d.b, k1, s.b); o.a = fmaf (d.a, k1, s.a); }
+  o.r = fmaf (d.r, k, s.r); o.g = fmaf (d.g, k, s.g); o.b = fmaf (d.b, k, s.b); o.a = fmaf (d.a, k, s.a);
   return metal::quant_rgba8 (o);
 }
 // ... over the 8-bit target value q.  `flat`: wave-uniform, the target still holds the uniform background colour `bgc` under every
 // lane (the first layer a wave draws over a black / white / transparent background): the target's read-back is then a scalar,
-// not eight conversions per pixel
+// not four conversions per pixel
 __device__ __forceinline__ uint32_t comp_blend (const CompLayer &L, const F4 &s, uint32_t q, bool flat, const F4 &bgc)
 {
   return flat ? comp_blend_f (L, s, bgc) : comp_blend_f (L, s, metal::unpack_rgba8 (q));
@@ -103,19 +112,21 @@ typedef uint4 __attribute__ ((aligned (4))) uint4_a4;
 // is fetched as ONE 16-byte load per row; RGBA / BGRA outputs leave as one 16-byte non-temporal store per row.
 __global__ __launch_bounds__ (256) void k_compositor (const CompParams p)
 {
-  const int bx = blockIdx.x * 64 + threadIdx.x;                                               // 4-pixel column group
-  const int by = __builtin_amdgcn_readfirstlane ((int) (blockIdx.y * 4 + threadIdx.y));      // one row of lanes = one wave
+  const int bx = p.bx0 + blockIdx.x * 64 + threadIdx.x;                                       // 4-pixel column group
+  const int by = __builtin_amdgcn_readfirstlane ((int) (p.by0 + blockIdx.y * 4 + threadIdx.y));      // one row of lanes = one wave
   if (2 * by >= p.out.h) return;
   const bool live = 4 * bx < p.out.w;
   int xs[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) xs[i] = min (4 * bx + i, p.out.w - 1);
   const int y0 = 2 * by, y1 = min (2 * by + 1, p.out.h - 1);
+  const unsigned z = blockIdx.z;
+  const metal::OutImg o = metal::out_at (p.out, z * p.out_pitch);
+  const bool bgra_out = o.fmt == VFHIP_FORMAT_BGRA;                   // q is kept in TARGET ORDER
   uint32_t q[2][4];
 #pragma unroll
-  for (int i = 0; i < 4; i++) { q[0][i] = comp_background (p, xs[i], y0); q[1][i] = comp_background (p, xs[i], y1); }
-  const int wx0 = (int) blockIdx.x * 256, wx1 = wx0 + 256;
-  const unsigned z = blockIdx.z;
+  for (int i = 0; i < 4; i++) { q[0][i] = comp_background (p, o, xs[i], y0); q[1][i] = comp_background (p, o, xs[i], y1); }
+  const int wx0 = 4 * (p.bx0 + (int) blockIdx.x * 64), wx1 = wx0 + 256;
   // which layers touch this wave's 256 x 2 strip?  All sixteen rectangles are tested up front: independent scalar loads that
   // pipeline into one memory latency (testing inside the layer loop chained one dependent scalar-load latency per layer, five
   // per wave on BASELINE configs[3], most of them for layers the wave never draws)
@@ -142,8 +153,8 @@ __global__ __launch_bounds__ (256) void k_compositor (const CompParams p)
 #pragma unroll
     for (int i = 0; i < 4; i++) cx[i] = xs[i] >= L.xpos && xs[i] < lx1;
     const bool cy0 = y0 >= L.ypos && y0 < ly1, cy1 = y1 >= L.ypos && y1 < ly1;
-    const bool rgba_in = im.fmt == VFHIP_FORMAT_RGBA;
-    const bool quad = cx[0] && cx[3] && xs[3] == xs[0] + 3 && (rgba_in || im.fmt == VFHIP_FORMAT_BGRA) && L.width == L.img.w && L.height == L.img.h;
+    const bool rgba_in = (im.fmt == VFHIP_FORMAT_RGBA) != bgra_out;        // the pad's texels are in target order
+    const bool quad = cx[0] && cx[3] && xs[3] == xs[0] + 3 && (im.fmt == VFHIP_FORMAT_RGBA || im.fmt == VFHIP_FORMAT_BGRA) && L.width == L.img.w && L.height == L.img.h;
     if (quad) {
       uint4 t[2];
 #pragma unroll
@@ -197,7 +208,7 @@ __global__ __launch_bounds__ (256) void k_compositor (const CompParams p)
         for (int r = 0; r < 2; r++) {
           const float fy = r ? 0.25f : 0.75f;
           const float cb = metal::lerp2 (hu[r], hu[r + 1], fy), cr = metal::lerp2 (hv[r], hv[r + 1], fy);
-          const F4 c = metal::yuv_to_rgb (metal::un8 ((Y[r] >> (8 * i)) & 0xffu), cb, cr, im.m709);
+          const F4 c = comp_order (metal::yuv_to_rgb (metal::un8 ((Y[r] >> (8 * i)) & 0xffu), cb, cr, im.m709), bgra_out);
           q[r][i] = comp_blend (L, c, q[r][i], flat, bgc);
         }
       }
@@ -213,7 +224,7 @@ __global__ __launch_bounds__ (256) void k_compositor (const CompParams p)
         uint32_t cur = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) cur = i == j ? q[j >> 2][j & 3] : cur;
-        const uint32_t v = comp_blend (L, comp_sample (L, im, xi, r ? y1 : y0), cur, flat, bgc);
+        const uint32_t v = comp_blend (L, comp_order (comp_sample (L, im, xi, r ? y1 : y0), bgra_out), cur, flat, bgc);
 #pragma unroll
         for (int j = 0; j < 8; j++) q[j >> 2][j & 3] = i == j ? v : q[j >> 2][j & 3];
       }
@@ -228,21 +239,21 @@ __global__ __launch_bounds__ (256) void k_compositor (const CompParams p)
         if (4 * bx + dx < p.out.w && 2 * by + dy < p.out.h) p.scratch[(size_t) (2 * by + dy) * p.scratch_stride + 4 * bx + dx] = q[dy][dx];
     return;
   }
-  const metal::OutImg o = metal::out_at (p.out, z * p.out_pitch);
   if ((o.fmt == VFHIP_FORMAT_BGRA || o.fmt == VFHIP_FORMAT_RGBA) && 4 * bx + 3 < o.w && !(((uintptr_t) o.p[0] | (uintptr_t) o.s[0]) & 15)) {
     typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
 #pragma unroll
     for (int dy = 0; dy < 2; dy++) {
       if (2 * by + dy >= o.h) break;
-      v4u v = { q[dy][0], q[dy][1], q[dy][2], q[dy][3] };
-      if (o.fmt == VFHIP_FORMAT_BGRA) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) v[i] = __builtin_amdgcn_perm (0u, v[i], 0x03000102u);     // swap bytes 0 and 2
-      }
+      const v4u v = { q[dy][0], q[dy][1], q[dy][2], q[dy][3] };                              // target order: stored as it is
       __builtin_nontemporal_store (v, reinterpret_cast<v4u *> (o.p[0] + (size_t) (2 * by + dy) * o.s[0]) + bx);
     }
     return;
   }
+  // store_block takes logical RGBA (an unaligned or odd-width BGRA output comes this way too)
+#pragma unroll
+  for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+    for (int dx = 0; dx < 4; dx++) q[dy][dx] = comp_swap_rb (q[dy][dx], bgra_out);
   const uint32_t qa[2][2] = { { q[0][0], q[0][1] }, { q[1][0], q[1][1] } };
   metal::store_block (o, 2 * bx, by, qa);
   if (4 * bx + 2 < o.w) {
@@ -266,8 +277,8 @@ constexpr int COMP_PAIRS = 2, COMP_ROWS = 2 * COMP_PAIRS;
 
 __global__ __launch_bounds__ (256) void k_compositor_unscaled (const CompParams p)
 {
-  const int bx = blockIdx.x * 64 + threadIdx.x;                                               // 4-pixel column group
-  const int by = __builtin_amdgcn_readfirstlane ((int) (blockIdx.y * 4 + threadIdx.y));      // one row of lanes = one wave
+  const int bx = p.bx0 + blockIdx.x * 64 + threadIdx.x;                                       // 4-pixel column group
+  const int by = __builtin_amdgcn_readfirstlane ((int) (p.by0 + blockIdx.y * 4 + threadIdx.y));      // one row of lanes = one wave
   if (COMP_ROWS * by >= p.out.h) return;
   const bool live = 4 * bx < p.out.w;
   int xs[4], ys[COMP_ROWS];
@@ -275,13 +286,15 @@ __global__ __launch_bounds__ (256) void k_compositor_unscaled (const CompParams 
   for (int i = 0; i < 4; i++) xs[i] = min (4 * bx + i, p.out.w - 1);
 #pragma unroll
   for (int r = 0; r < COMP_ROWS; r++) ys[r] = min (COMP_ROWS * by + r, p.out.h - 1);          // edge-clamped duplicates below the frame
+  const unsigned z = blockIdx.z;
+  const metal::OutImg o = metal::out_at (p.out, z * p.out_pitch);
+  const bool bgra_out = o.fmt == VFHIP_FORMAT_BGRA;                   // q is kept in TARGET ORDER
   uint32_t q[COMP_ROWS][4];
 #pragma unroll
   for (int r = 0; r < COMP_ROWS; r++)
 #pragma unroll
-    for (int i = 0; i < 4; i++) q[r][i] = comp_background (p, xs[i], ys[r]);
-  const int wx0 = (int) blockIdx.x * 256, wx1 = wx0 + 256, wy0 = ys[0], wy1 = ys[COMP_ROWS - 1];
-  const unsigned z = blockIdx.z;
+    for (int i = 0; i < 4; i++) q[r][i] = comp_background (p, o, xs[i], ys[r]);
+  const int wx0 = 4 * (p.bx0 + (int) blockIdx.x * 64), wx1 = wx0 + 256, wy0 = ys[0], wy1 = ys[COMP_ROWS - 1];
   // which layers touch this wave's strip?  All sixteen rectangles are tested up front: independent scalar loads that pipeline
   // into one memory latency (testing inside the layer loop chained one dependent scalar-load latency per layer)
   uint32_t hit = 0;
@@ -308,9 +321,9 @@ __global__ __launch_bounds__ (256) void k_compositor_unscaled (const CompParams 
     for (int i = 0; i < 4; i++) cx[i] = xs[i] >= L.xpos && xs[i] < lx1;
 #pragma unroll
     for (int r = 0; r < COMP_ROWS; r++) cy[r] = ys[r] >= L.ypos && ys[r] < ly1;
-    const bool rgba_in = im.fmt == VFHIP_FORMAT_RGBA;
+    const bool rgba_in = (im.fmt == VFHIP_FORMAT_RGBA) != bgra_out;        // the pad's texels are in target order
     const bool unscaled = true, full_x = cx[0] && cx[3] && xs[3] == xs[0] + 3;       // the host checked every layer (comp_launch)
-    if (full_x && unscaled && (rgba_in || im.fmt == VFHIP_FORMAT_BGRA)) {
+    if (full_x && unscaled && (im.fmt == VFHIP_FORMAT_RGBA || im.fmt == VFHIP_FORMAT_BGRA)) {
       uint4 t[COMP_ROWS];
 #pragma unroll
       for (int r = 0; r < COMP_ROWS; r++)                 // every row's load first, then the blends
@@ -326,80 +339,83 @@ __global__ __launch_bounds__ (256) void k_compositor_unscaled (const CompParams 
       continue;
     }
     const bool yuv420 = im.fmt == VFHIP_FORMAT_NV12 || im.fmt == VFHIP_FORMAT_I420;
-#pragma unroll 1
-    for (int pr = 0; pr < COMP_PAIRS; pr++) {
-      // row pair (r0, r0 + 1) of the lane's block; the register-indexed selects below keep q in registers with a rolled loop
-      const int r0 = 2 * pr;
-      const int y0 = pr ? ys[2] : ys[0], y1 = pr ? ys[3] : ys[1];
-      const bool cy0 = pr ? cy[2] : cy[0], cy1 = pr ? cy[3] : cy[1];
-      uint32_t qa[2][4];
+    if (full_x && yuv420 && im.w >= 7 && cy[0] && cy[COMP_ROWS - 1] && ys[COMP_ROWS - 1] == ys[0] + COMP_ROWS - 1 && !(((xs[0] - L.xpos) | (ys[0] - L.ypos)) & 1)) {
+      // unscaled 4:2:0 pad whose chroma grid is aligned with the lane's 4 x 4 block: the 16 pixels share 4 chroma rows x 4 chroma
+      // columns.  fetch_1to1's bilinear chroma (phases .25 / .75) from 4 chroma fetches of 8 (NV12) or 2 x 4 (I420) bytes + 4 luma
+      // dwords, ALL issued before the first conversion, instead of 144 byte loads; the chroma rows then stream through the
+      // horizontal interpolation one at a time (two rows of eight floats live) and each pair of consecutive rows yields the
+      // pixel rows between them.  Same operations per value as metal::fetch_1to1 / plane_taps -> bit-identical to the general path.
+      const int px = xs[0] - L.xpos, py = ys[0] - L.ypos, j = px >> 1, m = py >> 1;
+      const int cw = (im.w + 1) >> 1, chh = (im.h + 1) >> 1;
+      typedef uint32_t __attribute__ ((aligned (1))) u32_any;
+      typedef uint2 __attribute__ ((aligned (1))) u64_any;
+      uint32_t Y[COMP_ROWS], Ud[COMP_ROWS], Vd[COMP_ROWS];                 // Ud / Vd: chroma columns j - 1 .. j + 2, one byte each
 #pragma unroll
-      for (int i = 0; i < 4; i++) { qa[0][i] = pr ? q[2][i] : q[0][i]; qa[1][i] = pr ? q[3][i] : q[1][i]; }
-      if (full_x && unscaled && yuv420 && cy0 && cy1 && y1 == y0 + 1 && !(((xs[0] - L.xpos) | (y0 - L.ypos)) & 1)) {
-        // unscaled 4:2:0 pad whose chroma grid is aligned with the 4 x 2 block: the 8 pixels share 3 chroma rows x 4 chroma columns.
-        // fetch_1to1's bilinear chroma (phases .25 / .75) from 12 (U, V) fetches + 2 luma dwords instead of 72 byte loads, the
-        // horizontal interpolation of the middle chroma row shared by both pixel rows.  Same operations per value as
-        // metal::fetch_1to1 / plane_taps, so the result is bit-identical to the general path.
-        const int px = xs[0] - L.xpos, py = y0 - L.ypos, j = px >> 1, m = py >> 1;
-        const int cw = (im.w + 1) >> 1, chh = (im.h + 1) >> 1;
-        typedef uint32_t __attribute__ ((aligned (1))) u32_any;
-        typedef uint16_t __attribute__ ((aligned (1))) u16_any;
-        uint32_t Y[2];
-        Y[0] = *reinterpret_cast<const u32_any *> (im.p[0] + (size_t) py * im.s[0] + px);
-        Y[1] = *reinterpret_cast<const u32_any *> (im.p[0] + (size_t) (py + 1) * im.s[0] + px);
-        float cu[3][4], cv[3][4];
+      for (int r = 0; r < COMP_ROWS; r++) Y[r] = *reinterpret_cast<const u32_any *> (im.p[0] + (size_t) (py + r) * im.s[0] + px);
+      const bool nv12 = im.fmt == VFHIP_FORMAT_NV12;
+      // columns j - 1 .. j + 2 clamp to the plane only in a pad's first lane (j = 0: 0 0 1 2) and last lane (j + 2 = cw: j-1 j j+1 j+1):
+      // fetch the four columns from `start` and let the byte permute that de-interleaves NV12 duplicate the edge column
+      const int start = metal::iclamp (j - 1, 0, cw - 4);
+      const uint32_t selu = j < 1 ? 0x04020000u : (j + 2 >= cw ? 0x06060402u : 0x06040200u), selv = selu + 0x01010101u;
+      const uint32_t selp = j < 1 ? 0x02010000u : (j + 2 >= cw ? 0x03030201u : 0x03020100u);
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
-          const int row = metal::iclamp (m - 1 + r, 0, chh - 1);
-#pragma unroll
-          for (int c = 0; c < 4; c++) {
-            const int col = metal::iclamp (j - 1 + c, 0, cw - 1);
-            if (im.fmt == VFHIP_FORMAT_NV12) {
-              const uint32_t uv = *reinterpret_cast<const u16_any *> (im.p[1] + (size_t) row * im.s[1] + 2 * col);
-              cu[r][c] = metal::un8 (uv & 0xffu); cv[r][c] = metal::un8 (uv >> 8);
-            } else {
-              cu[r][c] = metal::un8 (im.p[1][(size_t) row * im.s[1] + col]); cv[r][c] = metal::un8 (im.p[2][(size_t) row * im.s[2] + col]);
-            }
-          }
+      for (int r = 0; r < COMP_ROWS; r++) {
+        const size_t row = (size_t) metal::iclamp (m - 1 + r, 0, chh - 1);
+        if (nv12) {
+          const uint2 v = *reinterpret_cast<const u64_any *> (im.p[1] + row * im.s[1] + 2 * start);
+          Ud[r] = __builtin_amdgcn_perm (v.y, v.x, selu); Vd[r] = __builtin_amdgcn_perm (v.y, v.x, selv);
+        } else {
+          Ud[r] = __builtin_amdgcn_perm (0u, *reinterpret_cast<const u32_any *> (im.p[1] + row * im.s[1] + start), selp);
+          Vd[r] = __builtin_amdgcn_perm (0u, *reinterpret_cast<const u32_any *> (im.p[2] + row * im.s[2] + start), selp);
         }
+      }
+      float hu0[4], hv0[4];
+#pragma unroll
+      for (int r = 0; r < COMP_ROWS; r++) {
+        float cu[4], cv[4], hu[4], hv[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) { cu[c] = metal::un8 ((Ud[r] >> (8 * c)) & 0xffu); cv[c] = metal::un8 ((Vd[r] >> (8 * c)) & 0xffu); }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
           // pixel px + i samples chroma at 0.5 (px + i) - 0.25: weight .75 for even i, .25 for odd i
-          const int a = (i + 1) >> 1;                        // index of the first tap in cu[][0..3]: i = 0 -> 0, 1 -> 1, 2 -> 1, 3 -> 2
+          const int a = (i + 1) >> 1;                        // index of the first tap in cu[0..3]: i = 0 -> 0, 1 -> 1, 2 -> 1, 3 -> 2
           const float fx = (i & 1) ? 0.25f : 0.75f;
-          float hu[3], hv[3];
+          hu[i] = metal::lerp2 (cu[a], cu[a + 1], fx); hv[i] = metal::lerp2 (cv[a], cv[a + 1], fx);
+        }
+        // chroma rows (m - 2 + r, m - 1 + r) -> pixel rows: r = 1 -> row 0 (.75); r = 2 -> rows 1 (.25) and 2 (.75); r = 3 -> row 3 (.25)
 #pragma unroll
-          for (int r = 0; r < 3; r++) { hu[r] = metal::lerp2 (cu[r][a], cu[r][a + 1], fx); hv[r] = metal::lerp2 (cv[r][a], cv[r][a + 1], fx); }
+        for (int k = 0; k < 2; k++) {
+          const int row = 2 * r - 2 - k;                     // r = 1: 0, (-1); r = 2: 2, 1; r = 3: (4), 3
+          if (r == 0 || row < 0 || row >= COMP_ROWS) continue;
+          const float fy = (row & 1) ? 0.25f : 0.75f;
 #pragma unroll
-          for (int r = 0; r < 2; r++) {
-            const float fy = r ? 0.25f : 0.75f;
-            const float cb = metal::lerp2 (hu[r], hu[r + 1], fy), cr = metal::lerp2 (hv[r], hv[r + 1], fy);
-            const F4 c = metal::yuv_to_rgb (metal::un8 ((Y[r] >> (8 * i)) & 0xffu), cb, cr, im.m709);
-            qa[r][i] = comp_blend (L, c, qa[r][i], flat, bgc);
+          for (int i = 0; i < 4; i++) {
+            const float cb = metal::lerp2 (hu0[i], hu[i], fy), cr = metal::lerp2 (hv0[i], hv[i], fy);
+            const F4 c = comp_order (metal::yuv_to_rgb (metal::un8 ((Y[row] >> (8 * i)) & 0xffu), cb, cr, im.m709), bgra_out);
+            q[row][i] = comp_blend (L, c, q[row][i], flat, bgc);
           }
         }
-      } else {
-        // lane blocks cut by the pad's edge, 4:2:0 pads off the chroma grid: exact-texel fetch pixel by pixel (ONE rolled instance)
+#pragma unroll
+        for (int i = 0; i < 4; i++) { hu0[i] = hu[i]; hv0[i] = hv[i]; }
+      }
+      continue;
+    }
+    // lane blocks cut by the pad's edge, 4:2:0 pads off the chroma grid: exact-texel fetch pixel by pixel (ONE rolled instance;
+    // the register-indexed selects keep q in registers)
 #pragma unroll 1
-        for (int i = 0; i < 8; i++) {
-          const int c = i & 3, r = i >> 2;
-          const bool cxi = c == 0 ? cx[0] : (c == 1 ? cx[1] : (c == 2 ? cx[2] : cx[3]));
-          if (!(cxi && (r ? cy1 : cy0))) continue;
-          const int xi = c == 0 ? xs[0] : (c == 1 ? xs[1] : (c == 2 ? xs[2] : xs[3]));
-          uint32_t cur = 0;
+    for (int i = 0; i < 4 * COMP_ROWS; i++) {
+      const int c = i & 3, r = i >> 2;
+      const bool cxi = c == 0 ? cx[0] : (c == 1 ? cx[1] : (c == 2 ? cx[2] : cx[3]));
+      const bool cyi = r == 0 ? cy[0] : (r == 1 ? cy[1] : (r == 2 ? cy[2] : cy[3]));
+      if (!(cxi && cyi)) continue;
+      const int xi = c == 0 ? xs[0] : (c == 1 ? xs[1] : (c == 2 ? xs[2] : xs[3]));
+      const int yi = r == 0 ? ys[0] : (r == 1 ? ys[1] : (r == 2 ? ys[2] : ys[3]));
+      uint32_t cur = 0;
 #pragma unroll
-          for (int j = 0; j < 8; j++) cur = i == j ? qa[j >> 2][j & 3] : cur;
-          const uint32_t v = comp_blend (L, metal::fetch_1to1 (im, xi - L.xpos, (r ? y1 : y0) - L.ypos, true), cur, flat, bgc);
+      for (int j = 0; j < 4 * COMP_ROWS; j++) cur = i == j ? q[j >> 2][j & 3] : cur;
+      const uint32_t v = comp_blend (L, comp_order (metal::fetch_1to1 (im, xi - L.xpos, yi - L.ypos, true), bgra_out), cur, flat, bgc);
 #pragma unroll
-          for (int j = 0; j < 8; j++) qa[j >> 2][j & 3] = i == j ? v : qa[j >> 2][j & 3];
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        q[0][i] = pr ? q[0][i] : qa[0][i]; q[1][i] = pr ? q[1][i] : qa[1][i];
-        q[2][i] = pr ? qa[0][i] : q[2][i]; q[3][i] = pr ? qa[1][i] : q[3][i];
-      }
-      (void) r0;
+      for (int j = 0; j < 4 * COMP_ROWS; j++) q[j >> 2][j & 3] = i == j ? v : q[j >> 2][j & 3];
     }
   }
   if (!live) return;
@@ -411,21 +427,21 @@ __global__ __launch_bounds__ (256) void k_compositor_unscaled (const CompParams 
         if (4 * bx + dx < p.out.w && COMP_ROWS * by + dy < p.out.h) p.scratch[(size_t) (COMP_ROWS * by + dy) * p.scratch_stride + 4 * bx + dx] = q[dy][dx];
     return;
   }
-  const metal::OutImg o = metal::out_at (p.out, z * p.out_pitch);
   if ((o.fmt == VFHIP_FORMAT_BGRA || o.fmt == VFHIP_FORMAT_RGBA) && 4 * bx + 3 < o.w && !(((uintptr_t) o.p[0] | (uintptr_t) o.s[0]) & 15)) {
     typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
 #pragma unroll
     for (int dy = 0; dy < COMP_ROWS; dy++) {
       if (COMP_ROWS * by + dy >= o.h) break;
-      v4u v = { q[dy][0], q[dy][1], q[dy][2], q[dy][3] };
-      if (o.fmt == VFHIP_FORMAT_BGRA) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) v[i] = __builtin_amdgcn_perm (0u, v[i], 0x03000102u);     // swap bytes 0 and 2
-      }
+      const v4u v = { q[dy][0], q[dy][1], q[dy][2], q[dy][3] };                              // target order: stored as it is
       __builtin_nontemporal_store (v, reinterpret_cast<v4u *> (o.p[0] + (size_t) (COMP_ROWS * by + dy) * o.s[0]) + bx);
     }
     return;
   }
+  // store_block takes logical RGBA (an unaligned or odd-width BGRA output comes this way too)
+#pragma unroll
+  for (int dy = 0; dy < COMP_ROWS; dy++)
+#pragma unroll
+    for (int dx = 0; dx < 4; dx++) q[dy][dx] = comp_swap_rb (q[dy][dx], bgra_out);
 #pragma unroll
   for (int pr = 0; pr < COMP_PAIRS; pr++) {
     if (2 * (COMP_PAIRS * by + pr) >= o.h) break;
@@ -435,6 +451,103 @@ __global__ __launch_bounds__ (256) void k_compositor_unscaled (const CompParams 
       const uint32_t qb[2][2] = { { q[2 * pr][2], q[2 * pr][3] }, { q[2 * pr + 1][2], q[2 * pr + 1][3] } };
       metal::store_block (o, 2 * bx + 1, COMP_PAIRS * by + pr, qb);
     }
+  }
+}
+
+
+// k_compositor_quads: the lean kernel — the target's start value (a background, or what an RGBA / BGRA output already holds) and up
+// to sixteen pads drawn at their own size from RGBA / BGRA frames, into an RGBA / BGRA output whose rows are 16-byte aligned
+// (the host checks all of this: comp_quads_ok).  One lane = a 4 x 4 pixel block, as in k_compositor_unscaled, but with neither
+// the 4:2:0 sampler nor the scaling sampler in the kernel it needs 61 VGPRs instead of 117-126: 8 waves per SIMD instead of 4,
+// and a frame of four 1080p quadrants went from 16.2 to 12.4 us (profiles/r02k_c4_occupancy.txt) — the kernel is a latency-bound
+// streaming copy with a blend in the middle, so the bytes in flight per CU are what sets its rate.  Pads of other kinds are drawn
+// by the other two kernels as separate launches over their own rectangle (comp_launch), the way the reference draws one quad
+// per pad into its render target.
+__global__ __launch_bounds__ (256) void k_compositor_quads (const CompParams p)
+{
+  typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
+  const int bx = p.bx0 + blockIdx.x * 64 + threadIdx.x;                                       // 4-pixel column group
+  const int by = __builtin_amdgcn_readfirstlane ((int) (p.by0 + blockIdx.y * 4 + threadIdx.y));      // one row of lanes = one wave
+  const int x0 = 4 * bx, y0 = COMP_ROWS * by;
+  if (y0 >= p.out.h) return;
+  const bool live = x0 < p.out.w;                                                             // out.w is a multiple of 4
+  const unsigned z = blockIdx.z;
+  const metal::OutImg o = metal::out_at (p.out, z * p.out_pitch);
+  const bool bgra_out = o.fmt == VFHIP_FORMAT_BGRA;
+  const int xl = live ? x0 : p.out.w - 4;                                                     // lanes right of the frame shadow its last block
+  bool rowok[COMP_ROWS];
+#pragma unroll
+  for (int r = 0; r < COMP_ROWS; r++) rowok[r] = y0 + r < p.out.h;                            // wave-uniform
+  uint32_t q[COMP_ROWS][4];
+  if (p.background == COMP_BG_IN_PLACE) {
+#pragma unroll
+    for (int r = 0; r < COMP_ROWS; r++) {
+      v4u v = { 0u, 0u, 0u, 0u };
+      if (rowok[r]) v = *reinterpret_cast<const v4u *> (o.p[0] + (size_t) (y0 + r) * o.s[0] + 4 * xl);
+#pragma unroll
+      for (int i = 0; i < 4; i++) q[r][i] = v[i];                    // TARGET ORDER: as stored
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < COMP_ROWS; r++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) q[r][i] = comp_background (p, o, xl + i, y0 + r);
+  }
+  const int wx0 = 4 * (p.bx0 + (int) blockIdx.x * 64), wx1 = wx0 + 256, wy1 = y0 + COMP_ROWS;
+  uint32_t hit = 0;                                           // all sixteen rectangle tests up front: independent scalar loads
+#pragma unroll
+  for (int k = 0; k < COMP_MAX_LAYERS; k++) {
+    const CompLayer &L = p.layer[k];
+    const bool miss = k >= p.n || wx1 <= L.xpos || wx0 >= L.xpos + L.width || wy1 <= L.ypos || y0 >= L.ypos + L.height;
+    hit |= miss ? 0u : 1u << k;
+  }
+  hit = (uint32_t) __builtin_amdgcn_readfirstlane ((int) hit);
+  bool flat = p.background == VFHIP_BG_BLACK || p.background == VFHIP_BG_WHITE || p.background == VFHIP_BG_TRANSPARENT;
+  F4 bgc;
+  bgc.r = bgc.g = bgc.b = p.background == VFHIP_BG_WHITE ? 1.0f : 0.0f; bgc.a = p.background == VFHIP_BG_TRANSPARENT ? 0.0f : 1.0f;
+  for (; hit; flat = false) {
+    const int k = __builtin_ctz (hit);
+    hit &= hit - 1;
+    const CompLayer &L = p.layer[k];
+    const uint8_t *base = L.img.p[0] + z * L.pitch;
+    const bool rgba_in = (L.img.fmt == VFHIP_FORMAT_RGBA) != bgra_out;        // the pad's texels are in target order
+    const int sx = xl - L.xpos, sy = y0 - L.ypos;                  // the lane block's origin in pad coordinates
+    if (sx + 3 < 0 || sx >= L.width) continue;                     // (per lane) no column of the block inside the pad
+    bool cy[COMP_ROWS];
+#pragma unroll
+    for (int r = 0; r < COMP_ROWS; r++) cy[r] = rowok[r] && sy + r >= 0 && sy + r < L.height;       // wave-uniform
+    v4u t[COMP_ROWS];
+    const bool full = sx >= 0 && sx + 3 < L.width;
+    if (full) {
+#pragma unroll
+      for (int r = 0; r < COMP_ROWS; r++)                           // every row's load first, then the blends
+        if (cy[r]) t[r] = *reinterpret_cast<const v4u __attribute__ ((aligned (4))) *> (base + (size_t) (sy + r) * L.img.s[0] + 4 * sx);
+    } else {
+      // the lanes a pad's left / right edge cuts: texel by texel, columns clamped into the pad (the uncovered ones are not drawn)
+#pragma unroll
+      for (int r = 0; r < COMP_ROWS; r++)
+        if (cy[r]) {
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            t[r][i] = *reinterpret_cast<const uint32_t *> (base + (size_t) (sy + r) * L.img.s[0] + 4 * metal::iclamp (sx + i, 0, L.width - 1));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < COMP_ROWS; r++) {
+      if (!cy[r]) continue;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const uint32_t v = comp_blend (L, comp_texel (t[r][i], rgba_in), q[r][i], flat, bgc);
+        q[r][i] = (full || (sx + i >= 0 && sx + i < L.width)) ? v : q[r][i];
+      }
+    }
+  }
+  if (!live) return;
+#pragma unroll
+  for (int r = 0; r < COMP_ROWS; r++) {
+    if (!rowok[r]) break;
+    const v4u v = { q[r][0], q[r][1], q[r][2], q[r][3] };
+    __builtin_nontemporal_store (v, reinterpret_cast<v4u *> (o.p[0] + (size_t) (y0 + r) * o.s[0]) + bx);
   }
 }
 
@@ -450,14 +563,89 @@ struct VfHipCompositor {
   Flights fl;                                    // _submit / _wait: flight k owns staging slots k * COMP_FLIGHT_SLOTS ...
 };
 
+static bool comp_pad_visible (const VfHipPadInput &in) { return in.width > 0 && in.height > 0; }
+static bool comp_pad_unscaled (const VfHipPadInput &in) { return in.width == in.frame.info.width && in.height == in.frame.info.height; }
+// a pad k_compositor_quads can draw
+static bool comp_pad_lean (const VfHipPadInput &in)
+{
+  return comp_pad_unscaled (in) && (in.frame.info.format == VFHIP_FORMAT_RGBA || in.frame.info.format == VFHIP_FORMAT_BGRA) &&
+      !(((uintptr_t) in.frame.data[0] | (uintptr_t) in.frame.stride[0]) & 3);
+}
+
+static void comp_fill_layer (CompLayer &L, const VfHipPadInput &in, size_t pitch)
+{
+  L.img = metal::make_img (&in.frame);
+  L.xpos = in.xpos; L.ypos = in.ypos; L.width = in.width; L.height = in.height;
+  L.alpha = (float) in.alpha; L.blend = in.blend_mode;
+  L.pitch = pitch;
+}
+
+// RGBA / BGRA output with 16-byte rows: the output itself is the render target, and the pads are drawn in RUNS — consecutive pads
+// of one kind (`lean`: what k_compositor_quads draws; the rest: the samplers of k_compositor_unscaled / k_compositor), at most
+// COMP_MAX_LAYERS each.  The first run's launch covers the frame and starts from the background; every later run is a launch over
+// the bounding rectangle of its pads that starts from what the output holds (COMP_BG_IN_PLACE) — one draw per run where the
+// reference has one draw per pad (metalcomprenderer.m:356-542), the same 8-bit target between them.  A lane reads and writes only
+// its own pixels, so drawing in place needs no second buffer.
+static int comp_launch_runs (VfHipCompositor *h, const VfHipPadInput *pads, int count, int background, VfHipFrame *out, hipStream_t s,
+    int n_frames, const size_t *pad_pitch, size_t out_pitch)
+{
+  const int w = h->out.width, hh = h->out.height;
+  const bool force_general = getenv ("VFHIP_COMP_GENERAL") != nullptr;       // test knobs: one kernel for every run
+  const bool no_lean = force_general || getenv ("VFHIP_COMP_NO_QUADS") != nullptr;
+  int k = 0;
+  bool first = true;
+  while (k < count || first) {
+    while (k < count && !comp_pad_visible (pads[k])) k++;
+    CompParams p {};
+    bool lean = !no_lean, unscaled = true;
+    int rx0 = w, ry0 = hh, rx1 = 0, ry1 = 0;
+    if (k < count) {
+      lean = !no_lean && comp_pad_lean (pads[k]);
+      for (; k < count && p.n < COMP_MAX_LAYERS; k++) {
+        const VfHipPadInput &in = pads[k];
+        if (!comp_pad_visible (in)) continue;
+        if ((!no_lean && comp_pad_lean (in)) != lean) break;
+        unscaled = unscaled && comp_pad_unscaled (in);
+        comp_fill_layer (p.layer[p.n++], in, pad_pitch ? pad_pitch[k] : 0);
+        rx0 = std::min (rx0, in.xpos); ry0 = std::min (ry0, in.ypos);
+        rx1 = std::max (rx1, (int) std::min ((long long) w, (long long) in.xpos + in.width));
+        ry1 = std::max (ry1, (int) std::min ((long long) hh, (long long) in.ypos + in.height));
+      }
+    }
+    if (first) { rx0 = 0; ry0 = 0; rx1 = w; ry1 = hh; }
+    rx0 = std::max (rx0, 0); ry0 = std::max (ry0, 0);
+    const bool draw = first || (p.n > 0 && rx0 < rx1 && ry0 < ry1);
+    p.background = first ? background : COMP_BG_IN_PLACE;
+    first = false;
+    if (!draw) continue;
+    unscaled = unscaled && !force_general;
+    const int rows = (lean || unscaled) ? COMP_ROWS : 2;
+    // whole 64-lane groups from a 256-pixel boundary keep the 16-byte lanes of a wave on one 1 KiB-aligned run of a row
+    p.bx0 = (rx0 / 256) * 64; p.by0 = ry0 / rows;
+    const int bx1 = (rx1 + 3) / 4, by1 = (ry1 + rows - 1) / rows;
+    dim3 grid ((unsigned) ((bx1 - p.bx0 + 63) / 64), (unsigned) ((by1 - p.by0 + 3) / 4), (unsigned) n_frames);
+    p.out = metal::make_out (out); p.out_pitch = out_pitch;
+    if (lean) hipLaunchKernelGGL (k_compositor_quads, grid, dim3 (64, 4), 0, s, p);
+    else if (unscaled) hipLaunchKernelGGL (k_compositor_unscaled, grid, dim3 (64, 4), 0, s, p);
+    else hipLaunchKernelGGL (k_compositor, grid, dim3 (64, 4), 0, s, p);
+    VFHIP_CHECK_HIP (hipGetLastError ());
+  }
+  return VFHIP_OK;
+}
+
 static int comp_launch (VfHipCompositor *h, const VfHipPadInput *pads, int count, int background, VfHipFrame *out, hipStream_t s,
     int n_frames = 1, const size_t *pad_pitch = nullptr, size_t out_pitch = 0)
 {
   const int w = h->out.width, hh = h->out.height;
+  const int ofmt = out->info.format;
+  if ((ofmt == VFHIP_FORMAT_RGBA || ofmt == VFHIP_FORMAT_BGRA) && !(w & 3) &&
+      !(((uintptr_t) out->data[0] | (uintptr_t) out->stride[0] | (uintptr_t) out_pitch) & 15) && !getenv ("VFHIP_COMP_ONE_PASS"))
+    return comp_launch_runs (h, pads, count, background, out, s, n_frames, pad_pitch, out_pitch);
+  // planar / odd-sized outputs: one launch walks all the pads (up to COMP_MAX_LAYERS; more chain through an RGBA8 scratch target)
   // every pad at its own size -> k_compositor_unscaled (4 x 4 pixel blocks per lane); otherwise the general kernel (4 x 2)
   bool unscaled = getenv ("VFHIP_COMP_GENERAL") == nullptr;       // test knob: force the general kernel
   for (int k = 0; k < count && unscaled; k++)
-    if (pads[k].width > 0 && pads[k].height > 0 && (pads[k].width != pads[k].frame.info.width || pads[k].height != pads[k].frame.info.height)) unscaled = false;
+    if (comp_pad_visible (pads[k]) && !comp_pad_unscaled (pads[k])) unscaled = false;
   const int rows = unscaled ? COMP_ROWS : 2;
   const int bw = (w + 3) / 4, bh = (hh + rows - 1) / rows;
   dim3 grid ((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4), (unsigned) n_frames);
@@ -469,15 +657,8 @@ static int comp_launch (VfHipCompositor *h, const VfHipPadInput *pads, int count
     CompParams p {};
     const int first = pass * COMP_MAX_LAYERS, n = count - first < COMP_MAX_LAYERS ? count - first : COMP_MAX_LAYERS;
     p.n = 0;
-    for (int k = 0; k < n; k++) {
-      const VfHipPadInput &in = pads[first + k];
-      if (in.width <= 0 || in.height <= 0) continue;
-      CompLayer &L = p.layer[p.n++];
-      L.img = metal::make_img (&in.frame);
-      L.xpos = in.xpos; L.ypos = in.ypos; L.width = in.width; L.height = in.height;
-      L.alpha = (float) in.alpha; L.blend = in.blend_mode;
-      L.pitch = pad_pitch ? pad_pitch[first + k] : 0;
-    }
+    for (int k = 0; k < n; k++)
+      if (comp_pad_visible (pads[first + k])) comp_fill_layer (p.layer[p.n++], pads[first + k], pad_pitch ? pad_pitch[first + k] : 0);
     p.background = pass == 0 ? background : -1;
     p.prev = pass == 0 ? nullptr : h->scratch[(pass - 1) & 1]; p.prev_stride = w;
     p.out = metal::make_out (out); p.out_pitch = out_pitch;
