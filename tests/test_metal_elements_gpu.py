@@ -565,3 +565,82 @@ def test_overlay_png_file_and_batch(vfhip, metalref, tmp_path):
     ov.load_image("")                                       # empty path clears, like the reference
     assert ov.image_size is None
     ov.close()
+
+
+def _mixed_pads(w, h, n, seed):
+    """pads of every kind in random z-order: unscaled RGBA / BGRA at any position (the lean kernel's), unscaled NV12 / I420 on and off
+    the chroma grid, scaled ones; some partly or wholly outside the frame"""
+    rng = np.random.default_rng(seed)
+    pads = []
+    for k in range(n):
+        fmt = ["BGRA", "RGBA", "BGRA", "NV12", "I420"][int(rng.integers(0, 5))]
+        pw, ph = int(rng.integers(3, 150)), int(rng.integers(3, 90))
+        if fmt in ("NV12", "I420") and rng.integers(0, 2):
+            pw, ph = pw & ~1 | 8, ph & ~1 | 8
+        raw = smooth(fmt, pw, ph, 1000 * seed + k)
+        if fmt in ("BGRA", "RGBA"):
+            raw.reshape(-1, 4)[:, 3] = rng.integers(0, 256, pw * ph)
+        scaled = rng.integers(0, 4) == 0
+        dw, dh = (int(rng.integers(4, 200)), int(rng.integers(4, 120))) if scaled else (pw, ph)
+        x, y = int(rng.integers(-40, w)), int(rng.integers(-30, h))
+        if not scaled and rng.integers(0, 2):
+            x, y = x & ~3, y & ~3                               # half of the unscaled pads on the lane grid
+        pads.append((fmt, pw, ph, raw, x, y, dw, dh, float(rng.uniform(0.2, 1.0)), int(rng.integers(0, 3)), bool(rng.integers(0, 2))))
+    return pads
+
+
+@pytest.mark.parametrize("ofmt", ["BGRA", "RGBA"])
+@pytest.mark.parametrize("bg", ["checker", "transparent"])
+def test_compositor_runs_of_pads(vfhip, metalref, ofmt, bg, monkeypatch):
+    """RGBA / BGRA outputs are drawn in runs (comp_launch_runs): a launch per run of like pads, later runs in place over their
+    bounding rectangle.  45 mixed pads on a frame wider than one wave: against the oracle, and bit for bit against the one-kernel
+    path (VFHIP_COMP_ONE_PASS) and against the runs with the lean kernel switched off."""
+    w, h = 600, 200
+    pads = _mixed_pads(w, h, 45, 7)
+    comp = vfhip.Compositor(0)
+    comp.configure(ofmt, w, h)
+    got = comp.composite(to_vf(vfhip, pads), background=bg)
+    close(got, metalref.compositor(ofmt, w, h, pads, vfhip.BACKGROUNDS[bg]), f"runs {ofmt} {bg}", max_off_by_one=0.05)
+    monkeypatch.setenv("VFHIP_COMP_ONE_PASS", "1")
+    one = comp.composite(to_vf(vfhip, pads), background=bg)
+    monkeypatch.delenv("VFHIP_COMP_ONE_PASS")
+    assert np.array_equal(got, one), "runs differ from the single-kernel path"
+    monkeypatch.setenv("VFHIP_COMP_NO_QUADS", "1")
+    noq = comp.composite(to_vf(vfhip, pads), background=bg)
+    monkeypatch.delenv("VFHIP_COMP_NO_QUADS")
+    assert np.array_equal(got, noq), "lean kernel differs from the samplers' exact-texel path"
+    monkeypatch.setenv("VFHIP_COMP_GENERAL", "1")
+    gen = comp.composite(to_vf(vfhip, pads), background=bg)
+    monkeypatch.delenv("VFHIP_COMP_GENERAL")
+    assert np.array_equal(got, gen), "general kernel differs"
+    comp.close()
+
+
+def test_compositor_runs_batch(vfhip, metalref):
+    """a batch through the runs: lean run over the frame, NV12 run in place over its rectangle, lean run on top"""
+    import torch
+    ow, oh, n = 520, 96, 3
+    a = [smooth("BGRA", 300, 96, 170 + k) for k in range(n)]
+    b = [smooth("NV12", 64, 48, 180 + k) for k in range(n)]
+    c = [smooth("RGBA", 37, 21, 190 + k) for k in range(n)]
+    for f in a + c:
+        f.reshape(-1, 4)[:, 3] = np.random.default_rng(5).integers(0, 256, f.size // 4)
+    pa, pb, pc = ((x[0].size + 255) // 256 * 256 for x in (a, b, c))
+    da, db, dc = _ring(a, pa), _ring(b, pb), _ring(c, pc)
+    dout = torch.zeros((n, ow * oh * 4), dtype=torch.uint8, device="cuda")
+    comp = vfhip.Compositor(0)
+    comp.configure("RGBA", ow, oh)
+    pads = [comp.pad("BGRA", 300, 96, da.data_ptr(), 0, 0, 300, 96, 0.9, "over"),
+            comp.pad("BGRA", 300, 96, da.data_ptr(), 260, 0, 300, 96, 0.5, "add"),
+            comp.pad("NV12", 64, 48, db.data_ptr(), 276, 20, 64, 48, 0.7, "over"),
+            comp.pad("RGBA", 37, 21, dc.data_ptr(), 301, 33, 37, 21, 1.0, "over")]
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    comp.composite_device(pads, dout.data_ptr(), background="white", stream=s.cuda_stream, n_frames=n, pad_pitches=[pa, pa, pb, pc], out_pitch=ow * oh * 4)
+    s.synchronize()
+    out = dout.cpu().numpy()
+    for k in range(n):
+        want = metalref.compositor("RGBA", ow, oh, [("BGRA", 300, 96, a[k], 0, 0, 300, 96, 0.9, 1), ("BGRA", 300, 96, a[k], 260, 0, 300, 96, 0.5, 2),
+                                                    ("NV12", 64, 48, b[k], 276, 20, 64, 48, 0.7, 1), ("RGBA", 37, 21, c[k], 301, 33, 37, 21, 1.0, 1)], 2)
+        close(out[k], want, f"runs batch frame {k}")
+    comp.close()
