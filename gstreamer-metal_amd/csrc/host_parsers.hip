@@ -4,9 +4,11 @@
 //
 // The reference decodes overlay images and PNG LUTs with CoreGraphics / ImageIO (overlay/metaloverlayrenderer.m:166-245,
 // videofilter/metalvideofilterrenderer.m:166-305), which do not exist here — SURVEY.md §8f item 4 lists "a PNG decoder"
-// as the dependency of both.  Supported: non-interlaced PNG, bit depths 8 and 16 (high byte), colour types grey, RGB,
-// palette (+ tRNS), grey+alpha, RGBA; all five scan-line filters.  Output: straight (non-premultiplied) RGBA8, row 0 first.
-// Anything else (interlaced, depths 1/2/4, broken CRC-less streams that fail to inflate) is an error, never a guess.
+// as the dependency of both.  Supported: every colour type at every bit depth the PNG specification allows (grey 1/2/4/8/16,
+// RGB 8/16, palette 1/2/4/8, grey+alpha and RGBA 8/16; 16-bit samples keep their high byte, 1/2/4-bit grey scales to 0..255),
+// tRNS in all three forms (palette alpha, grey key, RGB key), Adam7 interlacing, all five scan-line filters, IDAT split
+// anywhere.  Output: straight (non-premultiplied) RGBA8, row 0 first.  Ancillary chunks (gAMA, sRGB, iCCP, ...) are ignored:
+// sample values are taken as they are.  A stream that does not inflate to exactly the announced image is an error, never a guess.
 #include "vfhip_host.h"
 #include <zlib.h>
 #include <cctype>
@@ -56,64 +58,116 @@ static int decode_png_impl (const char *path, std::vector<uint8_t> &rgba, int *w
   }
   if (w <= 0 || h <= 0 || w > 16384 || h > 16384 || (size_t) w * (size_t) h > ((size_t) 64 << 20))
     return set_error (VFHIP_ERR_INVALID, "%s: bad PNG size %dx%d (at most 16384 per side, 64 Mpixel)", path, w, h);
-  if (interlace) return set_error (VFHIP_ERR_UNSUPPORTED, "%s: interlaced PNGs are not supported", path);
-  if (depth != 8 && depth != 16) return set_error (VFHIP_ERR_UNSUPPORTED, "%s: PNG bit depth %d is not supported (8 or 16)", path, depth);
+  if (interlace > 1) return set_error (VFHIP_ERR_UNSUPPORTED, "%s: PNG interlace method %d", path, interlace);
   int channels;
+  bool depth_ok;
   switch (ctype) {
-    case 0: channels = 1; break;
-    case 2: channels = 3; break;
-    case 3: channels = 1; if (depth != 8) return set_error (VFHIP_ERR_UNSUPPORTED, "%s: palette PNG must be 8-bit", path); break;
-    case 4: channels = 2; break;
-    case 6: channels = 4; break;
+    case 0: channels = 1; depth_ok = depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16; break;
+    case 2: channels = 3; depth_ok = depth == 8 || depth == 16; break;
+    case 3: channels = 1; depth_ok = depth == 1 || depth == 2 || depth == 4 || depth == 8; break;
+    case 4: channels = 2; depth_ok = depth == 8 || depth == 16; break;
+    case 6: channels = 4; depth_ok = depth == 8 || depth == 16; break;
     default: return set_error (VFHIP_ERR_UNSUPPORTED, "%s: PNG colour type %d", path, ctype);
   }
-  const size_t bpp = (size_t) channels * depth / 8, stride = (size_t) w * bpp;
-  std::vector<uint8_t> raw ((stride + 1) * (size_t) h);
+  if (!depth_ok) return set_error (VFHIP_ERR_UNSUPPORTED, "%s: PNG bit depth %d is not valid for colour type %d", path, depth, ctype);
+  // the sub-images of the stream: one, or Adam7's seven (x0, y0, dx, dy); empty passes carry no bytes
+  struct Pass { int x0, y0, dx, dy, pw, ph; size_t stride; };
+  static const int adam7[7][4] = { { 0, 0, 8, 8 }, { 4, 0, 8, 8 }, { 0, 4, 4, 8 }, { 2, 0, 4, 4 }, { 0, 2, 2, 4 }, { 1, 0, 2, 2 }, { 0, 1, 1, 2 } };
+  Pass pass[7];
+  int n_pass = 0;
+  const size_t bits = (size_t) channels * depth;
+  size_t total = 0;
+  for (int k = 0; k < (interlace ? 7 : 1); k++) {
+    Pass q;
+    if (interlace) { q.x0 = adam7[k][0]; q.y0 = adam7[k][1]; q.dx = adam7[k][2]; q.dy = adam7[k][3]; }
+    else { q.x0 = q.y0 = 0; q.dx = q.dy = 1; }
+    q.pw = (w - q.x0 + q.dx - 1) / q.dx; q.ph = (h - q.y0 + q.dy - 1) / q.dy;
+    if (q.pw <= 0 || q.ph <= 0) continue;
+    q.stride = ((size_t) q.pw * bits + 7) / 8;
+    total += (q.stride + 1) * (size_t) q.ph;
+    pass[n_pass++] = q;
+  }
+  const size_t bpp = bits >= 8 ? bits / 8 : 1;        // the filters' "corresponding byte" distance
+  std::vector<uint8_t> raw (total);
   uLongf out_len = (uLongf) raw.size ();
   if (idat.empty () || uncompress (raw.data (), &out_len, idat.data (), (uLong) idat.size ()) != Z_OK || out_len != raw.size ())
     return set_error (VFHIP_ERR_INVALID, "%s: PNG image data does not inflate to %dx%d", path, w, h);
-  // undo the scan-line filters in place
-  std::vector<uint8_t> zero (stride, 0);
-  for (int y = 0; y < h; y++) {
-    uint8_t *row = &raw[(stride + 1) * (size_t) y];
-    const int ft = row[0];
-    uint8_t *cur = row + 1;
-    const uint8_t *up = y ? &raw[(stride + 1) * (size_t) (y - 1) + 1] : zero.data ();
-    for (size_t i = 0; i < stride; i++) {
-      const int a = i >= bpp ? cur[i - bpp] : 0, b = up[i], c = i >= bpp ? up[i - bpp] : 0;
-      int v = cur[i];
-      switch (ft) {
-        case 0: break;
-        case 1: v += a; break;
-        case 2: v += b; break;
-        case 3: v += (a + b) >> 1; break;
-        case 4: v += paeth (a, b, c); break;
-        default: return set_error (VFHIP_ERR_INVALID, "%s: bad PNG filter type %d", path, ft);
-      }
-      cur[i] = (uint8_t) v;
-    }
-  }
+  if (ctype == 3 && plte.size () < 3) return set_error (VFHIP_ERR_INVALID, "%s: palette PNG without a PLTE chunk", path);
+  // tRNS of the grey / truecolour types: ONE colour (16-bit big-endian per sample, compared at the file's depth) is transparent
+  const bool key_grey = ctype == 0 && trns.size () >= 2, key_rgb = ctype == 2 && trns.size () >= 6;
+  unsigned key[3] = { 0, 0, 0 };
+  for (int k = 0; k < (key_rgb ? 3 : (key_grey ? 1 : 0)); k++) key[k] = ((unsigned) trns[2 * k] << 8) | trns[2 * k + 1];
   rgba.assign ((size_t) w * h * 4, 255);
-  const int step = depth / 8;                       // 16-bit samples: the high byte
-  for (int y = 0; y < h; y++) {
-    const uint8_t *s = &raw[(stride + 1) * (size_t) y + 1];
-    uint8_t *d = &rgba[(size_t) y * w * 4];
-    for (int x = 0; x < w; x++, d += 4) {
-      const uint8_t *p = s + (size_t) x * bpp;
-      switch (ctype) {
-        case 0: d[0] = d[1] = d[2] = p[0]; break;
-        case 2: d[0] = p[0]; d[1] = p[step]; d[2] = p[2 * step]; break;
-        case 3: {
-          const size_t k = p[0];
-          if (3 * k + 2 >= plte.size ()) return set_error (VFHIP_ERR_INVALID, "%s: palette index out of range", path);
-          d[0] = plte[3 * k]; d[1] = plte[3 * k + 1]; d[2] = plte[3 * k + 2];
-          if (k < trns.size ()) d[3] = trns[k];
-          break;
+  const int step = depth == 16 ? 2 : 1;               // 16-bit samples: the high byte is kept
+  const unsigned grey_scale = depth < 8 ? 255u / ((1u << depth) - 1u) : 1u;     // 1, 2, 4 bit grey -> 8 bit: x255, x85, x17
+  size_t at = 0;
+  for (int k = 0; k < n_pass; k++) {
+    const Pass &q = pass[k];
+    // undo the scan-line filters of this sub-image in place
+    std::vector<uint8_t> zero (q.stride, 0);
+    for (int y = 0; y < q.ph; y++) {
+      uint8_t *row = &raw[at + (q.stride + 1) * (size_t) y];
+      const int ft = row[0];
+      uint8_t *cur = row + 1;
+      const uint8_t *up = y ? row - q.stride : zero.data ();
+      for (size_t i = 0; i < q.stride; i++) {
+        const int a = i >= bpp ? cur[i - bpp] : 0, b = up[i], c = i >= bpp ? up[i - bpp] : 0;
+        int v = cur[i];
+        switch (ft) {
+          case 0: break;
+          case 1: v += a; break;
+          case 2: v += b; break;
+          case 3: v += (a + b) >> 1; break;
+          case 4: v += paeth (a, b, c); break;
+          default: return set_error (VFHIP_ERR_INVALID, "%s: bad PNG filter type %d", path, ft);
         }
-        case 4: d[0] = d[1] = d[2] = p[0]; d[3] = p[step]; break;
-        default: d[0] = p[0]; d[1] = p[step]; d[2] = p[2 * step]; d[3] = p[3 * step]; break;
+        cur[i] = (uint8_t) v;
       }
     }
+    for (int y = 0; y < q.ph; y++) {
+      const uint8_t *s = &raw[at + (q.stride + 1) * (size_t) y + 1];
+      for (int x = 0; x < q.pw; x++) {
+        uint8_t *d = &rgba[((size_t) (q.y0 + y * q.dy) * w + (size_t) (q.x0 + x * q.dx)) * 4];
+        if (depth < 8) {
+          // packed samples, leftmost in the high bits
+          const unsigned v = (s[((size_t) x * depth) >> 3] >> (8 - depth - (((size_t) x * depth) & 7))) & ((1u << depth) - 1u);
+          if (ctype == 3) {
+            if (3 * (size_t) v + 2 >= plte.size ()) return set_error (VFHIP_ERR_INVALID, "%s: palette index out of range", path);
+            d[0] = plte[3 * v]; d[1] = plte[3 * v + 1]; d[2] = plte[3 * v + 2];
+            if (v < trns.size ()) d[3] = trns[v];
+          } else {
+            d[0] = d[1] = d[2] = (uint8_t) (v * grey_scale);
+            if (key_grey && v == key[0]) d[3] = 0;
+          }
+          continue;
+        }
+        const uint8_t *p = s + (size_t) x * bpp;
+        switch (ctype) {
+          case 0:
+            d[0] = d[1] = d[2] = p[0];
+            if (key_grey && (depth == 16 ? (((unsigned) p[0] << 8) | p[1]) : p[0]) == key[0]) d[3] = 0;
+            break;
+          case 2:
+            d[0] = p[0]; d[1] = p[step]; d[2] = p[2 * step];
+            if (key_rgb) {
+              bool hit = true;
+              for (int c = 0; c < 3; c++) hit = hit && (depth == 16 ? (((unsigned) p[2 * c] << 8) | p[2 * c + 1]) : p[c]) == key[c];
+              if (hit) d[3] = 0;
+            }
+            break;
+          case 3: {
+            const size_t v = p[0];
+            if (3 * v + 2 >= plte.size ()) return set_error (VFHIP_ERR_INVALID, "%s: palette index out of range", path);
+            d[0] = plte[3 * v]; d[1] = plte[3 * v + 1]; d[2] = plte[3 * v + 2];
+            if (v < trns.size ()) d[3] = trns[v];
+            break;
+          }
+          case 4: d[0] = d[1] = d[2] = p[0]; d[3] = p[step]; break;
+          default: d[0] = p[0]; d[1] = p[step]; d[2] = p[2 * step]; d[3] = p[3 * step]; break;
+        }
+      }
+    }
+    at += (q.stride + 1) * (size_t) q.ph;
   }
   *width = w; *height = h;
   return VFHIP_OK;

@@ -124,7 +124,7 @@ void vfhip_device_free (int device, void *p);
 int vfhip_memcpy_h2d (int device, void *dst, const void *src, size_t bytes);
 int vfhip_memcpy_d2h (int device, void *dst, const void *src, size_t bytes);
 /* number of planes / plane geometry helpers shared by shells, tests and bench */
-/* PNG decoder used by the overlay image and PNG LUT loaders (host only; non-interlaced, 8 / 16 bit, all colour types):
+/* PNG decoder used by the overlay image and PNG LUT loaders (host only; every colour type and bit depth, Adam7, tRNS; 16-bit samples keep their high byte):
  * straight RGBA8, row 0 first, malloc'ed — release with vfhip_image_free */
 int vfhip_image_decode_png (const char *path, uint8_t **rgba, int *width, int *height);
 void vfhip_image_free (uint8_t *rgba);

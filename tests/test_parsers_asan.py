@@ -57,6 +57,12 @@ def test_png_decoder_under_asan(parsers, tmp_path):
     p = tmp_path / "pal.png"
     png_util.write_png(p, rng.integers(0, 5, (9, 11, 1)), 3, 8, palette=rng.integers(0, 256, (5, 3), dtype=np.uint8), trns=[0, 128, 255])
     files.append(p); good.append(str(p))
+    for k, (ctype, ch, depth, il) in enumerate([(0, 1, 1, 0), (0, 1, 2, 1), (0, 1, 4, 1), (3, 1, 1, 1), (3, 1, 4, 0), (6, 4, 8, 1), (2, 3, 16, 1), (4, 2, 8, 1)]):
+        p = tmp_path / f"ok_low{k}.png"                   # low bit depths and Adam7 (sizes that leave passes empty or one pixel wide)
+        w, h = [(13, 17), (1, 1), (3, 2), (5, 9)][k % 4]
+        png_util.write_png(p, rng.integers(0, min(1 << depth, 256), (h, w, ch)), ctype, depth, filters=[4, 3, 2, 1, 0],
+                           palette=rng.integers(0, 256, (1 << depth, 3), dtype=np.uint8) if ctype == 3 else None, interlace=il)
+        files.append(p); good.append(str(p))
     base = open(good[3], "rb").read()
     for n in list(range(0, 60)) + list(range(60, len(base), 7)):                    # every truncation point of the header, then strided
         q = tmp_path / f"trunc{n}.png"; q.write_bytes(base[:n]); files.append(q)
@@ -65,6 +71,15 @@ def test_png_decoder_under_asan(parsers, tmp_path):
         for _ in range(int(rng.integers(1, 4))):
             b[int(rng.integers(8, len(b)))] = int(rng.integers(0, 256))
         q = tmp_path / f"flip{k}.png"; q.write_bytes(bytes(b)); files.append(q)
+    for j, g in enumerate(good[7:]):                                                 # the same for the packed-sample / Adam7 files
+        gb = open(g, "rb").read()
+        for k in range(40):
+            b = bytearray(gb)
+            for _ in range(int(rng.integers(1, 4))):
+                b[int(rng.integers(8, len(b)))] = int(rng.integers(0, 256))
+            q = tmp_path / f"flip_low{j}_{k}.png"; q.write_bytes(bytes(b)); files.append(q)
+        for n in range(8, len(gb), 5):
+            q = tmp_path / f"trunc_low{j}_{n}.png"; q.write_bytes(gb[:n]); files.append(q)
     sig = b"\x89PNG\r\n\x1a\n"
     adversarial = {
         "huge.png": sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 16384, 16384, 16, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b""),
@@ -76,8 +91,12 @@ def test_png_decoder_under_asan(parsers, tmp_path):
         "badfilter.png": sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 4, 2, 8, 0, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\7abcd\5efgh")) + chunk(b"IEND", b""),
         "palidx.png": sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 4, 1, 8, 3, 0, 0, 0)) + chunk(b"PLTE", b"\1\2\3") + chunk(b"IDAT", zlib.compress(b"\0\0\1\2\xff")) + chunk(b"IEND", b""),
         "nopal.png": sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 4, 1, 8, 3, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\0\0\0\0\0")) + chunk(b"IEND", b""),
-        "interlaced.png": sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 4, 4, 8, 0, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(b"\0" * 40)) + chunk(b"IEND", b""),
-        "depth1.png": sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 8, 8, 1, 0, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\0" * 16)) + chunk(b"IEND", b""),
+        "interlaced_len.png": sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 4, 4, 8, 0, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(b"\0" * 40)) + chunk(b"IEND", b""),   # 7 passes of 4x4 hold 23 bytes
+        "interlace2.png": sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 4, 4, 8, 0, 0, 0, 2)) + chunk(b"IDAT", zlib.compress(b"\0" * 20)) + chunk(b"IEND", b""),
+        "depth1_len.png": sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 9, 8, 1, 0, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\0" * 16)) + chunk(b"IEND", b""),       # 9 pixels need 2 bytes per row
+        "depth3.png": sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 8, 8, 3, 0, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\0" * 32)) + chunk(b"IEND", b""),
+        "rgb_depth4.png": sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 8, 8, 4, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\0" * 104)) + chunk(b"IEND", b""),
+        "pal1_idx.png": sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 8, 1, 1, 3, 0, 0, 0)) + chunk(b"PLTE", b"\1\2\3") + chunk(b"IDAT", zlib.compress(b"\0\x10")) + chunk(b"IEND", b""),   # index 1, one-entry palette
         "empty.png": b"", "sigonly.png": sig,
     }
     for name, data in adversarial.items():
