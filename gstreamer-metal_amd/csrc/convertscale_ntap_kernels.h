@@ -141,7 +141,9 @@ __global__ __launch_bounds__ (THREADS) void k_cs_cubic_tile (const CubicTilePara
   const int ry0 = p.nv ? p.tab_v[(size_t) y0 * p.nv].x : y0, ry1 = p.nv ? p.tab_v[(size_t) (y0 + th - 1) * p.nv + p.nv - 1].x : y0 + th - 1;
   const int rh = ry1 - ry0 + 1;
   int rw = cx1 - cx0 + 1;
-  for (int i = tid; i < tw * p.nh; i += THREADS) lth[i] = p.tab_h[(size_t) x0 * p.nh + i];
+  // horizontal taps tap-major ([l][tx]): the lanes of a wave are consecutive tx, so tap l of 64 columns is 64 consecutive int2 —
+  // column-major ([tx][l], 8 * nh bytes apart) put every lane of a wave on the same four LDS banks
+  for (int i = tid; i < tw * p.nh; i += THREADS) { const int tx = i / p.nh, l = i - tx * p.nh; lth[l * CT_TW + tx] = p.tab_h[(size_t) x0 * p.nh + i]; }
   for (int i = tid; i < th * p.nv; i += THREADS) ltv[i] = p.tab_v[(size_t) y0 * p.nv + i];
   if (p.fast_nv12) {
     // region widened to whole 8-column groups; groups that would cross the right image edge fall back to cs_tap
@@ -185,9 +187,9 @@ __global__ __launch_bounds__ (THREADS) void k_cs_cubic_tile (const CubicTilePara
     } else {                                                           // tmp[ry][tx] = horizontal taps over the region's rows
       for (int i = tid; i < rh * tw; i += THREADS) {
         const int ry = i / tw, tx = i - ry * tw;
-        const int2 *t = lth + tx * p.nh;
+        const int2 *t = lth + tx;
         Acc4 a = { 0.0f, 0.0f, 0.0f, 0.0f };
-        for (int l = 0; l < p.nh; l++) ntap_acc (a, reg[ry][t[l].x - cx0], t[l].y);
+        for (int l = 0; l < p.nh; l++) ntap_acc (a, reg[ry][t[l * CT_TW].x - cx0], t[l * CT_TW].y);
         tmp[ry * CT_TW + tx] = ntap_finish (a);
       }
     }
@@ -199,16 +201,16 @@ __global__ __launch_bounds__ (THREADS) void k_cs_cubic_tile (const CubicTilePara
     uint32_t q;
     if (p.nh && p.nv) {
       if (p.vfirst) {
-        const int2 *t = lth + tx * p.nh;
-        for (int l = 0; l < p.nh; l++) ntap_acc (a, tmp[ty * rw + (t[l].x - cx0)], t[l].y);
+        const int2 *t = lth + tx;
+        for (int l = 0; l < p.nh; l++) ntap_acc (a, tmp[ty * rw + (t[l * CT_TW].x - cx0)], t[l * CT_TW].y);
       } else {
         const int2 *t = ltv + ty * p.nv;
         for (int l = 0; l < p.nv; l++) ntap_acc (a, tmp[(t[l].x - ry0) * CT_TW + tx], t[l].y);
       }
       q = ntap_finish (a);
     } else if (p.nh) {
-      const int2 *t = lth + tx * p.nh;
-      for (int l = 0; l < p.nh; l++) ntap_acc (a, reg[ty][t[l].x - cx0], t[l].y);
+      const int2 *t = lth + tx;
+      for (int l = 0; l < p.nh; l++) ntap_acc (a, reg[ty][t[l * CT_TW].x - cx0], t[l * CT_TW].y);
       q = ntap_finish (a);
     } else if (p.nv) {
       const int2 *t = ltv + ty * p.nv;
