@@ -872,7 +872,10 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
     dim3 grid ((unsigned) ((t.ow + CT_TW - 1) / CT_TW), (unsigned) ((t.oh + CT_TH - 1) / CT_TH), (unsigned) n_frames);
     // 512 lanes share one tile's 48 KB of LDS: 3 workgroups = 24 waves per CU (256 lanes: 12 waves, latency-bound)
     // (measured on C2 bicubic: 256 lanes 25.2 k frames/s, 512 lanes 28.6 k, 1024 lanes 19.6 k)
-    hipLaunchKernelGGL (k_cs_cubic_tile<512>, grid, dim3 (512), 0, s, t);
+    // a source format without alpha converts to A = 255 everywhere: the tile kernel then filters three channels (ntap_accf)
+    const bool opaque = h->in.format != VFHIP_FORMAT_BGRA && h->in.format != VFHIP_FORMAT_RGBA;
+    if (opaque) hipLaunchKernelGGL ((k_cs_cubic_tile<512, true>), grid, dim3 (512), 0, s, t);
+    else hipLaunchKernelGGL ((k_cs_cubic_tile<512, false>), grid, dim3 (512), 0, s, t);
     VFHIP_CHECK_HIP (hipGetLastError ());
     return VFHIP_OK;
   }

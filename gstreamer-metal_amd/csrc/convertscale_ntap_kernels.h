@@ -73,6 +73,25 @@ __global__ __launch_bounds__ (256) void k_ntap_h (const NtapParams p)
   *reinterpret_cast<uint32_t *> (p.out + (size_t) y * p.os + 4 * x) = ntap_finish (a);
 }
 
+// the tile kernel's form: the weight already a float (converted once when the tap table is staged in LDS), and — OPAQUE — no fourth
+// channel: a source without alpha converts to A = 255 in every pixel, the taps of an output sample sum to 64, so the filtered alpha
+// is (255 * 64 + 32) >> 6 = 255 whatever the weights (a quarter of the tap arithmetic)
+template <bool OPAQUE>
+__device__ __forceinline__ void ntap_accf (Acc4 &a, uint32_t v, float t)
+{
+  a.a0 = fmaf ((float) (v & 0xff), t, a.a0); a.a1 = fmaf ((float) ((v >> 8) & 0xff), t, a.a1);
+  a.a2 = fmaf ((float) ((v >> 16) & 0xff), t, a.a2);
+  if (!OPAQUE) a.a3 = fmaf ((float) (v >> 24), t, a.a3);
+}
+template <bool OPAQUE>
+__device__ __forceinline__ uint32_t ntap_finishf (const Acc4 &a)
+{
+  uint32_t q = __builtin_amdgcn_cvt_pk_u8_f32 (floorf (fmaf (a.a0, 0.015625f, 0.5f)), 0u, OPAQUE ? 0xff000000u : 0u);
+  q = __builtin_amdgcn_cvt_pk_u8_f32 (floorf (fmaf (a.a1, 0.015625f, 0.5f)), 1u, q);
+  q = __builtin_amdgcn_cvt_pk_u8_f32 (floorf (fmaf (a.a2, 0.015625f, 0.5f)), 2u, q);
+  return OPAQUE ? q : __builtin_amdgcn_cvt_pk_u8_f32 (floorf (fmaf (a.a3, 0.015625f, 0.5f)), 3u, q);
+}
+
 // ---- k_cs_cubic_tile: conversion + both n-tap passes fused per output tile ----------------------------------------------
 // One workgroup = a 64 x 16 tile of output pixels.  The source region the tile's taps reach (for 2:1: 135 x 39 pixels) is
 // converted ONCE into LDS as 8-bit RGBA (cs_tap: the gst-exact per-pixel conversion of k_cs_generic — GStreamer converts at
@@ -122,7 +141,7 @@ struct CubicTileParams {
   const int2 *tab_h, *tab_v;         // [ow][nh], [oh][nv] of {source index, 6-bit weight}; nh / nv == 0: no scaling on that axis
 };
 
-template <int THREADS>
+template <int THREADS, bool OPAQUE>
 __global__ __launch_bounds__ (THREADS) void k_cs_cubic_tile (const CubicTileParams p)
 {
   __shared__ __attribute__ ((aligned (16))) uint32_t reg[CT_RH][CT_RW];   // converted source region
@@ -143,8 +162,14 @@ __global__ __launch_bounds__ (THREADS) void k_cs_cubic_tile (const CubicTilePara
   int rw = cx1 - cx0 + 1;
   // horizontal taps tap-major ([l][tx]): the lanes of a wave are consecutive tx, so tap l of 64 columns is 64 consecutive int2 —
   // column-major ([tx][l], 8 * nh bytes apart) put every lane of a wave on the same four LDS banks
-  for (int i = tid; i < tw * p.nh; i += THREADS) { const int tx = i / p.nh, l = i - tx * p.nh; lth[l * CT_TW + tx] = p.tab_h[(size_t) x0 * p.nh + i]; }
-  for (int i = tid; i < th * p.nv; i += THREADS) ltv[i] = p.tab_v[(size_t) y0 * p.nv + i];
+  // staged as { index relative to the region, weight as float bits }: no subtraction and no int -> float conversion per tap
+  const int ga0 = p.fast_nv12 ? (cx0 & ~7) : cx0;                      // the region's first column (see below)
+  for (int i = tid; i < tw * p.nh; i += THREADS) {
+    const int tx = i / p.nh, l = i - tx * p.nh;
+    const int2 e = p.tab_h[(size_t) x0 * p.nh + i];
+    lth[l * CT_TW + tx] = make_int2 (e.x - ga0, __float_as_int ((float) e.y));
+  }
+  for (int i = tid; i < th * p.nv; i += THREADS) { const int2 e = p.tab_v[(size_t) y0 * p.nv + i]; ltv[i] = make_int2 (e.x - ry0, __float_as_int ((float) e.y)); }
   if (p.fast_nv12) {
     // region widened to whole 8-column groups; groups that would cross the right image edge fall back to cs_tap
     const int ga = cx0 & ~7, groups = ((cx1 + 1 - ga) + 7) >> 3;
@@ -181,16 +206,16 @@ __global__ __launch_bounds__ (THREADS) void k_cs_cubic_tile (const CubicTilePara
         const int ty = i / rw, rx = i - ty * rw;
         const int2 *t = ltv + ty * p.nv;
         Acc4 a = { 0.0f, 0.0f, 0.0f, 0.0f };
-        for (int l = 0; l < p.nv; l++) ntap_acc (a, reg[t[l].x - ry0][rx], t[l].y);
-        tmp[ty * rw + rx] = ntap_finish (a);
+        for (int l = 0; l < p.nv; l++) ntap_accf<OPAQUE> (a, reg[t[l].x][rx], __int_as_float (t[l].y));
+        tmp[ty * rw + rx] = ntap_finishf<OPAQUE> (a);
       }
     } else {                                                           // tmp[ry][tx] = horizontal taps over the region's rows
       for (int i = tid; i < rh * tw; i += THREADS) {
         const int ry = i / tw, tx = i - ry * tw;
         const int2 *t = lth + tx;
         Acc4 a = { 0.0f, 0.0f, 0.0f, 0.0f };
-        for (int l = 0; l < p.nh; l++) ntap_acc (a, reg[ry][t[l * CT_TW].x - cx0], t[l * CT_TW].y);
-        tmp[ry * CT_TW + tx] = ntap_finish (a);
+        for (int l = 0; l < p.nh; l++) ntap_accf<OPAQUE> (a, reg[ry][t[l * CT_TW].x], __int_as_float (t[l * CT_TW].y));
+        tmp[ry * CT_TW + tx] = ntap_finishf<OPAQUE> (a);
       }
     }
     __syncthreads ();
@@ -202,20 +227,20 @@ __global__ __launch_bounds__ (THREADS) void k_cs_cubic_tile (const CubicTilePara
     if (p.nh && p.nv) {
       if (p.vfirst) {
         const int2 *t = lth + tx;
-        for (int l = 0; l < p.nh; l++) ntap_acc (a, tmp[ty * rw + (t[l * CT_TW].x - cx0)], t[l * CT_TW].y);
+        for (int l = 0; l < p.nh; l++) ntap_accf<OPAQUE> (a, tmp[ty * rw + t[l * CT_TW].x], __int_as_float (t[l * CT_TW].y));
       } else {
         const int2 *t = ltv + ty * p.nv;
-        for (int l = 0; l < p.nv; l++) ntap_acc (a, tmp[(t[l].x - ry0) * CT_TW + tx], t[l].y);
+        for (int l = 0; l < p.nv; l++) ntap_accf<OPAQUE> (a, tmp[t[l].x * CT_TW + tx], __int_as_float (t[l].y));
       }
-      q = ntap_finish (a);
+      q = ntap_finishf<OPAQUE> (a);
     } else if (p.nh) {
       const int2 *t = lth + tx;
-      for (int l = 0; l < p.nh; l++) ntap_acc (a, reg[ty][t[l * CT_TW].x - cx0], t[l * CT_TW].y);
-      q = ntap_finish (a);
+      for (int l = 0; l < p.nh; l++) ntap_accf<OPAQUE> (a, reg[ty][t[l * CT_TW].x], __int_as_float (t[l * CT_TW].y));
+      q = ntap_finishf<OPAQUE> (a);
     } else if (p.nv) {
       const int2 *t = ltv + ty * p.nv;
-      for (int l = 0; l < p.nv; l++) ntap_acc (a, reg[t[l].x - ry0][tx], t[l].y);
-      q = ntap_finish (a);
+      for (int l = 0; l < p.nv; l++) ntap_accf<OPAQUE> (a, reg[t[l].x][tx], __int_as_float (t[l].y));
+      q = ntap_finishf<OPAQUE> (a);
     } else q = reg[ty][tx];
     *reinterpret_cast<uint32_t *> (out + (size_t) (y0 + ty) * p.os + 4 * (x0 + tx)) = q;
   }
