@@ -73,23 +73,27 @@ __global__ __launch_bounds__ (256) void k_ntap_h (const NtapParams p)
   *reinterpret_cast<uint32_t *> (p.out + (size_t) y * p.os + 4 * x) = ntap_finish (a);
 }
 
-// the tile kernel's form: the weight already a float (converted once when the tap table is staged in LDS), and — OPAQUE — no fourth
-// channel: a source without alpha converts to A = 255 in every pixel, the taps of an output sample sum to 64, so the filtered alpha
-// is (255 * 64 + 32) >> 6 = 255 whatever the weights (a quarter of the tap arithmetic)
+// the tile kernel's form: the weight already a float (converted once when the tap table is staged in LDS), and — OPAQUE — no
+// per-tap arithmetic on the fourth channel.  A source without alpha converts to A = 255 in every pixel, so every input of one pass's
+// sum carries the SAME alpha `ain` (255 in the first pass; in the second, the first pass's value for that row / column, which depends
+// only on the first pass's tap sum) and the filtered alpha is ((ain * sum of the taps) + 32) >> 6.  The tap sum is carried instead of
+// assumed: GStreamer's 6-bit taps do not always sum to 64 (at 3:1 some columns sum to 63 and videoscale really outputs A = 251 there —
+// found by tools/fuzz_gst_exact.py against the pinned oracle), so a constant 255 would be wrong.
 template <bool OPAQUE>
 __device__ __forceinline__ void ntap_accf (Acc4 &a, uint32_t v, float t)
 {
   a.a0 = fmaf ((float) (v & 0xff), t, a.a0); a.a1 = fmaf ((float) ((v >> 8) & 0xff), t, a.a1);
   a.a2 = fmaf ((float) ((v >> 16) & 0xff), t, a.a2);
-  if (!OPAQUE) a.a3 = fmaf ((float) (v >> 24), t, a.a3);
+  if (OPAQUE) a.a3 += t; else a.a3 = fmaf ((float) (v >> 24), t, a.a3);
 }
+// `ain`: OPAQUE only — the alpha every input of this sum carried (see above)
 template <bool OPAQUE>
-__device__ __forceinline__ uint32_t ntap_finishf (const Acc4 &a)
+__device__ __forceinline__ uint32_t ntap_finishf (const Acc4 &a, float ain)
 {
-  uint32_t q = __builtin_amdgcn_cvt_pk_u8_f32 (floorf (fmaf (a.a0, 0.015625f, 0.5f)), 0u, OPAQUE ? 0xff000000u : 0u);
+  uint32_t q = __builtin_amdgcn_cvt_pk_u8_f32 (floorf (fmaf (a.a0, 0.015625f, 0.5f)), 0u, 0u);
   q = __builtin_amdgcn_cvt_pk_u8_f32 (floorf (fmaf (a.a1, 0.015625f, 0.5f)), 1u, q);
   q = __builtin_amdgcn_cvt_pk_u8_f32 (floorf (fmaf (a.a2, 0.015625f, 0.5f)), 2u, q);
-  return OPAQUE ? q : __builtin_amdgcn_cvt_pk_u8_f32 (floorf (fmaf (a.a3, 0.015625f, 0.5f)), 3u, q);
+  return __builtin_amdgcn_cvt_pk_u8_f32 (floorf (fmaf (OPAQUE ? a.a3 * ain : a.a3, 0.015625f, 0.5f)), 3u, q);
 }
 
 // ---- k_cs_cubic_tile: conversion + both n-tap passes fused per output tile ----------------------------------------------
@@ -207,7 +211,7 @@ __global__ __launch_bounds__ (THREADS) void k_cs_cubic_tile (const CubicTilePara
         const int2 *t = ltv + ty * p.nv;
         Acc4 a = { 0.0f, 0.0f, 0.0f, 0.0f };
         for (int l = 0; l < p.nv; l++) ntap_accf<OPAQUE> (a, reg[t[l].x][rx], __int_as_float (t[l].y));
-        tmp[ty * rw + rx] = ntap_finishf<OPAQUE> (a);
+        tmp[ty * rw + rx] = ntap_finishf<OPAQUE> (a, 255.0f);
       }
     } else {                                                           // tmp[ry][tx] = horizontal taps over the region's rows
       for (int i = tid; i < rh * tw; i += THREADS) {
@@ -215,7 +219,7 @@ __global__ __launch_bounds__ (THREADS) void k_cs_cubic_tile (const CubicTilePara
         const int2 *t = lth + tx;
         Acc4 a = { 0.0f, 0.0f, 0.0f, 0.0f };
         for (int l = 0; l < p.nh; l++) ntap_accf<OPAQUE> (a, reg[ry][t[l * CT_TW].x], __int_as_float (t[l * CT_TW].y));
-        tmp[ry * CT_TW + tx] = ntap_finishf<OPAQUE> (a);
+        tmp[ry * CT_TW + tx] = ntap_finishf<OPAQUE> (a, 255.0f);
       }
     }
     __syncthreads ();
@@ -225,22 +229,25 @@ __global__ __launch_bounds__ (THREADS) void k_cs_cubic_tile (const CubicTilePara
     Acc4 a = { 0.0f, 0.0f, 0.0f, 0.0f };
     uint32_t q;
     if (p.nh && p.nv) {
+      float ain;
       if (p.vfirst) {
         const int2 *t = lth + tx;
+        ain = (float) (tmp[ty * rw + t[0].x] >> 24);
         for (int l = 0; l < p.nh; l++) ntap_accf<OPAQUE> (a, tmp[ty * rw + t[l * CT_TW].x], __int_as_float (t[l * CT_TW].y));
       } else {
         const int2 *t = ltv + ty * p.nv;
+        ain = (float) (tmp[t[0].x * CT_TW + tx] >> 24);
         for (int l = 0; l < p.nv; l++) ntap_accf<OPAQUE> (a, tmp[t[l].x * CT_TW + tx], __int_as_float (t[l].y));
       }
-      q = ntap_finishf<OPAQUE> (a);
+      q = ntap_finishf<OPAQUE> (a, ain);
     } else if (p.nh) {
       const int2 *t = lth + tx;
       for (int l = 0; l < p.nh; l++) ntap_accf<OPAQUE> (a, reg[ty][t[l * CT_TW].x], __int_as_float (t[l * CT_TW].y));
-      q = ntap_finishf<OPAQUE> (a);
+      q = ntap_finishf<OPAQUE> (a, 255.0f);
     } else if (p.nv) {
       const int2 *t = ltv + ty * p.nv;
       for (int l = 0; l < p.nv; l++) ntap_accf<OPAQUE> (a, reg[t[l].x][tx], __int_as_float (t[l].y));
-      q = ntap_finishf<OPAQUE> (a);
+      q = ntap_finishf<OPAQUE> (a, 255.0f);
     } else q = reg[ty][tx];
     *reinterpret_cast<uint32_t *> (out + (size_t) (y0 + ty) * p.os + 4 * (x0 + tx)) = q;
   }

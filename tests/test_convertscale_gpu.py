@@ -248,6 +248,22 @@ def test_bicubic_outside_the_pinned_domain_is_refused(vfhip):
     cs.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("ifmt,w,h,ow,oh", [("I420", 54, 67, 18, 74), ("I420", 93, 32, 33, 101), ("NV12", 54, 67, 18, 74), ("NV12", 54, 67, 18, 67),
+                                            ("UYVY", 60, 40, 20, 13), ("BGRA", 54, 67, 18, 74), ("NV12", 300, 200, 100, 67)])
+def test_bicubic_alpha_where_the_taps_do_not_sum_to_64(vfhip, oracle, ifmt, w, h, ow, oh):
+    """GStreamer's 6-bit catrom taps sum to 63 in some columns / rows at 3:1, and videoscale then outputs A = 251 for an opaque
+    source (pinned: the oracle equals the real element on such vectors).  The tile kernel, which does not filter the alpha of a
+    source without alpha tap by tap, has to reproduce that from the tap sums."""
+    rng = np.random.default_rng(w * 1000 + h)
+    raw = rng.integers(0, 256, vfhip.plane_layout(ifmt, w, h)[1], dtype=np.uint8)
+    got, kname = run(vfhip, ifmt, w, h, raw, "bt601", "jpeg", "bicubic", "RGBA", ow, oh)
+    want = oracle.convertscale(ifmt, w, h, raw, "bt601", "jpeg", "bicubic", "RGBA", ow, oh)
+    assert np.array_equal(got, want), kname
+    if ifmt != "BGRA" and (w, ow) != (300, 100):
+        assert (want.reshape(oh, ow, 4)[..., 3] != 255).any()       # the case really has such columns
+
+
 def test_bicubic_1080p_to_540p_vs_oracle_and_batch(vfhip, oracle):
     """the headline shape at half size (vertical pass first, 8 taps each way) against the oracle, plus a 3-frame batch"""
     import torch

@@ -30,6 +30,11 @@ cases = [("C4 full: 4 quadrants (over, .9) + NV12 720p centred", qp + [nvp], [qu
          ("4 quadrants over a checker background", qp, [quads[0].shape[1]] * 4, "checker"),
          ("no pads: background only", [], [], "black"),
          ("C4 with the NV12 pad one pixel off the chroma grid (general sampler path)", qp + [nvodd], [quads[0].shape[1]] * 4 + [nv.shape[1]], "black")]
+# mosaics of camera-style pads: four NV12 / I420 1080p quadrants (every pad goes through the 4:2:0 sampler)
+nvq = [ring(NC, vfhip.plane_layout("NV12", 1920, 1080)[1], 30 + k) for k in range(4)]
+for fmt in ("NV12", "I420"):
+    qq = [comp.pad(fmt, 1920, 1080, nvq[k].data_ptr(), (k % 2) * 1920, (k // 2) * 1080, 1920, 1080, 1.0, "over", colorimetry="bt709") for k in range(4)]
+    cases.append((f"4 {fmt} 1080p quadrants (over, 1.0)", qq, [nvq[0].shape[1]] * 4, "black"))
 for name, pads, pitches, bg in cases:
     def run():
         comp.composite_device(pads, out.data_ptr(), background=bg, stream=s.cuda_stream, n_frames=NC, pad_pitches=pitches, out_pitch=out.shape[1])
