@@ -20,6 +20,7 @@ namespace vfhip {
 
 constexpr int COMP_MAX_LAYERS = 16;     // per launch; more pads chain through an RGBA8 scratch target
 constexpr int COMP_BG_IN_PLACE = -2;
+constexpr int COMP_MAX_COVER = 8;
 
 struct CompLayer {
   metal::Img img;
@@ -35,6 +36,8 @@ struct CompParams {
                                         // start from what `out` (RGBA / BGRA) already holds — a later draw over part of the frame
   const uint32_t *prev; int prev_stride;
   int bx0, by0;                         // the launch's first lane block (region launches; 0 for a full frame)
+  int n_cover;                          // k_compositor_quads / k_compositor_420 drawing a frame's FIRST run: rectangles (x0, y0, x1, y1) that a later
+  int cover[COMP_MAX_COVER][4];         // opaque pad overwrites completely — a wave whose strip lies inside one draws nothing
   metal::OutImg out;
   uint32_t *scratch; int scratch_stride;   // != nullptr: write logical RGBA8 here instead of `out`
   size_t out_pitch;                     // batch: output frame z at base + z * out_pitch (single-pass launches only)
@@ -102,6 +105,16 @@ __device__ __forceinline__ uint32_t comp_blend (const CompLayer &L, const F4 &s,
 }
 
 typedef uint4 __attribute__ ((aligned (4))) uint4_a4;
+
+// the wave's strip [wx0, wx1) x [wy0, wy1) lies inside a rectangle that a later opaque pad overwrites (wave-uniform)
+__device__ __forceinline__ bool comp_covered (const CompParams &p, int wx0, int wx1, int wy0, int wy1)
+{
+  bool c = false;
+#pragma unroll
+  for (int k = 0; k < COMP_MAX_COVER; k++)
+    c = c || (k < p.n_cover && wx0 >= p.cover[k][0] && wy0 >= p.cover[k][1] && wx1 <= p.cover[k][2] && wy1 <= p.cover[k][3]);
+  return c;
+}
 
 // k_compositor: the general kernel (any mix of scaled and unscaled pads).
 // Workgroup = 64 x 4 lanes; one lane = a 4 x 2 block of output pixels (two of the store epilogue's 2x2 blocks), so a wave
@@ -494,6 +507,7 @@ __global__ __launch_bounds__ (256) void k_compositor_quads (const CompParams p)
       for (int i = 0; i < 4; i++) q[r][i] = comp_background (p, o, xl + i, y0 + r);
   }
   const int wx0 = 4 * (p.bx0 + (int) blockIdx.x * 64), wx1 = wx0 + 256, wy1 = y0 + COMP_ROWS;
+  if (comp_covered (p, wx0, min (wx1, p.out.w), y0, min (wy1, p.out.h))) return;
   uint32_t hit = 0;                                           // all sixteen rectangle tests up front: independent scalar loads
 #pragma unroll
   for (int k = 0; k < COMP_MAX_LAYERS; k++) {
@@ -551,6 +565,214 @@ __global__ __launch_bounds__ (256) void k_compositor_quads (const CompParams p)
   }
 }
 
+
+// k_compositor_420: ONE pad drawn at its own size from an NV12 / I420 frame on the chroma grid (even xpos / ypos: comp_pad_420) into an
+// RGBA / BGRA output with 16-byte rows — a camera or decoder feed in a mosaic, the inset of BASELINE configs[3].
+// k_compositor_unscaled draws such a pad from a 4 x 4 block per lane with all sixteen running colours in registers (117 VGPRs, 4 waves
+// per SIMD, 17.2 us for a frame of four 1080p NV12 quadrants where the traffic needs 7.4); with one pad there is nothing to carry
+// between pads, so this kernel WALKS a strip of COMP420_ROWS rows, two rows (one chroma step) per trip: a row's four target pixels are
+// loaded, blended and stored, and the only state is the two horizontally interpolated chroma rows the next trip starts from.
+// Same operations per value as metal::fetch_1to1 / plane_taps (horizontal lerp of each chroma row, then the vertical lerp, .25 / .75
+// phases) -> bit-identical to the other kernels.  Rows and lanes outside the pad are not touched when drawing in place; an opaque pad
+// (alpha 1, not ADD: out = s exactly, k = 1 - 1 = 0) does not read the target under it at all.
+// Lanes that a pad edge cuts (xpos or width not a multiple of 4) take the exact-texel sampler pixel by pixel.
+constexpr int COMP420_ROWS = 8;
+
+struct C420Row { float u[4], v[4]; };
+struct C420Raw { uint32_t a, b; };      // a chroma row's four columns as loaded: NV12 two dwords of (U, V) pairs, I420 the U and the V dword
+// chroma row `row` (clamped by the caller), columns start .. start + 3 (start: j - 1 clamped into the plane: see k_compositor_unscaled)
+__device__ __forceinline__ C420Raw comp420_load (const metal::Img &im, size_t row, int start)
+{
+  typedef uint32_t __attribute__ ((aligned (1))) u32_any;
+  typedef uint2 __attribute__ ((aligned (1))) u64_any;
+  C420Raw r;
+  if (im.fmt == VFHIP_FORMAT_NV12) {
+    const uint2 c = *reinterpret_cast<const u64_any *> (im.p[1] + row * im.s[1] + 2 * start);
+    r.a = c.x; r.b = c.y;
+  } else {
+    r.a = *reinterpret_cast<const u32_any *> (im.p[1] + row * im.s[1] + start);
+    r.b = *reinterpret_cast<const u32_any *> (im.p[2] + row * im.s[2] + start);
+  }
+  return r;
+}
+// ... -> columns j - 1 .. j + 2 edge-clamped by the byte selectors -> the four pixels' horizontally interpolated (U, V)
+__device__ __forceinline__ C420Row comp420_hrow (const C420Raw &c, bool nv12, uint32_t selu, uint32_t selp)
+{
+  const uint32_t Ud = nv12 ? __builtin_amdgcn_perm (c.b, c.a, selu) : __builtin_amdgcn_perm (0u, c.a, selp);
+  const uint32_t Vd = nv12 ? __builtin_amdgcn_perm (c.b, c.a, selu + 0x01010101u) : __builtin_amdgcn_perm (0u, c.b, selp);
+  float cu[4], cv[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { cu[k] = metal::un8 ((Ud >> (8 * k)) & 0xffu); cv[k] = metal::un8 ((Vd >> (8 * k)) & 0xffu); }
+  C420Row h;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int t = (i + 1) >> 1;                            // pixel px + i: taps (t, t + 1) of the four columns, weight .75 (even i) / .25 (odd i)
+    const float fx = (i & 1) ? 0.25f : 0.75f;
+    h.u[i] = metal::lerp2 (cu[t], cu[t + 1], fx); h.v[i] = metal::lerp2 (cv[t], cv[t + 1], fx);
+  }
+  return h;
+}
+
+// clamp01 (fmaf (a, b, c)) in one instruction (the clamp output modifier of v_fma_f32; see deinterlace.hip)
+__device__ __forceinline__ float comp_fma_sat (float a, float b, float c)
+{
+  float d;
+  asm ("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+// TARGET: the pad's pixels are blended with what the target holds (read back pixel by pixel); false: with one wave-uniform colour — the
+// flat background of a frame's first run, or nothing at all under an opaque pad (k = 0) — so the fast path loads no target, converts
+// none, and the alpha it writes is a constant.  Everything the per-pixel code would branch on (matrix, byte order, operator) is
+// turned into wave-uniform coefficients before the loop, and the loads of a row pair are issued one trip ahead (row and chroma
+// indices clamped, so the prefetch needs no branch): the loop body is straight-line code with its inputs already on their way.
+template <bool TARGET>
+__global__ __launch_bounds__ (256) void k_compositor_420 (const CompParams p)
+{
+  typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
+  typedef uint32_t __attribute__ ((aligned (1))) u32_any;
+  const int bx = p.bx0 + blockIdx.x * 64 + threadIdx.x;
+  const int by = __builtin_amdgcn_readfirstlane ((int) (p.by0 + blockIdx.y * 4 + threadIdx.y));      // one row of lanes = one wave
+  const int x0 = 4 * bx, y0 = COMP420_ROWS * by;
+  if (y0 >= p.out.h) return;
+  const int y1 = min (y0 + COMP420_ROWS, p.out.h);
+  const bool live = x0 < p.out.w;                              // out.w is a multiple of 4
+  const int xl = live ? x0 : p.out.w - 4;
+  const unsigned z = blockIdx.z;
+  const metal::OutImg o = metal::out_at (p.out, z * p.out_pitch);
+  const bool bgra_out = o.fmt == VFHIP_FORMAT_BGRA;
+  const bool in_place = p.background == COMP_BG_IN_PLACE;
+  const int wx0 = 4 * (p.bx0 + (int) blockIdx.x * 64);
+  if (!in_place && comp_covered (p, wx0, min (wx0 + 256, p.out.w), y0, y1)) return;
+  const CompLayer &L = p.layer[0];
+  const metal::Img im = metal::img_at (L.img, z * L.pitch);
+  const bool nv12 = im.fmt == VFHIP_FORMAT_NV12;
+  // the strip's rows under the pad: [ya, yb) (wave-uniform); ya - ypos is even because ypos and the strip height are
+  const int ya = max (y0, L.ypos), yb = min (y1, L.ypos + L.height);
+  uint8_t *orow = o.p[0] + 4 * (size_t) xl;
+  if (!in_place && live) {
+    // a frame's first run: the strip's rows above and below the pad are background
+    for (int y = y0; y < y1; y++) {
+      if (y >= ya && y < yb) continue;
+      v4u b;
+#pragma unroll
+      for (int i = 0; i < 4; i++) b[i] = comp_background (p, o, xl + i, y);
+      __builtin_nontemporal_store (b, reinterpret_cast<v4u *> (orow + (size_t) y * o.s[0]));
+    }
+  }
+  if (ya >= yb) return;
+  const bool flat = !in_place && (p.background == VFHIP_BG_BLACK || p.background == VFHIP_BG_WHITE || p.background == VFHIP_BG_TRANSPARENT);
+  F4 bgc;
+  bgc.r = bgc.g = bgc.b = p.background == VFHIP_BG_WHITE ? 1.0f : 0.0f; bgc.a = p.background == VFHIP_BG_TRANSPARENT ? 0.0f : 1.0f;
+  if (in_place) bgc.r = bgc.g = bgc.b = bgc.a = 0.0f;           // (TARGET false in place: an opaque pad, the target is multiplied by k = 0)
+  const int sx = xl - L.xpos;                                   // even (comp_pad_420)
+  const bool anyx = sx + 3 >= 0 && sx < L.width, full = sx >= 0 && sx + 3 < L.width;
+  if (!full) {
+    // lanes beside the pad (a first run gives them the background) and lanes its left / right edge cuts: the target under them, then
+    // the exact-texel sampler for the covered pixels, one at a time (one rolled instance)
+    if (in_place && !anyx) return;
+#pragma unroll 1
+    for (int y = ya; y < yb; y++) {
+      v4u q;
+      if (in_place) q = *reinterpret_cast<const v4u *> (orow + (size_t) y * o.s[0]);
+      else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) q[i] = comp_background (p, o, xl + i, y);
+      }
+      if (anyx) {
+#pragma unroll 1
+        for (int i = 0; i < 4; i++) {
+          if (sx + i < 0 || sx + i >= L.width) continue;
+          const uint32_t cur = i == 0 ? q[0] : (i == 1 ? q[1] : (i == 2 ? q[2] : q[3]));
+          const uint32_t v = comp_blend (L, comp_order (metal::fetch_1to1 (im, sx + i, y - L.ypos, true), bgra_out), cur, flat, bgc);
+          q[0] = i == 0 ? v : q[0]; q[1] = i == 1 ? v : q[1]; q[2] = i == 2 ? v : q[2]; q[3] = i == 3 ? v : q[3];
+        }
+      }
+      if (live) __builtin_nontemporal_store (q, reinterpret_cast<v4u *> (orow + (size_t) y * o.s[0]));
+    }
+    return;
+  }
+  // ---- lanes inside the pad ----
+  // the blend of a pixel without alpha of its own (c.a = 1): s.a = 1 * alpha = alpha, s.rgb = c.rgb * alpha, out = d * k + s with
+  // k = 0 (source), 1 (add), 1 - alpha (over) — comp_blend_f's operations with the wave-uniform ones done once
+  const float alpha = L.alpha;
+  const float kb = L.blend == VFHIP_BLEND_SOURCE ? 0.0f : (L.blend == VFHIP_BLEND_ADD ? 1.0f : 1.0f - alpha);
+  const bool m709 = im.m709 != 0;
+  const float c_rv = m709 ? 1.792741f : 1.596027f, c_gu = m709 ? -0.213249f : -0.391762f, c_gv = m709 ? -0.532909f : -0.812968f,
+              c_bu = m709 ? 2.112402f : 2.017232f;           // metal::yuv_to_rgb's two matrices
+  const uint32_t qa_flat = __builtin_amdgcn_cvt_pk_u8_f32 (fmaf (bgc.a, kb, alpha) * 255.0f, 3u, 0u);      // TARGET false: the alpha byte, in place
+  const int cw = (im.w + 1) >> 1, chh = (im.h + 1) >> 1;
+  const int j = sx >> 1, start = metal::iclamp (j - 1, 0, cw - 4);
+  const uint32_t selu = j < 1 ? 0x04020000u : (j + 2 >= cw ? 0x06060402u : 0x06040200u);
+  const uint32_t selp = j < 1 ? 0x02010000u : (j + 2 >= cw ? 0x03030201u : 0x03020100u);
+  const int sy0 = ya - L.ypos, m0 = sy0 >> 1;                   // first pad row of the strip (even), its chroma row
+  const uint8_t *yrow = im.p[0] + sx;
+  // prologue: chroma rows m0 - 1 and m0, and the first pair's loads
+  const C420Raw ra = comp420_load (im, (size_t) max (m0 - 1, 0), start), rb = comp420_load (im, (size_t) min (m0, chh - 1), start);
+  uint32_t Yn[2];
+  C420Raw rn;
+  v4u qn[2] = { { 0u, 0u, 0u, 0u }, { 0u, 0u, 0u, 0u } };
+  auto prefetch = [&] (int sy, int ye) {
+#pragma unroll
+    for (int r = 0; r < 2; r++) Yn[r] = *reinterpret_cast<const u32_any *> (yrow + (size_t) min (sy + r, L.height - 1) * im.s[0]);
+    rn = comp420_load (im, (size_t) min ((sy >> 1) + 1, chh - 1), start);
+    if (TARGET && in_place) {
+#pragma unroll
+      for (int r = 0; r < 2; r++) qn[r] = *reinterpret_cast<const v4u *> (orow + (size_t) min (ye + r, p.out.h - 1) * o.s[0]);
+    }
+  };
+  prefetch (sy0, ya);
+  C420Row hA = comp420_hrow (ra, nv12, selu, selp), hB = comp420_hrow (rb, nv12, selu, selp);
+#pragma unroll 1
+  for (int ye = ya; ye < yb; ye += 2) {
+    const int sy = ye - L.ypos;                                 // even
+    const uint32_t Y[2] = { Yn[0], Yn[1] };
+    const C420Raw rc = rn;
+    v4u q[2] = { qn[0], qn[1] };
+    prefetch (min (sy + 2, L.height - 1) & ~1, min (ye + 2, p.out.h - 1));       // the next pair's (the last trip re-reads its own: no branch)
+    if (TARGET && !in_place) {
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) q[r][i] = comp_background (p, o, xl + i, min (ye + r, p.out.h - 1));
+    }
+    const C420Row hC = comp420_hrow (rc, nv12, selu, selp);
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      // row 2m leans on chroma rows (m - 1, m) with .75, row 2m + 1 on (m, m + 1) with .25
+      const C420Row &c0 = r ? hB : hA, &c1 = r ? hC : hB;
+      const float fy = r ? 0.25f : 0.75f;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float cb = metal::lerp2 (c0.u[i], c1.u[i], fy), cr = metal::lerp2 (c0.v[i], c1.v[i], fy);
+        // metal::yuv_to_rgb, the matrix in registers and each clamp folded into the fma that feeds it
+        const float yy = metal::un8 ((Y[r] >> (8 * i)) & 0xffu) - 16.0f / 255.0f, u = cb - 128.0f / 255.0f, v = cr - 128.0f / 255.0f;
+        const float ly = 1.164383f * yy;
+        const float cr_ = comp_fma_sat (c_rv, v, ly), cg_ = comp_fma_sat (c_gv, v, fmaf (c_gu, u, ly)), cb_ = comp_fma_sat (c_bu, u, ly);
+        const float s0 = (bgra_out ? cb_ : cr_) * alpha, s1 = cg_ * alpha, s2 = (bgra_out ? cr_ : cb_) * alpha;      // target order, premultiplied
+        uint32_t v8;
+        if (TARGET) {
+          const F4 d = metal::unpack_rgba8 (q[r][i]);
+          v8 = __builtin_amdgcn_cvt_pk_u8_f32 (fmaf (d.r, kb, s0) * 255.0f, 0u, 0u);
+          v8 = __builtin_amdgcn_cvt_pk_u8_f32 (fmaf (d.g, kb, s1) * 255.0f, 1u, v8);
+          v8 = __builtin_amdgcn_cvt_pk_u8_f32 (fmaf (d.b, kb, s2) * 255.0f, 2u, v8);
+          v8 = __builtin_amdgcn_cvt_pk_u8_f32 (fmaf (d.a, kb, alpha) * 255.0f, 3u, v8);
+        } else {
+          v8 = __builtin_amdgcn_cvt_pk_u8_f32 (fmaf (bgc.r, kb, s0) * 255.0f, 0u, qa_flat);
+          v8 = __builtin_amdgcn_cvt_pk_u8_f32 (fmaf (bgc.g, kb, s1) * 255.0f, 1u, v8);
+          v8 = __builtin_amdgcn_cvt_pk_u8_f32 (fmaf (bgc.b, kb, s2) * 255.0f, 2u, v8);
+        }
+        q[r][i] = v8;
+      }
+    }
+    hA = hB; hB = hC;
+    if (live) {
+      __builtin_nontemporal_store (q[0], reinterpret_cast<v4u *> (orow + (size_t) ye * o.s[0]));
+      if (ye + 1 < yb) __builtin_nontemporal_store (q[1], reinterpret_cast<v4u *> (orow + (size_t) (ye + 1) * o.s[0]));
+    }
+  }
+}
+
 }  // namespace vfhip
 
 struct VfHipCompositor {
@@ -571,6 +793,20 @@ static bool comp_pad_lean (const VfHipPadInput &in)
   return comp_pad_unscaled (in) && (in.frame.info.format == VFHIP_FORMAT_RGBA || in.frame.info.format == VFHIP_FORMAT_BGRA) &&
       !(((uintptr_t) in.frame.data[0] | (uintptr_t) in.frame.stride[0]) & 3);
 }
+// a pad k_compositor_420 can draw: 4:2:0 at its own size, on the chroma grid of the output's lane blocks
+static bool comp_pad_420 (const VfHipPadInput &in)
+{
+  return comp_pad_unscaled (in) && (in.frame.info.format == VFHIP_FORMAT_NV12 || in.frame.info.format == VFHIP_FORMAT_I420) &&
+      !((in.xpos | in.ypos) & 1) && in.frame.info.width >= 7;
+}
+// what is under this pad does not show: it replaces the target (alpha 1 and a format without alpha under OVER; SOURCE always)
+static bool comp_pad_overwrites (const VfHipPadInput &in)
+{
+  const int f = in.frame.info.format;
+  if (in.blend_mode == VFHIP_BLEND_SOURCE) return true;
+  return in.blend_mode == VFHIP_BLEND_OVER && (float) in.alpha == 1.0f && f != VFHIP_FORMAT_RGBA && f != VFHIP_FORMAT_BGRA;
+}
+enum { COMP_KIND_LEAN, COMP_KIND_420, COMP_KIND_HEAVY };
 
 static void comp_fill_layer (CompLayer &L, const VfHipPadInput &in, size_t pitch)
 {
@@ -590,21 +826,29 @@ static int comp_launch_runs (VfHipCompositor *h, const VfHipPadInput *pads, int 
     int n_frames, const size_t *pad_pitch, size_t out_pitch)
 {
   const int w = h->out.width, hh = h->out.height;
-  const bool force_general = getenv ("VFHIP_COMP_GENERAL") != nullptr;       // test knobs: one kernel for every run
-  const bool no_lean = force_general || getenv ("VFHIP_COMP_NO_QUADS") != nullptr;
+  const bool force_general = getenv ("VFHIP_COMP_GENERAL") != nullptr;       // test knobs: one kernel for every run, ...
+  const bool no_lean = force_general || getenv ("VFHIP_COMP_NO_QUADS") != nullptr;       // ... no k_compositor_quads, ...
+  const bool no_420 = force_general || getenv ("VFHIP_COMP_NO_420") != nullptr;          // ... no k_compositor_420, ...
+  const bool no_cover = getenv ("VFHIP_COMP_NO_COVER") != nullptr;                       // ... draw what a later opaque pad hides
+  auto kind_of = [&] (const VfHipPadInput &in) {
+    if (!no_lean && comp_pad_lean (in)) return (int) COMP_KIND_LEAN;
+    if (!no_420 && comp_pad_420 (in)) return (int) COMP_KIND_420;
+    return (int) COMP_KIND_HEAVY;
+  };
   int k = 0;
   bool first = true;
   while (k < count || first) {
     while (k < count && !comp_pad_visible (pads[k])) k++;
     CompParams p {};
-    bool lean = !no_lean, unscaled = true;
+    int kind = no_lean ? COMP_KIND_HEAVY : COMP_KIND_LEAN;
+    bool unscaled = true;
     int rx0 = w, ry0 = hh, rx1 = 0, ry1 = 0;
     if (k < count) {
-      lean = !no_lean && comp_pad_lean (pads[k]);
-      for (; k < count && p.n < COMP_MAX_LAYERS; k++) {
+      kind = kind_of (pads[k]);
+      for (; k < count && p.n < (kind == COMP_KIND_420 ? 1 : COMP_MAX_LAYERS); k++) {
         const VfHipPadInput &in = pads[k];
         if (!comp_pad_visible (in)) continue;
-        if ((!no_lean && comp_pad_lean (in)) != lean) break;
+        if (kind_of (in) != kind) break;
         unscaled = unscaled && comp_pad_unscaled (in);
         comp_fill_layer (p.layer[p.n++], in, pad_pitch ? pad_pitch[k] : 0);
         rx0 = std::min (rx0, in.xpos); ry0 = std::min (ry0, in.ypos);
@@ -612,20 +856,48 @@ static int comp_launch_runs (VfHipCompositor *h, const VfHipPadInput *pads, int 
         ry1 = std::max (ry1, (int) std::min ((long long) hh, (long long) in.ypos + in.height));
       }
     }
-    if (first) { rx0 = 0; ry0 = 0; rx1 = w; ry1 = hh; }
+    if (kind == COMP_KIND_420 && p.n == 0) kind = COMP_KIND_LEAN;            // (no pad left: a background-only launch)
+    if (first) {
+      rx0 = 0; ry0 = 0; rx1 = w; ry1 = hh;
+      // what later opaque pads overwrite completely need not be drawn by this launch (largest rectangles first)
+      if (!no_cover && kind != COMP_KIND_HEAVY) {
+        struct R { int x0, y0, x1, y1; long long area; } best[COMP_MAX_COVER];
+        int nb = 0;
+        for (int j = k; j < count; j++) {
+          const VfHipPadInput &in = pads[j];
+          if (!comp_pad_visible (in) || !comp_pad_overwrites (in)) continue;
+          R r { std::max (in.xpos, 0), std::max (in.ypos, 0), (int) std::min ((long long) w, (long long) in.xpos + in.width),
+                (int) std::min ((long long) hh, (long long) in.ypos + in.height), 0 };
+          if (r.x0 >= r.x1 || r.y0 >= r.y1) continue;
+          r.area = (long long) (r.x1 - r.x0) * (r.y1 - r.y0);
+          int at = nb < COMP_MAX_COVER ? nb++ : -1;
+          if (at < 0) { for (int q = 0; q < nb; q++) if (best[q].area < r.area && (at < 0 || best[q].area < best[at].area)) at = q; }
+          if (at >= 0) best[at] = r;
+        }
+        p.n_cover = nb;
+        for (int q = 0; q < nb; q++) { p.cover[q][0] = best[q].x0; p.cover[q][1] = best[q].y0; p.cover[q][2] = best[q].x1; p.cover[q][3] = best[q].y1; }
+      }
+    }
     rx0 = std::max (rx0, 0); ry0 = std::max (ry0, 0);
     const bool draw = first || (p.n > 0 && rx0 < rx1 && ry0 < ry1);
     p.background = first ? background : COMP_BG_IN_PLACE;
     first = false;
     if (!draw) continue;
     unscaled = unscaled && !force_general;
-    const int rows = (lean || unscaled) ? COMP_ROWS : 2;
+    const int rows = kind == COMP_KIND_420 ? COMP420_ROWS : ((kind == COMP_KIND_LEAN || unscaled) ? COMP_ROWS : 2);
     // whole 64-lane groups from a 256-pixel boundary keep the 16-byte lanes of a wave on one 1 KiB-aligned run of a row
     p.bx0 = (rx0 / 256) * 64; p.by0 = ry0 / rows;
     const int bx1 = (rx1 + 3) / 4, by1 = (ry1 + rows - 1) / rows;
     dim3 grid ((unsigned) ((bx1 - p.bx0 + 63) / 64), (unsigned) ((by1 - p.by0 + 3) / 4), (unsigned) n_frames);
     p.out = metal::make_out (out); p.out_pitch = out_pitch;
-    if (lean) hipLaunchKernelGGL (k_compositor_quads, grid, dim3 (64, 4), 0, s, p);
+    if (kind == COMP_KIND_LEAN) hipLaunchKernelGGL (k_compositor_quads, grid, dim3 (64, 4), 0, s, p);
+    else if (kind == COMP_KIND_420) {
+      // nothing to read back under the pad: an opaque pad drawn in place (out = s), or a frame's first run over a uniform background
+      const bool flat_bg = p.background == VFHIP_BG_BLACK || p.background == VFHIP_BG_WHITE || p.background == VFHIP_BG_TRANSPARENT;
+      const bool opaque = p.layer[0].alpha == 1.0f && p.layer[0].blend != VFHIP_BLEND_ADD;
+      if (p.background == COMP_BG_IN_PLACE ? opaque : flat_bg) hipLaunchKernelGGL (k_compositor_420<false>, grid, dim3 (64, 4), 0, s, p);
+      else hipLaunchKernelGGL (k_compositor_420<true>, grid, dim3 (64, 4), 0, s, p);
+    }
     else if (unscaled) hipLaunchKernelGGL (k_compositor_unscaled, grid, dim3 (64, 4), 0, s, p);
     else hipLaunchKernelGGL (k_compositor, grid, dim3 (64, 4), 0, s, p);
     VFHIP_CHECK_HIP (hipGetLastError ());

@@ -613,6 +613,40 @@ def test_compositor_runs_of_pads(vfhip, metalref, ofmt, bg, monkeypatch):
     gen = comp.composite(to_vf(vfhip, pads), background=bg)
     monkeypatch.delenv("VFHIP_COMP_GENERAL")
     assert np.array_equal(got, gen), "general kernel differs"
+    monkeypatch.setenv("VFHIP_COMP_NO_420", "1")
+    n420 = comp.composite(to_vf(vfhip, pads), background=bg)
+    monkeypatch.delenv("VFHIP_COMP_NO_420")
+    assert np.array_equal(got, n420), "the 4:2:0 row walker differs from the block kernel"
+    monkeypatch.setenv("VFHIP_COMP_NO_COVER", "1")
+    ncov = comp.composite(to_vf(vfhip, pads), background=bg)
+    monkeypatch.delenv("VFHIP_COMP_NO_COVER")
+    assert np.array_equal(got, ncov), "skipping what later opaque pads overwrite changed the picture"
+    comp.close()
+
+
+@pytest.mark.parametrize("fmt", ["NV12", "I420"])
+@pytest.mark.parametrize("ofmt", ["BGRA", "RGBA"])
+def test_compositor_420_mosaic(vfhip, metalref, fmt, ofmt, monkeypatch):
+    """a mosaic of opaque 4:2:0 pads (k_compositor_420: first run over the frame with the later pads' rectangles skipped, the others in
+    place without reading the target), a translucent and an additive one on top, odd sizes and pads hanging over every frame edge"""
+    w, h = 520, 136
+    rng = np.random.default_rng(3)
+    geo = [(0, 0, 260, 68), (260, 0, 260, 68), (0, 68, 260, 68), (260, 68, 260, 68),          # four quadrants, opaque
+           (100, 30, 161, 45), (-14, -6, 80, 50), (470, 100, 90, 60), (254, 60, 13, 17)]      # odd sizes, off-frame corners, a sliver across the seams
+    pads = []
+    for k, (x, y, pw, ph) in enumerate(geo):
+        raw = smooth(fmt, pw, ph, 300 + k)
+        alpha, blend = (1.0, 1) if k < 4 else [(0.6, 1), (1.0, 2), (1.0, 1), (0.8, 0)][k - 4]
+        pads.append((fmt, pw, ph, raw, x, y, pw, ph, alpha, blend, bool(k & 1)))
+    comp = vfhip.Compositor(0)
+    comp.configure(ofmt, w, h)
+    got = comp.composite(to_vf(vfhip, pads), background="checker")
+    close(got, metalref.compositor(ofmt, w, h, pads, 0), f"4:2:0 mosaic {fmt} {ofmt}", max_off_by_one=0.05)
+    for knob in ("VFHIP_COMP_NO_420", "VFHIP_COMP_NO_COVER", "VFHIP_COMP_ONE_PASS"):
+        monkeypatch.setenv(knob, "1")
+        other = comp.composite(to_vf(vfhip, pads), background="checker")
+        monkeypatch.delenv(knob)
+        assert np.array_equal(got, other), knob
     comp.close()
 
 
