@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off fuzz of the `metal`-numerics kernels on the GPU against oracle/metalref.c (tolerance: 1 LSB): random formats, odd
-sizes, parameters.  usage: fuzz_metal.py [cases] [seed]"""
+sizes, parameters.  usage: fuzz_metal.py [cases] [seed] [element 0..5]"""
 import os
 import sys
 
@@ -30,9 +30,12 @@ def check(what, got, want):
         print("MISMATCH", what, "max", int(d.max()), "count", int((d > 1).sum()), flush=True)
 
 
+ONLY = int(sys.argv[3]) if len(sys.argv) > 3 else -1                # restrict to one element (3 = compositor)
 for case in range(N):
-    kind = rng.integers(6)
+    kind = rng.integers(6) if ONLY < 0 else ONLY
     w, h = int(rng.integers(2, 150)), int(rng.integers(2, 110))
+    if kind == 3 and rng.integers(2):
+        w, h = 4 * int(rng.integers(1, 160)), int(rng.integers(2, 140))          # the compositor's run kernels need width % 4 == 0; wider than one wave
     m709 = bool(rng.integers(2))
     col = "bt709" if m709 else "bt601"
     if kind == 0:
@@ -76,15 +79,17 @@ for case in range(N):
         vf.close()
     elif kind == 3:
         ofmt = F4[rng.integers(4)]
-        n = int(rng.integers(0, 5))
+        n = int(rng.integers(0, 7))
         pads, opads = [], []
         for _ in range(n):
             f = F4[rng.integers(4)]
             pw, ph = int(rng.integers(2, 90)), int(rng.integers(2, 70))
             r = frame(f, pw, ph)
             x, y = int(rng.integers(-40, w)), int(rng.integers(-40, h))
-            dw, dh = (pw, ph) if rng.integers(2) else (int(rng.integers(1, 120)), int(rng.integers(1, 90)))
-            a, b = float(rng.random()), ["source", "over", "add"][rng.integers(3)]
+            if rng.integers(2):
+                x, y = x & ~1, y & ~1                                # on the chroma grid (k_compositor_420) half of the time
+            dw, dh = (pw, ph) if rng.integers(3) else (int(rng.integers(1, 120)), int(rng.integers(1, 90)))
+            a, b = (1.0 if rng.integers(3) == 0 else float(rng.random())), ["source", "over", "add"][rng.integers(3)]     # alpha 1: opaque pads
             pads.append((f, pw, ph, r, x, y, dw, dh, a, b, col))
             opads.append((f, pw, ph, r, x, y, dw, dh, a, vfhip.BLEND_MODES[b], m709))
         bg = ["checker", "black", "white", "transparent"][rng.integers(4)]
