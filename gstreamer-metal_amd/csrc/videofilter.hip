@@ -63,6 +63,17 @@ __device__ __forceinline__ float hash12 (float px, float py, uint32_t frame)
   x += d; y += d; z += d;
   return fractf_ ((x + y) * z);
 }
+// 1 / x for a positive normal x: exponent-flip seed + three Newton steps of two fma each — the same fixed sequence as
+// oracle/metalref.c vf_rcp (relative error < 6e-8).  7 full-rate instructions where an IEEE division is ~10, two of them quarter-rate;
+// MSL's fast-math division is a reciprocal approximation times the numerator anyway.
+__device__ __forceinline__ float vf_rcp (float x)
+{
+  float r = __uint_as_float (0x7EF311C7u - __float_as_uint (x));
+  r = fmaf (r, fmaf (-x, r, 1.0f), r);
+  r = fmaf (r, fmaf (-x, r, 1.0f), r);
+  r = fmaf (r, fmaf (-x, r, 1.0f), r);
+  return r;
+}
 __device__ __forceinline__ void rgb_to_hsv (float r, float g, float b, float *h, float *s, float *v)
 {
   const float Kx = 0.0f, Ky = -1.0f / 3.0f, Kz = 2.0f / 3.0f, Kw = -1.0f;
@@ -72,8 +83,8 @@ __device__ __forceinline__ void rgb_to_hsv (float r, float g, float b, float *h,
   const float qx = mixf (px, r, t2), qy = mixf (py, py, t2), qz = mixf (pw, pz, t2), qw = mixf (r, px, t2);
   const float d = qx - fminf (qw, qy);
   const float e = 1.0e-10f;
-  *h = fabsf (qz + (qw - qy) / (6.0f * d + e));
-  *s = d / (qx + e);
+  *h = fabsf (qz + (qw - qy) * vf_rcp (6.0f * d + e));
+  *s = d * vf_rcp (qx + e);
   *v = qx;
 }
 __device__ __forceinline__ void hsv_to_rgb (float h, float s, float v, float *r, float *g, float *b)
@@ -97,7 +108,7 @@ __device__ __forceinline__ float vf_powf (float x, float y)
   int e = (int) (ux >> 23) - 127;
   float m = __uint_as_float ((ux & 0x007fffffu) | 0x3f800000u);
   if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
-  const float t = (m - 1.0f) / (m + 1.0f), t2 = t * t;
+  const float t = (m - 1.0f) * vf_rcp (m + 1.0f), t2 = t * t;
   float p = 0.11111111f;
   p = fmaf (p, t2, 0.14285714f); p = fmaf (p, t2, 0.2f); p = fmaf (p, t2, 0.33333333f); p = fmaf (p, t2, 1.0f);
   const float l2 = fmaf (t * p, 2.88539008f, (float) e);
@@ -184,7 +195,7 @@ __device__ __forceinline__ void lut_sample (const float4 *cells, int N, F4 &c)
 __device__ __forceinline__ uint32_t vf_pass1 (const VfParams &p, int x, int y)
 {
   x = metal::iclamp (x, 0, p.out.w - 1); y = metal::iclamp (y, 0, p.out.h - 1);
-  const float tu = ((float) x + 0.5f) / (float) p.out.w, tv = ((float) y + 0.5f) / (float) p.out.h;
+  const float tu = ((float) x + 0.5f) * (1.0f / (float) p.out.w), tv = ((float) y + 0.5f) * (1.0f / (float) p.out.h);      // wave-uniform reciprocals (oracle: inv_w, inv_h)
   F4 c = metal::fetch_1to1 (p.in, x, y, true);
   c = color_adjust (c, p.u, tu, tv, p.out.w, p.out.h);
   if (p.lut) lut_sample (p.lut, p.lut_size, c);

@@ -678,3 +678,27 @@ def test_compositor_runs_batch(vfhip, metalref):
                                                     ("NV12", 64, 48, b[k], 276, 20, 64, 48, 0.7, 1), ("RGBA", 37, 21, c[k], 301, 33, 37, 21, 1.0, 1)], 2)
         close(out[k], want, f"runs batch frame {k}")
     comp.close()
+
+
+def test_compositor_many_opaque_tiles(vfhip, metalref, monkeypatch):
+    """more opaque pads than a launch has cover rectangles (12 tiles of a 4 x 3 mosaic, mixed NV12 / I420 / BGRA-source, over a
+    translucent full-frame pad that they hide): the skipping of overwritten areas must stay invisible"""
+    w, h = 512, 192
+    tw, th = 128, 64
+    under = smooth("BGRA", w, h, 500)
+    under.reshape(-1, 4)[:, 3] = np.random.default_rng(1).integers(0, 256, w * h)
+    pads = [("BGRA", w, h, under, 0, 0, w, h, 0.8, 1, False)]
+    for k in range(12):
+        fmt = ["NV12", "I420", "BGRA"][k % 3]
+        raw = smooth(fmt, tw, th, 510 + k)
+        pads.append((fmt, tw, th, raw, (k % 4) * tw, (k // 4) * th, tw, th, 1.0, 0 if fmt == "BGRA" else 1, bool(k & 1)))
+    comp = vfhip.Compositor(0)
+    comp.configure("BGRA", w, h)
+    got = comp.composite(to_vf(vfhip, pads), background="white")
+    close(got, metalref.compositor("BGRA", w, h, pads, 2), "12 opaque tiles", max_off_by_one=0.05)
+    for knob in ("VFHIP_COMP_NO_COVER", "VFHIP_COMP_NO_420", "VFHIP_COMP_NO_QUADS", "VFHIP_COMP_ONE_PASS"):
+        monkeypatch.setenv(knob, "1")
+        other = comp.composite(to_vf(vfhip, pads), background="white")
+        monkeypatch.delenv(knob)
+        assert np.array_equal(got, other), knob
+    comp.close()
