@@ -566,6 +566,109 @@ __global__ __launch_bounds__ (256) void k_compositor_quads (const CompParams p)
 }
 
 
+// k_compositor_scaled: up to sixteen RGBA / BGRA pads drawn at ANY size (the multiviewer: feeds scaled into the tiles of a mosaic) into an
+// RGBA / BGRA output with 16-byte rows.  k_compositor draws a scaled pad through metal::sample_rgba — four plane samples of four
+// byte loads each per pixel, the eight pixels of a lane one after the other in a rolled loop (the only way its six-format sampler
+// fits the register file): a chain of eight memory latencies per layer, 62 us for a 1080p frame of four down-scaled 1080p feeds.
+// Here one lane = 4 x 2 pixels; the tap positions of the four columns and two rows are computed once per layer (metal::lin_taps on
+// the same texture coordinate: same operations), a row's sixteen texels (4 pixels x 2 x 2 taps, whole dwords) are loaded together,
+// and each pixel is then four byte-wise bilinear interpolations in plane_taps' order -> bit-identical to the general kernel.
+constexpr int COMP_SROWS = 2;
+
+__global__ __launch_bounds__ (256) void k_compositor_scaled (const CompParams p)
+{
+  typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
+  const int bx = p.bx0 + blockIdx.x * 64 + threadIdx.x;                                       // 4-pixel column group
+  const int by = __builtin_amdgcn_readfirstlane ((int) (p.by0 + blockIdx.y * 4 + threadIdx.y));      // one row of lanes = one wave
+  const int x0 = 4 * bx, y0 = COMP_SROWS * by;
+  if (y0 >= p.out.h) return;
+  const int wx0 = 4 * (p.bx0 + (int) blockIdx.x * 64), wx1 = wx0 + 256, wy1 = y0 + COMP_SROWS;
+  const bool in_place = p.background == COMP_BG_IN_PLACE;
+  if (!in_place && comp_covered (p, wx0, min (wx1, p.out.w), y0, min (wy1, p.out.h))) return;
+  const bool live = x0 < p.out.w;                                                             // out.w is a multiple of 4
+  const unsigned z = blockIdx.z;
+  const metal::OutImg o = metal::out_at (p.out, z * p.out_pitch);
+  const bool bgra_out = o.fmt == VFHIP_FORMAT_BGRA;
+  const int xl = live ? x0 : p.out.w - 4;                                                     // lanes right of the frame shadow its last block
+  bool rowok[COMP_SROWS];
+#pragma unroll
+  for (int r = 0; r < COMP_SROWS; r++) rowok[r] = y0 + r < p.out.h;                           // wave-uniform
+  v4u q[COMP_SROWS];
+#pragma unroll
+  for (int r = 0; r < COMP_SROWS; r++) {
+    q[r] = v4u { 0u, 0u, 0u, 0u };
+    if (in_place) { if (rowok[r]) q[r] = *reinterpret_cast<const v4u *> (o.p[0] + (size_t) (y0 + r) * o.s[0] + 4 * xl); }
+    else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) q[r][i] = comp_background (p, o, xl + i, y0 + r);
+    }
+  }
+  uint32_t hit = 0;                                           // all sixteen rectangle tests up front: independent scalar loads
+#pragma unroll
+  for (int k = 0; k < COMP_MAX_LAYERS; k++) {
+    const CompLayer &L = p.layer[k];
+    const bool miss = k >= p.n || wx1 <= L.xpos || wx0 >= L.xpos + L.width || wy1 <= L.ypos || y0 >= L.ypos + L.height;
+    hit |= miss ? 0u : 1u << k;
+  }
+  hit = (uint32_t) __builtin_amdgcn_readfirstlane ((int) hit);
+  bool flat = p.background == VFHIP_BG_BLACK || p.background == VFHIP_BG_WHITE || p.background == VFHIP_BG_TRANSPARENT;
+  F4 bgc;
+  bgc.r = bgc.g = bgc.b = p.background == VFHIP_BG_WHITE ? 1.0f : 0.0f; bgc.a = p.background == VFHIP_BG_TRANSPARENT ? 0.0f : 1.0f;
+  for (; hit; flat = false) {
+    const int k = __builtin_ctz (hit);
+    hit &= hit - 1;
+    const CompLayer &L = p.layer[k];
+    if (xl + 3 < L.xpos || xl >= L.xpos + L.width) continue;       // (per lane) no column of the block inside the quad
+    const uint8_t *base = L.img.p[0] + z * L.pitch;
+    const int W = L.img.w, H = L.img.h;
+    const bool swap = (L.img.fmt == VFHIP_FORMAT_BGRA) != bgra_out;  // the pad's bytes 0 and 2 change places on the way into target order
+    // the quad's texture coordinate at a pixel centre and its two taps per axis (compositorVertex + the linear sampler: comp_sample)
+    uint32_t c0[4], c1[4];                                           // byte offsets of the two tap columns
+    float fx[4];
+    bool cx[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      cx[i] = xl + i >= L.xpos && xl + i < L.xpos + L.width;
+      const float tu = (((float) (xl + i) + 0.5f) - (float) L.xpos) / (float) L.width;
+      const metal::Taps t = metal::lin_taps (W, tu);
+      c0[i] = 4u * (uint32_t) t.i0; c1[i] = 4u * (uint32_t) t.i1; fx[i] = t.f;
+    }
+#pragma unroll
+    for (int r = 0; r < COMP_SROWS; r++) {
+      if (!rowok[r] || y0 + r < L.ypos || y0 + r >= L.ypos + L.height) continue;      // wave-uniform
+      const float tv = (((float) (y0 + r) + 0.5f) - (float) L.ypos) / (float) L.height;
+      const metal::Taps ty = metal::lin_taps (H, tv);
+      const uint8_t *r0 = base + (size_t) ty.i0 * L.img.s[0], *r1 = base + (size_t) ty.i1 * L.img.s[0];
+      uint32_t t00[4], t10[4], t01[4], t11[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {                               // the row's sixteen texels first (clamped taps: always inside the frame)
+        t00[i] = *reinterpret_cast<const uint32_t *> (r0 + c0[i]); t10[i] = *reinterpret_cast<const uint32_t *> (r0 + c1[i]);
+        t01[i] = *reinterpret_cast<const uint32_t *> (r1 + c0[i]); t11[i] = *reinterpret_cast<const uint32_t *> (r1 + c1[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {                             // metal::plane_taps per byte: horizontal lerp of each tap row, then vertical
+          const float a = metal::lerp2 (metal::un8 ((t00[i] >> (8 * c)) & 0xffu), metal::un8 ((t10[i] >> (8 * c)) & 0xffu), fx[i]);
+          const float b = metal::lerp2 (metal::un8 ((t01[i] >> (8 * c)) & 0xffu), metal::un8 ((t11[i] >> (8 * c)) & 0xffu), fx[i]);
+          v[c] = metal::lerp2 (a, b, ty.f);
+        }
+        F4 sc;
+        sc.r = swap ? v[2] : v[0]; sc.g = v[1]; sc.b = swap ? v[0] : v[2]; sc.a = v[3];      // target order
+        const uint32_t nv = comp_blend (L, sc, q[r][i], flat, bgc);
+        q[r][i] = cx[i] ? nv : q[r][i];
+      }
+    }
+  }
+  if (!live) return;
+#pragma unroll
+  for (int r = 0; r < COMP_SROWS; r++) {
+    if (!rowok[r]) break;
+    __builtin_nontemporal_store (q[r], reinterpret_cast<v4u *> (o.p[0] + (size_t) (y0 + r) * o.s[0]) + bx);
+  }
+}
+
 // k_compositor_420: ONE pad drawn at its own size from an NV12 / I420 frame on the chroma grid (even xpos / ypos: comp_pad_420) into an
 // RGBA / BGRA output with 16-byte rows — a camera or decoder feed in a mosaic, the inset of BASELINE configs[3].
 // k_compositor_unscaled draws such a pad from a 4 x 4 block per lane with all sixteen running colours in registers (117 VGPRs, 4 waves
@@ -806,7 +909,13 @@ static bool comp_pad_overwrites (const VfHipPadInput &in)
   if (in.blend_mode == VFHIP_BLEND_SOURCE) return true;
   return in.blend_mode == VFHIP_BLEND_OVER && (float) in.alpha == 1.0f && f != VFHIP_FORMAT_RGBA && f != VFHIP_FORMAT_BGRA;
 }
-enum { COMP_KIND_LEAN, COMP_KIND_420, COMP_KIND_HEAVY };
+// a pad k_compositor_scaled can draw: RGBA / BGRA, scaled (a pad at its own size is sampled at exact texels: comp_sample)
+static bool comp_pad_rgba (const VfHipPadInput &in)
+{
+  return !comp_pad_unscaled (in) && (in.frame.info.format == VFHIP_FORMAT_RGBA || in.frame.info.format == VFHIP_FORMAT_BGRA) &&
+      !(((uintptr_t) in.frame.data[0] | (uintptr_t) in.frame.stride[0]) & 3);
+}
+enum { COMP_KIND_LEAN, COMP_KIND_420, COMP_KIND_SCALED, COMP_KIND_HEAVY };
 
 static void comp_fill_layer (CompLayer &L, const VfHipPadInput &in, size_t pitch)
 {
@@ -829,10 +938,12 @@ static int comp_launch_runs (VfHipCompositor *h, const VfHipPadInput *pads, int 
   const bool force_general = getenv ("VFHIP_COMP_GENERAL") != nullptr;       // test knobs: one kernel for every run, ...
   const bool no_lean = force_general || getenv ("VFHIP_COMP_NO_QUADS") != nullptr;       // ... no k_compositor_quads, ...
   const bool no_420 = force_general || getenv ("VFHIP_COMP_NO_420") != nullptr;          // ... no k_compositor_420, ...
+  const bool no_scaled = force_general || getenv ("VFHIP_COMP_NO_SCALED") != nullptr;    // ... no k_compositor_scaled, ...
   const bool no_cover = getenv ("VFHIP_COMP_NO_COVER") != nullptr;                       // ... draw what a later opaque pad hides
   auto kind_of = [&] (const VfHipPadInput &in) {
     if (!no_lean && comp_pad_lean (in)) return (int) COMP_KIND_LEAN;
     if (!no_420 && comp_pad_420 (in)) return (int) COMP_KIND_420;
+    if (!no_scaled && comp_pad_rgba (in)) return (int) COMP_KIND_SCALED;
     return (int) COMP_KIND_HEAVY;
   };
   int k = 0;
@@ -860,7 +971,7 @@ static int comp_launch_runs (VfHipCompositor *h, const VfHipPadInput *pads, int 
     if (first) {
       rx0 = 0; ry0 = 0; rx1 = w; ry1 = hh;
       // what later opaque pads overwrite completely need not be drawn by this launch (largest rectangles first)
-      if (!no_cover && kind != COMP_KIND_HEAVY) {
+      if (!no_cover && kind != COMP_KIND_HEAVY) {      // (the three run kernels test the rectangles; the samplers' kernels draw everything)
         struct R { int x0, y0, x1, y1; long long area; } best[COMP_MAX_COVER];
         int nb = 0;
         for (int j = k; j < count; j++) {
@@ -884,7 +995,7 @@ static int comp_launch_runs (VfHipCompositor *h, const VfHipPadInput *pads, int 
     first = false;
     if (!draw) continue;
     unscaled = unscaled && !force_general;
-    const int rows = kind == COMP_KIND_420 ? COMP420_ROWS : ((kind == COMP_KIND_LEAN || unscaled) ? COMP_ROWS : 2);
+    const int rows = kind == COMP_KIND_420 ? COMP420_ROWS : (kind == COMP_KIND_SCALED ? COMP_SROWS : ((kind == COMP_KIND_LEAN || unscaled) ? COMP_ROWS : 2));
     // whole 64-lane groups from a 256-pixel boundary keep the 16-byte lanes of a wave on one 1 KiB-aligned run of a row
     p.bx0 = (rx0 / 256) * 64; p.by0 = ry0 / rows;
     const int bx1 = (rx1 + 3) / 4, by1 = (ry1 + rows - 1) / rows;
@@ -898,6 +1009,7 @@ static int comp_launch_runs (VfHipCompositor *h, const VfHipPadInput *pads, int 
       if (p.background == COMP_BG_IN_PLACE ? opaque : flat_bg) hipLaunchKernelGGL (k_compositor_420<false>, grid, dim3 (64, 4), 0, s, p);
       else hipLaunchKernelGGL (k_compositor_420<true>, grid, dim3 (64, 4), 0, s, p);
     }
+    else if (kind == COMP_KIND_SCALED) hipLaunchKernelGGL (k_compositor_scaled, grid, dim3 (64, 4), 0, s, p);
     else if (unscaled) hipLaunchKernelGGL (k_compositor_unscaled, grid, dim3 (64, 4), 0, s, p);
     else hipLaunchKernelGGL (k_compositor, grid, dim3 (64, 4), 0, s, p);
     VFHIP_CHECK_HIP (hipGetLastError ());

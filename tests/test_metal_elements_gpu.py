@@ -621,6 +621,10 @@ def test_compositor_runs_of_pads(vfhip, metalref, ofmt, bg, monkeypatch):
     ncov = comp.composite(to_vf(vfhip, pads), background=bg)
     monkeypatch.delenv("VFHIP_COMP_NO_COVER")
     assert np.array_equal(got, ncov), "skipping what later opaque pads overwrite changed the picture"
+    monkeypatch.setenv("VFHIP_COMP_NO_SCALED", "1")
+    nsc = comp.composite(to_vf(vfhip, pads), background=bg)
+    monkeypatch.delenv("VFHIP_COMP_NO_SCALED")
+    assert np.array_equal(got, nsc), "the scaled-RGBA kernel differs from the general sampler"
     comp.close()
 
 
@@ -699,6 +703,34 @@ def test_compositor_many_opaque_tiles(vfhip, metalref, monkeypatch):
     for knob in ("VFHIP_COMP_NO_COVER", "VFHIP_COMP_NO_420", "VFHIP_COMP_NO_QUADS", "VFHIP_COMP_ONE_PASS"):
         monkeypatch.setenv(knob, "1")
         other = comp.composite(to_vf(vfhip, pads), background="white")
+        monkeypatch.delenv(knob)
+        assert np.array_equal(got, other), knob
+    comp.close()
+
+
+@pytest.mark.parametrize("ofmt", ["BGRA", "RGBA"])
+def test_compositor_multiviewer_scaled_pads(vfhip, metalref, ofmt, monkeypatch):
+    """feeds scaled into the tiles of a mosaic (k_compositor_scaled: RGBA / BGRA pads at any size), down- and up-scaled, odd
+    positions, overhanging the frame, translucent with per-pixel alpha, all three operators; NV12 feeds scaled by the general kernel"""
+    w, h = 640, 180
+    rng = np.random.default_rng(11)
+    pads = []
+    geo = [(0, 0, 320, 90, 640, 360), (320, 0, 320, 90, 333, 201), (0, 90, 320, 90, 96, 54), (320, 90, 320, 90, 640, 360),
+           (150, 40, 301, 77, 64, 48), (-33, -9, 120, 70, 50, 20), (600, 150, 90, 70, 200, 100), (317, 1, 7, 177, 3, 90)]
+    for k, (x, y, dw, dh, pw, ph) in enumerate(geo):
+        fmt = ["BGRA", "RGBA", "BGRA", "NV12", "RGBA", "BGRA", "I420", "RGBA"][k]
+        raw = smooth(fmt, pw, ph, 700 + k)
+        if fmt in ("BGRA", "RGBA") and k >= 4:
+            raw.reshape(-1, 4)[:, 3] = rng.integers(0, 256, pw * ph)
+        alpha, blend = [(1.0, 1), (1.0, 1), (0.9, 1), (1.0, 1), (0.7, 1), (1.0, 2), (0.5, 1), (1.0, 0)][k]
+        pads.append((fmt, pw, ph, raw, x, y, dw, dh, alpha, blend, bool(k & 1)))
+    comp = vfhip.Compositor(0)
+    comp.configure(ofmt, w, h)
+    got = comp.composite(to_vf(vfhip, pads), background="checker")
+    close(got, metalref.compositor(ofmt, w, h, pads, 0), f"multiviewer {ofmt}", max_off_by_one=0.05)
+    for knob in ("VFHIP_COMP_NO_SCALED", "VFHIP_COMP_GENERAL", "VFHIP_COMP_ONE_PASS", "VFHIP_COMP_NO_COVER"):
+        monkeypatch.setenv(knob, "1")
+        other = comp.composite(to_vf(vfhip, pads), background="checker")
         monkeypatch.delenv(knob)
         assert np.array_equal(got, other), knob
     comp.close()

@@ -35,9 +35,23 @@ nvq = [ring(NC, vfhip.plane_layout("NV12", 1920, 1080)[1], 30 + k) for k in rang
 for fmt in ("NV12", "I420"):
     qq = [comp.pad(fmt, 1920, 1080, nvq[k].data_ptr(), (k % 2) * 1920, (k // 2) * 1080, 1920, 1080, 1.0, "over", colorimetry="bt709") for k in range(4)]
     cases.append((f"4 {fmt} 1080p quadrants (over, 1.0)", qq, [nvq[0].shape[1]] * 4, "black"))
+# a multiviewer: four 1080p feeds scaled down to the quadrants of a 1080p output (every pad through the scaling sampler)
+mv_out = torch.empty((NC, 4 * 1920 * 1080), dtype=torch.uint8, device="cuda")
+MV = {}
+for fmt, src in (("BGRA", quads), ("NV12", nvq)):
+    qq = [comp.pad(fmt, 1920, 1080, src[k].data_ptr(), (k % 2) * 960, (k // 2) * 540, 960, 540, 1.0, "over", colorimetry="bt709") for k in range(4)]
+    MV[f"multiviewer: 4 {fmt} 1080p feeds scaled to 960x540 quadrants of a 1080p output"] = (qq, [src[0].shape[1]] * 4)
 for name, pads, pitches, bg in cases:
     def run():
         comp.composite_device(pads, out.data_ptr(), background=bg, stream=s.cuda_stream, n_frames=NC, pad_pitches=pitches, out_pitch=out.shape[1])
+    ms = timed(run, s, 10) / NC
+    print(json.dumps({"case": name, "us_per_frame": round(ms * 1e3, 2), "frames_per_s": round(1e3 / ms, 1)}), flush=True)
+comp.close()
+comp = vfhip.Compositor(0)
+comp.configure("BGRA", 1920, 1080)
+for name, (pads, pitches) in MV.items():
+    def run():
+        comp.composite_device(pads, mv_out.data_ptr(), background="black", stream=s.cuda_stream, n_frames=NC, pad_pitches=pitches, out_pitch=mv_out.shape[1])
     ms = timed(run, s, 10) / NC
     print(json.dumps({"case": name, "us_per_frame": round(ms * 1e3, 2), "frames_per_s": round(1e3 / ms, 1)}), flush=True)
 comp.close()
