@@ -137,6 +137,31 @@ __device__ __forceinline__ void cs_convert8_nv12 (const CsParams &p, const uint8
   }
 }
 
+// ---- k_cs_nv12_same<COSITED>: NV12 -> BGRA / RGBA at the SAME size ------------------------------------------------------------------
+// The element as a plain converter (a decoder's NV12 to RGB for display or inference, no scaling): videoscale passes through and
+// what is left is videoconvert's chroma up-sampling and matrix.  k_cs_taps ran this shape as a 2-tap scale with unit weights — four
+// conversions per output pixel, byte-wise: 12.1 us for a 1080p frame, 49.5 us for 2160p (0.12 of the roofline).  Here one lane =
+// eight adjacent pixels of one row: cs_convert8_nv12 (one 8-byte luma load, the two chroma rows of the pixel's vertical filter with
+// their neighbour pairs, the packed ORC pipeline of the 2:1 kernel) and two 16-byte non-temporal stores.  A wave covers 512
+// consecutive pixels of a row; the chroma rows are fetched by the luma rows that lean on them (L2 hits).
+// Contract (checked by the host): width % 8 == 0, 8-byte aligned planes / strides / pitch, 16-byte aligned output.
+template <bool COSITED>
+__global__ __launch_bounds__ (256) void k_cs_nv12_same (const CsParams p)
+{
+  const int groups = p.in_w >> 3;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= groups * p.in_h) return;
+  const int row = t / groups, g = t - row * groups;
+  const uint8_t *in[3] = { p.in[0] + (size_t) blockIdx.y * p.in_pitch, p.in[1] + (size_t) blockIdx.y * p.in_pitch, nullptr };
+  uint32_t px[8];
+  cs_convert8_nv12<COSITED> (p, in, 8 * g, row, px);
+  typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
+  v4u *d = reinterpret_cast<v4u *> (p.out + (size_t) blockIdx.y * p.out_pitch + (size_t) row * p.os) + 2 * g;
+  const v4u a = { px[0], px[1], px[2], px[3] }, b = { px[4], px[5], px[6], px[7] };
+  __builtin_nontemporal_store (a, d);
+  __builtin_nontemporal_store (b, d + 1);
+}
+
 struct CubicTileParams {
   CsParams cs;                       // input planes / strides / matrix / formats for cs_tap; in_pitch, out_pitch for batches
   uint8_t *out; int os;

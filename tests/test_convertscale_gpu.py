@@ -765,3 +765,59 @@ def test_matrix_change_hd_vs_oracle_and_batch(vfhip, oracle, ifmt, ofmt, w, h, o
         assert np.array_equal(meaningful(ofmt, ow, oh, out[k, :osz]), meaningful(ofmt, ow, oh, want)), f"frame {k}"
         assert np.array_equal(meaningful(ofmt, ow, oh, cs.process(frames[k])), meaningful(ofmt, ow, oh, want))
     cs.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h", [(64, 36), (200, 113), (16, 3), (1920, 1080), (24, 2), (136, 77)])
+@pytest.mark.parametrize("col,site", [("bt601", "jpeg"), ("bt709", "mpeg2"), ("bt2020", "mpeg2")])
+def test_nv12_same_size_conversion(vfhip, oracle, w, h, col, site, monkeypatch):
+    """the element as a plain converter: NV12 -> BGRA / RGBA at the same size runs k_cs_nv12_same (eight pixels per lane) — against the
+    oracle, against the generic kernel it replaces, for both scaling methods (videoscale passes through either way), odd heights included"""
+    rng = np.random.default_rng(w * 7 + h)
+    raw = rng.integers(0, 256, vfhip.plane_layout("NV12", w, h)[1], dtype=np.uint8)
+    for ofmt in ("BGRA", "RGBA"):
+        want = oracle.convertscale("NV12", w, h, raw, col, site, "bilinear", ofmt, w, h)
+        for method in ("bilinear", "nearest"):
+            got, kname = run(vfhip, "NV12", w, h, raw, col, site, method, ofmt, w, h)
+            assert kname == "k_cs_nv12_same", kname
+            assert np.array_equal(got, want), (ofmt, method)
+        monkeypatch.setenv("VFHIP_NO_SAME", "1")
+        old, kname = run(vfhip, "NV12", w, h, raw, col, site, "bilinear", ofmt, w, h)
+        monkeypatch.delenv("VFHIP_NO_SAME")
+        assert kname == "k_cs_taps" and np.array_equal(old, want)
+
+
+@pytest.mark.gpu
+def test_nv12_same_size_batch_and_unaligned_fallback(vfhip, oracle):
+    """a batch through k_cs_nv12_same on the device path, and a frame whose planes miss the kernel's alignment contract (the generic
+    kernel must take over for that call and produce the same bytes)"""
+    import torch
+    w, h, n = 320, 90, 3
+    rng = np.random.default_rng(8)
+    size = vfhip.plane_layout("NV12", w, h)[1]
+    frames = [rng.integers(0, 256, size, dtype=np.uint8) for _ in range(n)]
+    want = [oracle.convertscale("NV12", w, h, f, "bt709", "mpeg2", "bilinear", "BGRA", w, h) for f in frames]
+    cs = vfhip.ConvertScale(0)
+    cs.configure("NV12", w, h, "BGRA", w, h, colorimetry="bt709", chroma_site="mpeg2")
+    assert cs.kernel_name == "k_cs_nv12_same"
+    pitch = (size + 255) // 256 * 256
+    ring = np.zeros((n, pitch), np.uint8)
+    for k, f in enumerate(frames):
+        ring[k, :size] = f
+    din, dout = torch.from_numpy(ring).cuda(), torch.zeros((n, w * h * 4), dtype=torch.uint8, device="cuda")
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    cs.process_device(din.data_ptr(), dout.data_ptr(), stream=s.cuda_stream, n_frames=n, in_pitch=pitch, out_pitch=w * h * 4)
+    s.synchronize()
+    out = dout.cpu().numpy()
+    for k in range(n):
+        assert np.array_equal(out[k].reshape(h, w, 4), want[k].reshape(h, w, 4)), k
+    # the input 4 bytes off an 8-byte boundary
+    flat = torch.zeros(size + 64, dtype=torch.uint8, device="cuda")
+    flat[4:4 + size] = torch.from_numpy(frames[0]).cuda()
+    one = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    cs.process_device(flat.data_ptr() + 4, one.data_ptr(), stream=s.cuda_stream)
+    s.synchronize()
+    assert np.array_equal(one.cpu().numpy().reshape(h, w, 4), want[0].reshape(h, w, 4))
+    cs.close()
