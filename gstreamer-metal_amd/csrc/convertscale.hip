@@ -55,7 +55,7 @@ struct VfHipConvertScale {
   int vfirst = 1, hscale_on = 0;
   uint32_t hinc = 0;
   enum Kernel { K_NONE, K_HALF, K_GENERIC, K_TAPS, K_METAL, K_STAGED, K_NTAP, K_SAME } kernel = K_NONE;
-  Kernel same_fallback = K_NONE;    // K_SAME: what runs instead when a frame misses k_cs_nv12_same's alignment contract
+  Kernel same_fallback = K_NONE;    // K_SAME: what runs instead when a frame misses k_cs_yuv_same's alignment contract
   const char *kernel_name = "none";
   // K_STAGED: videoconvert at the input size into `mid` (when the format changes), then per-plane videoscale
   PlaneCfg plane[3];
@@ -542,12 +542,12 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
   const bool half = in_yuv && method == VFHIP_SCALE_BILINEAR && !h->add_borders &&
                     in->width == 2 * out->width && in->height == 2 * out->height && (out->width % 4) == 0 && out->height >= 3;
   const bool taps = in_yuv && method == VFHIP_SCALE_BILINEAR && in->width >= 8;
-  // conversion only: NV12 at the output's size, nothing to scale and no borders (bilinear or nearest: videoscale passes through either way)
-  const bool same = in->format == VFHIP_FORMAT_NV12 && method != VFHIP_SCALE_BICUBIC && in->width == out->width && in->height == out->height &&
+  // conversion only: NV12 / I420 at the output's size, nothing to scale and no borders (bilinear or nearest: videoscale passes through either way)
+  const bool same = (in->format == VFHIP_FORMAT_NV12 || in->format == VFHIP_FORMAT_I420) && method != VFHIP_SCALE_BICUBIC && in->width == out->width && in->height == out->height &&
                     h->rw == out->width && h->rh == out->height && (in->width % 8) == 0 && in->width >= 16 && getenv ("VFHIP_NO_SAME") == nullptr;
   if (half) { h->kernel = VfHipConvertScale::K_HALF; h->kernel_name = in->format == VFHIP_FORMAT_I420 ? "k_cs_i420_half" : "k_cs_nv12_half"; }
   else if (same) {
-    h->kernel = VfHipConvertScale::K_SAME; h->kernel_name = "k_cs_nv12_same";
+    h->kernel = VfHipConvertScale::K_SAME; h->kernel_name = in->format == VFHIP_FORMAT_I420 ? "k_cs_i420_same" : "k_cs_nv12_same";
     h->same_fallback = taps ? VfHipConvertScale::K_TAPS : VfHipConvertScale::K_GENERIC;
   }
   else if (taps) { h->kernel = VfHipConvertScale::K_TAPS; h->kernel_name = "k_cs_taps"; }
@@ -928,16 +928,19 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
   }
   bool same = h->kernel == VfHipConvertScale::K_SAME;
   if (same) {
-    const uintptr_t a = (uintptr_t) p.in[0] | (uintptr_t) p.in[1] | (uintptr_t) p.is[0] | (uintptr_t) p.is[1] | (uintptr_t) in_pitch;
+    const bool i420 = p.in_fmt == VFHIP_FORMAT_I420;
+    const uintptr_t luma = (uintptr_t) p.in[0] | (uintptr_t) p.is[0] | (uintptr_t) in_pitch;
+    const uintptr_t chroma = (uintptr_t) p.in[1] | (uintptr_t) p.is[1] | (i420 ? (uintptr_t) p.in[2] | (uintptr_t) p.is[2] : 0);
     const uintptr_t b = (uintptr_t) p.out | (uintptr_t) p.os | (uintptr_t) out_pitch;
-    if ((a & 7) || (b & 15)) same = false;                         // the generic kernels compute the same bytes
+    if ((luma & 7) || (chroma & (i420 ? 3 : 7)) || (b & 15)) same = false;      // the generic kernels compute the same bytes
   }
   if (half) {
     launch_half (p, n_frames, h->dev->n_cu, s);
   } else if (same) {
     dim3 grid ((unsigned) (((size_t) (p.in_w >> 3) * p.in_h + 255) / 256), (unsigned) n_frames);
-    if (p.cosited) hipLaunchKernelGGL (k_cs_nv12_same<true>, grid, dim3 (256), 0, s, p);
-    else hipLaunchKernelGGL (k_cs_nv12_same<false>, grid, dim3 (256), 0, s, p);
+    if (p.in_fmt == VFHIP_FORMAT_I420) hipLaunchKernelGGL ((k_cs_yuv_same<true, false>), grid, dim3 (256), 0, s, p);
+    else if (p.cosited) hipLaunchKernelGGL ((k_cs_yuv_same<false, true>), grid, dim3 (256), 0, s, p);
+    else hipLaunchKernelGGL ((k_cs_yuv_same<false, false>), grid, dim3 (256), 0, s, p);
   } else {
     dim3 grid ((unsigned) ((p.out_w + 63) / 64), (unsigned) ((p.out_h + 3) / 4), (unsigned) n_frames);
     // window loads need >= 2 luma columns and >= 4 chroma pairs per row; tiny frames and nearest / RGB inputs use k_cs_generic

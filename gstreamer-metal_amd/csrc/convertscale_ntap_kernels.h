@@ -137,24 +137,52 @@ __device__ __forceinline__ void cs_convert8_nv12 (const CsParams &p, const uint8
   }
 }
 
-// ---- k_cs_nv12_same<COSITED>: NV12 -> BGRA / RGBA at the SAME size ------------------------------------------------------------------
-// The element as a plain converter (a decoder's NV12 to RGB for display or inference, no scaling): videoscale passes through and
+// the same for I420: GStreamer's I420 fast path replicates the chroma sample of row cy >> 1 to its two columns and two rows (nearest:
+// oracle/gst114.c gst114_yuv420_to_rgb, planar = 1), so a group is one 8-byte luma load and one 4-byte load from each chroma plane.
+// Requires 8-byte aligned luma and 4-byte aligned chroma planes / strides, gx % 8 == 0 and gx + 8 <= in_w.
+__device__ __forceinline__ void cs_convert8_i420 (const CsParams &p, const uint8_t *const in[3], int gx, int cy, uint32_t out[8])
+{
+  const uint32_t X = 0x80808080u;
+  const size_t j = (size_t) (cy >> 1);
+  const uint32_t U4 = *reinterpret_cast<const uint32_t *> (in[1] + j * p.is[1] + (gx >> 1)) ^ X;
+  const uint32_t V4 = *reinterpret_cast<const uint32_t *> (in[2] + j * p.is[2] + (gx >> 1)) ^ X;
+  const uint2 yv = *reinterpret_cast<const uint2 *> (in[0] + (size_t) cy * p.is[0] + gx);
+  const uint32_t y0 = yv.x ^ X, y1 = yv.y ^ X;
+  const int bias = 128 << 16;
+#pragma unroll
+  for (int n = 0; n < 4; n++) {
+    const uint32_t sel = (n & 1) ? 0x03030202u : 0x01010000u;
+    const uint32_t uv = perm_b32 (V4, U4, (uint32_t) (((4 + n) << 24) | ((4 + n) << 16) | (n << 8) | n));       // [U_n U_n V_n V_n]
+    uint32_t bb, gg, rr;
+    orc_pair (perm_b32 (0u, n < 2 ? y0 : y1, sel), uv, uv, p.c, bias, bb, gg, rr);
+    const uint32_t x = p.out_rgba ? rr : bb, z = p.out_rgba ? bb : rr;        // byte 0 / byte 2 channel
+    const uint32_t xg = perm_b32 (gg, x, 0x05010400u);                          // [x_e, g_e, x_o, g_o]
+    const uint32_t za = perm_b32 (0xffffffffu, z, 0x07010700u);                 // [z_e, ff, z_o, ff]
+    out[2 * n] = perm_b32 (za, xg, 0x05040100u);                                // [x_e, g_e, z_e, ff]
+    out[2 * n + 1] = perm_b32 (za, xg, 0x07060302u);                            // [x_o, g_o, z_o, ff]
+  }
+}
+
+// ---- k_cs_yuv_same<I420, COSITED>: NV12 / I420 -> BGRA / RGBA at the SAME size -----------------------------------------------------
+// The element as a plain converter (a decoder's NV12 / I420 to RGB for display or inference, no scaling): videoscale passes through and
 // what is left is videoconvert's chroma up-sampling and matrix.  k_cs_taps ran this shape as a 2-tap scale with unit weights — four
-// conversions per output pixel, byte-wise: 12.1 us for a 1080p frame, 49.5 us for 2160p (0.12 of the roofline).  Here one lane =
+// conversions per output pixel, byte-wise: 12.1 us for a 1080p NV12 frame, 49.5 us for 2160p (0.12 of the roofline).  Here one lane =
 // eight adjacent pixels of one row: cs_convert8_nv12 (one 8-byte luma load, the two chroma rows of the pixel's vertical filter with
-// their neighbour pairs, the packed ORC pipeline of the 2:1 kernel) and two 16-byte non-temporal stores.  A wave covers 512
-// consecutive pixels of a row; the chroma rows are fetched by the luma rows that lean on them (L2 hits).
-// Contract (checked by the host): width % 8 == 0, 8-byte aligned planes / strides / pitch, 16-byte aligned output.
-template <bool COSITED>
-__global__ __launch_bounds__ (256) void k_cs_nv12_same (const CsParams p)
+// their neighbour pairs, the packed ORC pipeline of the 2:1 kernel) or cs_convert8_i420, and two 16-byte non-temporal stores.  A
+// wave covers 512 consecutive pixels of a row; the chroma rows are fetched by the luma rows that lean on them (L2 hits).
+// Contract (checked by the host): width % 8 == 0, 8-byte aligned planes / strides / pitch (I420 chroma: 4-byte), 16-byte aligned output.
+template <bool I420, bool COSITED>
+__global__ __launch_bounds__ (256) void k_cs_yuv_same (const CsParams p)
 {
   const int groups = p.in_w >> 3;
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= groups * p.in_h) return;
   const int row = t / groups, g = t - row * groups;
-  const uint8_t *in[3] = { p.in[0] + (size_t) blockIdx.y * p.in_pitch, p.in[1] + (size_t) blockIdx.y * p.in_pitch, nullptr };
+  const size_t fo = (size_t) blockIdx.y * p.in_pitch;
+  const uint8_t *in[3] = { p.in[0] + fo, p.in[1] + fo, I420 ? p.in[2] + fo : nullptr };
   uint32_t px[8];
-  cs_convert8_nv12<COSITED> (p, in, 8 * g, row, px);
+  if (I420) cs_convert8_i420 (p, in, 8 * g, row, px);
+  else cs_convert8_nv12<COSITED> (p, in, 8 * g, row, px);
   typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
   v4u *d = reinterpret_cast<v4u *> (p.out + (size_t) blockIdx.y * p.out_pitch + (size_t) row * p.os) + 2 * g;
   const v4u a = { px[0], px[1], px[2], px[3] }, b = { px[4], px[5], px[6], px[7] };

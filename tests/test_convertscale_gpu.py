@@ -768,21 +768,22 @@ def test_matrix_change_hd_vs_oracle_and_batch(vfhip, oracle, ifmt, ofmt, w, h, o
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ifmt", ["NV12", "I420"])
 @pytest.mark.parametrize("w,h", [(64, 36), (200, 113), (16, 3), (1920, 1080), (24, 2), (136, 77)])
 @pytest.mark.parametrize("col,site", [("bt601", "jpeg"), ("bt709", "mpeg2"), ("bt2020", "mpeg2")])
-def test_nv12_same_size_conversion(vfhip, oracle, w, h, col, site, monkeypatch):
-    """the element as a plain converter: NV12 -> BGRA / RGBA at the same size runs k_cs_nv12_same (eight pixels per lane) — against the
-    oracle, against the generic kernel it replaces, for both scaling methods (videoscale passes through either way), odd heights included"""
+def test_yuv420_same_size_conversion(vfhip, oracle, ifmt, w, h, col, site, monkeypatch):
+    """the element as a plain converter: NV12 / I420 -> BGRA / RGBA at the same size runs k_cs_yuv_same (eight pixels per lane) — against
+    the oracle, against the generic kernel it replaces, for both scaling methods (videoscale passes through either way), odd heights included"""
     rng = np.random.default_rng(w * 7 + h)
-    raw = rng.integers(0, 256, vfhip.plane_layout("NV12", w, h)[1], dtype=np.uint8)
+    raw = rng.integers(0, 256, vfhip.plane_layout(ifmt, w, h)[1], dtype=np.uint8)
     for ofmt in ("BGRA", "RGBA"):
-        want = oracle.convertscale("NV12", w, h, raw, col, site, "bilinear", ofmt, w, h)
+        want = oracle.convertscale(ifmt, w, h, raw, col, site, "bilinear", ofmt, w, h)
         for method in ("bilinear", "nearest"):
-            got, kname = run(vfhip, "NV12", w, h, raw, col, site, method, ofmt, w, h)
-            assert kname == "k_cs_nv12_same", kname
+            got, kname = run(vfhip, ifmt, w, h, raw, col, site, method, ofmt, w, h)
+            assert kname == ("k_cs_nv12_same" if ifmt == "NV12" else "k_cs_i420_same"), kname
             assert np.array_equal(got, want), (ofmt, method)
         monkeypatch.setenv("VFHIP_NO_SAME", "1")
-        old, kname = run(vfhip, "NV12", w, h, raw, col, site, "bilinear", ofmt, w, h)
+        old, kname = run(vfhip, ifmt, w, h, raw, col, site, "bilinear", ofmt, w, h)
         monkeypatch.delenv("VFHIP_NO_SAME")
         assert kname == "k_cs_taps" and np.array_equal(old, want)
 
