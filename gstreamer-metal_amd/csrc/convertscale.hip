@@ -542,12 +542,12 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
   const bool half = in_yuv && method == VFHIP_SCALE_BILINEAR && !h->add_borders &&
                     in->width == 2 * out->width && in->height == 2 * out->height && (out->width % 4) == 0 && out->height >= 3;
   const bool taps = in_yuv && method == VFHIP_SCALE_BILINEAR && in->width >= 8;
-  // conversion only: NV12 / I420 at the output's size, nothing to scale and no borders (bilinear or nearest: videoscale passes through either way)
-  const bool same = (in->format == VFHIP_FORMAT_NV12 || in->format == VFHIP_FORMAT_I420) && method != VFHIP_SCALE_BICUBIC && in->width == out->width && in->height == out->height &&
+  // conversion only: NV12 / I420 / UYVY / YUY2 at the output's size, nothing to scale and no borders (bilinear or nearest: videoscale passes through either way)
+  const bool same = any_yuv_in && method != VFHIP_SCALE_BICUBIC && in->width == out->width && in->height == out->height &&
                     h->rw == out->width && h->rh == out->height && (in->width % 8) == 0 && in->width >= 16 && getenv ("VFHIP_NO_SAME") == nullptr;
   if (half) { h->kernel = VfHipConvertScale::K_HALF; h->kernel_name = in->format == VFHIP_FORMAT_I420 ? "k_cs_i420_half" : "k_cs_nv12_half"; }
   else if (same) {
-    h->kernel = VfHipConvertScale::K_SAME; h->kernel_name = in->format == VFHIP_FORMAT_I420 ? "k_cs_i420_same" : "k_cs_nv12_same";
+    h->kernel = VfHipConvertScale::K_SAME; h->kernel_name = in->format == VFHIP_FORMAT_I420 ? "k_cs_i420_same" : (in->format == VFHIP_FORMAT_NV12 ? "k_cs_nv12_same" : (in->format == VFHIP_FORMAT_UYVY ? "k_cs_uyvy_same" : "k_cs_yuy2_same"));
     h->same_fallback = taps ? VfHipConvertScale::K_TAPS : VfHipConvertScale::K_GENERIC;
   }
   else if (taps) { h->kernel = VfHipConvertScale::K_TAPS; h->kernel_name = "k_cs_taps"; }
@@ -928,19 +928,20 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
   }
   bool same = h->kernel == VfHipConvertScale::K_SAME;
   if (same) {
-    const bool i420 = p.in_fmt == VFHIP_FORMAT_I420;
+    const bool i420 = p.in_fmt == VFHIP_FORMAT_I420, packed = p.in_fmt == VFHIP_FORMAT_UYVY || p.in_fmt == VFHIP_FORMAT_YUY2;
     const uintptr_t luma = (uintptr_t) p.in[0] | (uintptr_t) p.is[0] | (uintptr_t) in_pitch;
-    const uintptr_t chroma = (uintptr_t) p.in[1] | (uintptr_t) p.is[1] | (i420 ? (uintptr_t) p.in[2] | (uintptr_t) p.is[2] : 0);
+    const uintptr_t chroma = packed ? 0 : ((uintptr_t) p.in[1] | (uintptr_t) p.is[1] | (i420 ? (uintptr_t) p.in[2] | (uintptr_t) p.is[2] : 0));
     const uintptr_t b = (uintptr_t) p.out | (uintptr_t) p.os | (uintptr_t) out_pitch;
-    if ((luma & 7) || (chroma & (i420 ? 3 : 7)) || (b & 15)) same = false;      // the generic kernels compute the same bytes
+    if ((luma & (packed ? 15 : 7)) || (chroma & (i420 ? 3 : 7)) || (b & 15)) same = false;      // the generic kernels compute the same bytes
   }
   if (half) {
     launch_half (p, n_frames, h->dev->n_cu, s);
   } else if (same) {
     dim3 grid ((unsigned) (((size_t) (p.in_w >> 3) * p.in_h + 255) / 256), (unsigned) n_frames);
-    if (p.in_fmt == VFHIP_FORMAT_I420) hipLaunchKernelGGL ((k_cs_yuv_same<true, false>), grid, dim3 (256), 0, s, p);
-    else if (p.cosited) hipLaunchKernelGGL ((k_cs_yuv_same<false, true>), grid, dim3 (256), 0, s, p);
-    else hipLaunchKernelGGL ((k_cs_yuv_same<false, false>), grid, dim3 (256), 0, s, p);
+    const int f = p.in_fmt == VFHIP_FORMAT_NV12 ? 0 : (p.in_fmt == VFHIP_FORMAT_I420 ? 1 : (p.in_fmt == VFHIP_FORMAT_UYVY ? 2 : 3));
+#define VF_SAME(F) { if (p.cosited) hipLaunchKernelGGL ((k_cs_yuv_same<F, true>), grid, dim3 (256), 0, s, p); else hipLaunchKernelGGL ((k_cs_yuv_same<F, false>), grid, dim3 (256), 0, s, p); }
+    if (f == 0) VF_SAME (0) else if (f == 1) hipLaunchKernelGGL ((k_cs_yuv_same<1, false>), grid, dim3 (256), 0, s, p); else if (f == 2) VF_SAME (2) else VF_SAME (3)
+#undef VF_SAME
   } else {
     dim3 grid ((unsigned) ((p.out_w + 63) / 64), (unsigned) ((p.out_h + 3) / 4), (unsigned) n_frames);
     // window loads need >= 2 luma columns and >= 4 chroma pairs per row; tiny frames and nearest / RGB inputs use k_cs_generic

@@ -163,15 +163,51 @@ __device__ __forceinline__ void cs_convert8_i420 (const CsParams &p, const uint8
   }
 }
 
-// ---- k_cs_yuv_same<I420, COSITED>: NV12 / I420 -> BGRA / RGBA at the SAME size -----------------------------------------------------
+// ... and for packed 4:2:2 (UYVY: U Y0 V Y1, YUY2: Y0 U Y1 V): eight pixels are one 16-byte load; the chroma pairs and the luma bytes
+// come apart with four byte permutes, the row's chroma is up-sampled horizontally with NV12's rule (hfilter; there is no vertical
+// step: oracle/gst114.c gst114_packed422_to_rgb), then the ORC matrix.  The neighbour chroma pairs are the macro-pixels 4 bytes before
+// and 16 bytes after the group, replicated at the ends of the row.  Requires 16-byte aligned rows, gx % 8 == 0 and gx + 8 <= in_w.
+template <bool YUY2, bool COSITED>
+__device__ __forceinline__ void cs_convert8_packed (const CsParams &p, const uint8_t *const in[3], int gx, int cy, uint32_t out[8])
+{
+  const uint32_t X = 0x80808080u;
+  const uint8_t *row = in[0] + (size_t) cy * p.is[0] + 2 * gx;
+  const uint4 m = *reinterpret_cast<const uint4 *> (row);
+  const uint32_t csel = YUY2 ? 0x07050301u : 0x06040200u, ysel = YUY2 ? 0x06040200u : 0x07050301u, psel = YUY2 ? 0x0c0c0301u : 0x0c0c0200u;
+  CRaw r;
+  r.v.x = perm_b32 (m.y, m.x, csel); r.v.y = perm_b32 (m.w, m.z, csel);              // [U0V0U1V1][U2V2U3V3]
+  const bool last = gx + 8 >= p.in_w, first = gx == 0;
+  const uint32_t rd = *reinterpret_cast<const uint32_t *> (row + (last ? 12 : 16)), ld = *reinterpret_cast<const uint32_t *> (row - (first ? 0 : 4));
+  r.right = perm_b32 (0u, rd, psel);                                                 // the next macro-pixel's (U, V); the row's last one is its own
+  r.left = perm_b32 (0u, ld, psel);
+  const CRow c = hfilter<COSITED> (r);
+  const uint32_t e01 = c.e01 ^ X, e23 = c.e23 ^ X, o01 = c.o01 ^ X, o23 = c.o23 ^ X;
+  const uint32_t y0 = perm_b32 (m.y, m.x, ysel) ^ X, y1 = perm_b32 (m.w, m.z, ysel) ^ X;
+  const int bias = 128 << 16;
+#pragma unroll
+  for (int n = 0; n < 4; n++) {
+    const uint32_t sel = (n & 1) ? 0x03030202u : 0x01010000u;
+    const uint32_t yn = n < 2 ? y0 : y1, en = n < 2 ? e01 : e23, on = n < 2 ? o01 : o23;
+    uint32_t bb, gg, rr;
+    orc_pair (perm_b32 (0u, yn, sel), perm_b32 (0u, en, sel), perm_b32 (0u, on, sel), p.c, bias, bb, gg, rr);
+    const uint32_t x = p.out_rgba ? rr : bb, z = p.out_rgba ? bb : rr;        // byte 0 / byte 2 channel
+    const uint32_t xg = perm_b32 (gg, x, 0x05010400u);                          // [x_e, g_e, x_o, g_o]
+    const uint32_t za = perm_b32 (0xffffffffu, z, 0x07010700u);                 // [z_e, ff, z_o, ff]
+    out[2 * n] = perm_b32 (za, xg, 0x05040100u);                                // [x_e, g_e, z_e, ff]
+    out[2 * n + 1] = perm_b32 (za, xg, 0x07060302u);                            // [x_o, g_o, z_o, ff]
+  }
+}
+
+// ---- k_cs_yuv_same<FMT, COSITED>: NV12 / I420 / UYVY / YUY2 -> BGRA / RGBA at the SAME size -----------------------------------------------------
 // The element as a plain converter (a decoder's NV12 / I420 to RGB for display or inference, no scaling): videoscale passes through and
 // what is left is videoconvert's chroma up-sampling and matrix.  k_cs_taps ran this shape as a 2-tap scale with unit weights — four
 // conversions per output pixel, byte-wise: 12.1 us for a 1080p NV12 frame, 49.5 us for 2160p (0.12 of the roofline).  Here one lane =
 // eight adjacent pixels of one row: cs_convert8_nv12 (one 8-byte luma load, the two chroma rows of the pixel's vertical filter with
-// their neighbour pairs, the packed ORC pipeline of the 2:1 kernel) or cs_convert8_i420, and two 16-byte non-temporal stores.  A
+// their neighbour pairs, the packed ORC pipeline of the 2:1 kernel), cs_convert8_i420 or cs_convert8_packed, and two 16-byte non-temporal stores.  A
 // wave covers 512 consecutive pixels of a row; the chroma rows are fetched by the luma rows that lean on them (L2 hits).
-// Contract (checked by the host): width % 8 == 0, 8-byte aligned planes / strides / pitch (I420 chroma: 4-byte), 16-byte aligned output.
-template <bool I420, bool COSITED>
+// Contract (checked by the host): width % 8 == 0, 8-byte aligned planes / strides / pitch (I420 chroma: 4-byte; packed: 16-byte), 16-byte aligned output.
+// FMT: 0 NV12, 1 I420, 2 UYVY, 3 YUY2
+template <int FMT, bool COSITED>
 __global__ __launch_bounds__ (256) void k_cs_yuv_same (const CsParams p)
 {
   const int groups = p.in_w >> 3;
@@ -179,10 +215,11 @@ __global__ __launch_bounds__ (256) void k_cs_yuv_same (const CsParams p)
   if (t >= groups * p.in_h) return;
   const int row = t / groups, g = t - row * groups;
   const size_t fo = (size_t) blockIdx.y * p.in_pitch;
-  const uint8_t *in[3] = { p.in[0] + fo, p.in[1] + fo, I420 ? p.in[2] + fo : nullptr };
+  const uint8_t *in[3] = { p.in[0] + fo, FMT <= 1 ? p.in[1] + fo : nullptr, FMT == 1 ? p.in[2] + fo : nullptr };
   uint32_t px[8];
-  if (I420) cs_convert8_i420 (p, in, 8 * g, row, px);
-  else cs_convert8_nv12<COSITED> (p, in, 8 * g, row, px);
+  if (FMT == 1) cs_convert8_i420 (p, in, 8 * g, row, px);
+  else if (FMT == 0) cs_convert8_nv12<COSITED> (p, in, 8 * g, row, px);
+  else cs_convert8_packed<FMT == 3, COSITED> (p, in, 8 * g, row, px);
   typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
   v4u *d = reinterpret_cast<v4u *> (p.out + (size_t) blockIdx.y * p.out_pitch + (size_t) row * p.os) + 2 * g;
   const v4u a = { px[0], px[1], px[2], px[3] }, b = { px[4], px[5], px[6], px[7] };

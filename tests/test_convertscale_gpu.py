@@ -300,7 +300,7 @@ def test_golden_gstreamer_vectors_packed_inputs(vfhip, case):
     raw, want = ZP[case["name"] + "_in"], ZP[case["name"] + "_out"]
     got, kname = run(vfhip, case["in_format"], case["w"], case["h"], raw, case["colorimetry"], case["chroma_site"], case["method"],
                      case["out_format"], case["ow"], case["oh"])
-    assert kname in ("k_cs_generic", "k_cs_cubic_tile", "k_cs_ntap")            # never the metal arithmetic
+    assert kname in ("k_cs_generic", "k_cs_cubic_tile", "k_cs_ntap", "k_cs_uyvy_same", "k_cs_yuy2_same")            # never the metal arithmetic
     assert np.array_equal(got.reshape(-1), want), f"{kname}: {(got.reshape(-1) != want).sum()} bytes differ"
 
 
@@ -768,7 +768,7 @@ def test_matrix_change_hd_vs_oracle_and_batch(vfhip, oracle, ifmt, ofmt, w, h, o
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ifmt", ["NV12", "I420"])
+@pytest.mark.parametrize("ifmt", ["NV12", "I420", "UYVY", "YUY2"])
 @pytest.mark.parametrize("w,h", [(64, 36), (200, 113), (16, 3), (1920, 1080), (24, 2), (136, 77)])
 @pytest.mark.parametrize("col,site", [("bt601", "jpeg"), ("bt709", "mpeg2"), ("bt2020", "mpeg2")])
 def test_yuv420_same_size_conversion(vfhip, oracle, ifmt, w, h, col, site, monkeypatch):
@@ -780,12 +780,12 @@ def test_yuv420_same_size_conversion(vfhip, oracle, ifmt, w, h, col, site, monke
         want = oracle.convertscale(ifmt, w, h, raw, col, site, "bilinear", ofmt, w, h)
         for method in ("bilinear", "nearest"):
             got, kname = run(vfhip, ifmt, w, h, raw, col, site, method, ofmt, w, h)
-            assert kname == ("k_cs_nv12_same" if ifmt == "NV12" else "k_cs_i420_same"), kname
+            assert kname == f"k_cs_{ifmt.lower()}_same", kname
             assert np.array_equal(got, want), (ofmt, method)
         monkeypatch.setenv("VFHIP_NO_SAME", "1")
         old, kname = run(vfhip, ifmt, w, h, raw, col, site, "bilinear", ofmt, w, h)
         monkeypatch.delenv("VFHIP_NO_SAME")
-        assert kname == "k_cs_taps" and np.array_equal(old, want)
+        assert kname == ("k_cs_taps" if ifmt in ("NV12", "I420") else "k_cs_generic") and np.array_equal(old, want)
 
 
 @pytest.mark.gpu
