@@ -355,7 +355,8 @@ typedef uint16_t __attribute__ ((aligned (1))) uint16_a1;
 template <bool I420>
 __global__ __launch_bounds__ (256) void k_cs_taps (const CsParams p)
 {
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  const int x = blockIdx.x * 64 + threadIdx.x;
+  const int y = __builtin_amdgcn_readfirstlane ((int) (blockIdx.y * 4 + threadIdx.y));        // one row per wave: the row's taps are scalar loads
   if (x >= p.out_w || y >= p.out_h) return;
   const uint8_t *yp = p.in[0] + (size_t) blockIdx.z * p.in_pitch;
   const uint8_t *up = p.in[1] + (size_t) blockIdx.z * p.in_pitch;
@@ -363,7 +364,8 @@ __global__ __launch_bounds__ (256) void k_cs_taps (const CsParams p)
   uint32_t *o = reinterpret_cast<uint32_t *> (p.out + (size_t) blockIdx.z * p.out_pitch + (size_t) y * p.os) + x;
   const int dx = x - p.rx, dy = y - p.ry;
   if (dx < 0 || dy < 0 || dx >= p.rw || dy >= p.rh) { *o = p.border; return; }
-  const int i0 = p.vtab[4 * dy], i1 = p.vtab[4 * dy + 1], w = p.vtab[4 * dy + 2];
+  // the row's taps are the same for the whole wave: as scalars, so that the row addresses below are scalar arithmetic
+  const int i0 = __builtin_amdgcn_readfirstlane (p.vtab[4 * dy]), i1 = __builtin_amdgcn_readfirstlane (p.vtab[4 * dy + 1]), w = __builtin_amdgcn_readfirstlane (p.vtab[4 * dy + 2]);
   int xa = dx, xb = dx, f = 0;
   if (p.hscale_on) {
     const uint32_t t = (uint32_t) dx * p.hinc;
@@ -376,7 +378,7 @@ __global__ __launch_bounds__ (256) void k_cs_taps (const CsParams p)
   // luma window: 2 bytes at ybase, per-lane selector -> [ya ya yb yb]
   const int ybase = min (xa, p.in_w - 2);
   const uint32_t oa = (uint32_t) (xa - ybase), ob = (uint32_t) (xb - ybase);
-  const uint32_t sely = (oa * 0x0101u) | ((ob * 0x0101u) << 16);
+  const uint32_t sely = oa | (oa << 8) | (ob << 16) | (ob << 24);
 
   uint32_t sel_c = 0, sel_n = 0;
   int cbase = 0;
@@ -387,8 +389,10 @@ __global__ __launch_bounds__ (256) void k_cs_taps (const CsParams p)
     const int knb = (xb & 1) ? min (kb + 1, cw - 1) : (p.cosited ? kb : max (kb - 1, 0));
     cbase = max (min (ka - 1, cw - 4), 0);
     const uint32_t fa = (uint32_t) (ka - cbase), fb = (uint32_t) (kb - cbase), ga = (uint32_t) (kna - cbase), gb = (uint32_t) (knb - cbase);
-    sel_c = (fa * 0x0202u + 0x0100u) | ((fb * 0x0202u + 0x0100u) << 16);
-    sel_n = (ga * 0x0202u + 0x0100u) | ((gb * 0x0202u + 0x0100u) << 16);
+    // pair k of the window = bytes (2k, 2k + 1): selector halves 2k | (2k + 1) << 8, built with shifts (a 32-bit multiply is quarter rate)
+    const uint32_t pc = (fa << 1) | (fb << 17), pn = (ga << 1) | (gb << 17);
+    sel_c = (pc | (pc << 8)) + 0x01000100u;
+    sel_n = (pn | (pn << 8)) + 0x01000100u;
   }
 
   uint32_t bb[2], gg[2], rr[2];
@@ -398,13 +402,14 @@ __global__ __launch_bounds__ (256) void k_cs_taps (const CsParams p)
     const int j = r >> 1;
     uint32_t uv;                                        // [U(xa) V(xa) U(xb) V(xb)], already ^0x80
     if (I420) {                                         // GStreamer's I420 fast path: nearest-replicated chroma
-      const uint32_t ua = up[(size_t) j * p.is[1] + ka], ub = up[(size_t) j * p.is[1] + kb];
-      const uint32_t va = vp[(size_t) j * p.is[2] + ka], vb = vp[(size_t) j * p.is[2] + kb];
+      const uint32_t cu = (uint32_t) j * (uint32_t) p.is[1], cv = (uint32_t) j * (uint32_t) p.is[2];      // scalar row offsets + 32-bit lane offsets
+      const uint32_t ua = up[cu + (uint32_t) ka], ub = up[cu + (uint32_t) kb];
+      const uint32_t va = vp[cv + (uint32_t) ka], vb = vp[cv + (uint32_t) kb];
       uv = (ua | (va << 8) | (ub << 16) | (vb << 24)) ^ X;
     } else {
       const int jn = (r & 1) ? min (j + 1, chh - 1) : max (j - 1, 0);
-      const uint2 w0 = *reinterpret_cast<const uint2_a2 *> (up + (size_t) j * p.is[1] + 2 * cbase);
-      const uint2 w1 = *reinterpret_cast<const uint2_a2 *> (up + (size_t) jn * p.is[1] + 2 * cbase);
+      const uint2 w0 = *reinterpret_cast<const uint2_a2 *> (up + ((uint32_t) j * (uint32_t) p.is[1] + 2u * (uint32_t) cbase));      // scalar row offset + 32-bit lane offset
+      const uint2 w1 = *reinterpret_cast<const uint2_a2 *> (up + ((uint32_t) jn * (uint32_t) p.is[1] + 2u * (uint32_t) cbase));
       const uint32_t a0 = perm_b32 (w0.y, w0.x, sel_c), n0 = perm_b32 (w0.y, w0.x, sel_n);
       const uint32_t a1 = perm_b32 (w1.y, w1.x, sel_c), n1 = perm_b32 (w1.y, w1.x, sel_n);
       // horizontal first: co-sited even columns have n == a, so (a+n+1)>>1 == a; then vertical (3a+b+2)>>2
@@ -412,7 +417,7 @@ __global__ __launch_bounds__ (256) void k_cs_taps (const CsParams p)
       const uint32_t h1 = p.cosited ? lerp_u8 (a1, n1, K1) : filt31_u8 (a1, n1);
       uv = filt31_u8 (h0, h1) ^ X;
     }
-    const uint32_t yw = (uint32_t) *reinterpret_cast<const uint16_a1 *> (yp + (size_t) r * p.is[0] + ybase) ^ 0x8080u;
+    const uint32_t yw = (uint32_t) *reinterpret_cast<const uint16_a1 *> (yp + ((uint32_t) r * (uint32_t) p.is[0] + (uint32_t) ybase)) ^ 0x8080u;
     orc_pair (perm_b32 (0u, yw, sely), perm_b32 (0u, uv, 0x01010000u), perm_b32 (0u, uv, 0x03030202u), p.c, bias, bb[t], gg[t], rr[t]);
   }
 
