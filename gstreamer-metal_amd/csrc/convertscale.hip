@@ -9,10 +9,13 @@
 #include "convertscale_ntap_kernels.h"
 #include "convertscale_metal_kernels.h"
 #include "convertscale_planar_kernels.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
 using namespace vfhip;
+
+static constexpr int BL_TH = 32;      // k_cs_bilinear_tile's tile height
 
 // videoconvert's RGB -> YUV 8-bit integer matrices (oracle/gst114.c RGB2YUV, pinned against the real element)
 // videoconvert's 8-bit YUV -> YUV matrices, [matrix in][matrix out][row (Y, U, V) x (a, b, c, d)]: out = clamp8 (((a Y + b U + c V) >> 8) + d)
@@ -54,7 +57,7 @@ struct VfHipConvertScale {
   int *d_vtab = nullptr, *d_htab = nullptr;
   int vfirst = 1, hscale_on = 0;
   uint32_t hinc = 0;
-  enum Kernel { K_NONE, K_HALF, K_GENERIC, K_TAPS, K_METAL, K_STAGED, K_NTAP, K_SAME } kernel = K_NONE;
+  enum Kernel { K_NONE, K_HALF, K_GENERIC, K_TAPS, K_METAL, K_STAGED, K_NTAP, K_SAME, K_BLTILE } kernel = K_NONE;
   Kernel same_fallback = K_NONE;    // K_SAME: what runs instead when a frame misses k_cs_yuv_same's alignment contract
   const char *kernel_name = "none";
   // K_STAGED: videoconvert at the input size into `mid` (when the format changes), then per-plane videoscale
@@ -552,6 +555,26 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
   }
   else if (taps) { h->kernel = VfHipConvertScale::K_TAPS; h->kernel_name = "k_cs_taps"; }
   else { h->kernel = VfHipConvertScale::K_GENERIC; h->kernel_name = "k_cs_generic"; }
+  // bilinear without minification (up-scales, one axis only, conversion at the same size from RGB): the source region of a 64 x 32 output
+  // tile is smaller than the tile — k_cs_bilinear_tile converts each source pixel once per tile instead of four times per output pixel
+  if ((h->kernel == VfHipConvertScale::K_TAPS || h->kernel == VfHipConvertScale::K_GENERIC) && method == VFHIP_SCALE_BILINEAR &&
+      h->rw == out->width && h->rh == out->height && h->rx == 0 && h->ry == 0 && out->width >= in->width && out->height >= in->height &&
+      getenv ("VFHIP_NO_BILINEAR_TILE") == nullptr) {
+    const int iw = in->width, ow = out->width, oh = out->height;
+    auto xa_of = [&] (int x) { return h->hscale_on ? std::min ((int) (((uint32_t) x * h->hinc) >> 16), iw - 1) : x; };
+    int rwm = 0, rhm = 0;
+    for (int x0 = 0; x0 < ow; x0 += CT_TW) {
+      const int x1 = std::min (x0 + CT_TW, ow) - 1;
+      rwm = std::max (rwm, std::min (xa_of (x1) + (h->hscale_on ? 1 : 0), iw - 1) - xa_of (x0) + 1);
+    }
+    for (int y0 = 0; y0 < oh; y0 += BL_TH) {
+      const int y1 = std::min (y0 + BL_TH, oh) - 1;
+      rhm = std::max (rhm, vt[4 * y1 + 1] - vt[4 * y0] + 1);
+    }
+    const int rwa = rwm + 14;                          // 8-column alignment slack of the NV12 fast conversion on both sides
+    const bool vf = h->vfirst || !h->hscale_on;
+    if (rwa <= CT_RW && rhm <= CT_RH && (vf ? BL_TH * rwa : rhm * CT_TW) <= CT_RH * CT_TW) { h->kernel = VfHipConvertScale::K_BLTILE; h->kernel_name = "k_cs_bilinear_tile"; }
+  }
   h->configured = true;
   return VFHIP_OK;
 }
@@ -934,7 +957,12 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
     const uintptr_t b = (uintptr_t) p.out | (uintptr_t) p.os | (uintptr_t) out_pitch;
     if ((luma & (packed ? 15 : 7)) || (chroma & (i420 ? 3 : 7)) || (b & 15)) same = false;      // the generic kernels compute the same bytes
   }
-  if (half) {
+  if (h->kernel == VfHipConvertScale::K_BLTILE) {
+    const uintptr_t a = (uintptr_t) p.in[0] | (uintptr_t) p.in[1] | (uintptr_t) p.is[0] | (uintptr_t) p.is[1] | (uintptr_t) in_pitch;
+    const int fast_nv12 = p.in_fmt == VFHIP_FORMAT_NV12 && !(a & 7) && p.in_w >= 16 && getenv ("VFHIP_CUBIC_SCALAR") == nullptr;
+    dim3 grid ((unsigned) ((p.out_w + CT_TW - 1) / CT_TW), (unsigned) ((p.out_h + BL_TH - 1) / BL_TH), (unsigned) n_frames);
+    hipLaunchKernelGGL ((k_cs_bilinear_tile<512, BL_TH>), grid, dim3 (512), 0, s, p, fast_nv12);
+  } else if (half) {
     launch_half (p, n_frames, h->dev->n_cu, s);
   } else if (same) {
     dim3 grid ((unsigned) (((size_t) (p.in_w >> 3) * p.in_h + 255) / 256), (unsigned) n_frames);

@@ -343,4 +343,125 @@ __global__ __launch_bounds__ (THREADS) void k_cs_cubic_tile (const CubicTilePara
   }
 }
 
+// ---- k_cs_bilinear_tile: conversion + GStreamer's two 2-tap passes fused per output tile (bilinear at any ratio the tile holds) -------
+// k_cs_taps / k_cs_generic evaluate an output pixel from four converted taps: 4 conversions (with their chroma filters) per OUTPUT
+// pixel whatever the ratio — 16 x the source pixels at 2 x up-scaling, ~220 VALU instructions per output pixel, 42 us for 1080p -> 2160p.
+// GStreamer converts at the input size and then scales the 8-bit RGBA lines, vertical pass first iff in_h > out_h + 2, with an 8-bit
+// rounding between the passes; this kernel does exactly that per 64 x TH output tile: the source region the tile's taps reach is
+// converted ONCE into LDS (aligned 8-pixel groups through the packed ORC pipeline for NV12, cs_tap otherwise), the first pass runs
+// LDS -> LDS, the second LDS -> HBM.  Both passes work on whole RGBA dwords as two u16 pairs:
+//   vertical  (a * (256 - w) + b * w + 128) >> 8   ==  a + (((b - a) * w + 128) >> 8)   (the sum stays below 2^16),
+//   horizontal (a * (256 - f) + b * f) >> 8,  xa = (x * hinc) >> 16, f = ((x * hinc) >> 8) & 255
+// — the arithmetic of k_cs_generic, bit for bit.  Used where it pays: no minification on either axis (the region is then smaller than
+// the tile: at 2 x up-scaling 4 x fewer conversions than output pixels) with 64 x 32 tiles; for down-scales the per-pixel kernels'
+// ~1.6 x more arithmetic costs less than the tile's three barriers (measured: 1080p -> 720p 5.3 vs 5.4 us, I420 / RGB inputs slower).
+__device__ __forceinline__ uint32_t bl_vtap (uint32_t a, uint32_t b, uint32_t ww, uint32_t wm)
+{
+  const u16x2 al = as_u16x2 (a & 0x00ff00ffu), ah = as_u16x2 ((a >> 8) & 0x00ff00ffu), bl = as_u16x2 (b & 0x00ff00ffu), bh = as_u16x2 ((b >> 8) & 0x00ff00ffu);
+  const u16x2 tl = bl * as_u16x2 (ww) + (al * as_u16x2 (wm) + as_u16x2 (0x00800080u));
+  const u16x2 th = bh * as_u16x2 (ww) + (ah * as_u16x2 (wm) + as_u16x2 (0x00800080u));
+  return ((as_u32 (tl) >> 8) & 0x00ff00ffu) | (as_u32 (th) & 0xff00ff00u);
+}
+__device__ __forceinline__ uint32_t bl_htap (uint32_t a, uint32_t b, uint32_t fw, uint32_t fm)
+{
+  const u16x2 al = as_u16x2 (a & 0x00ff00ffu), ah = as_u16x2 ((a >> 8) & 0x00ff00ffu), bl = as_u16x2 (b & 0x00ff00ffu), bh = as_u16x2 ((b >> 8) & 0x00ff00ffu);
+  const u16x2 tl = bl * as_u16x2 (fw) + al * as_u16x2 (fm);
+  const u16x2 th = bh * as_u16x2 (fw) + ah * as_u16x2 (fm);
+  return ((as_u32 (tl) >> 8) & 0x00ff00ffu) | (as_u32 (th) & 0xff00ff00u);
+}
+
+template <int THREADS, int TH>
+__global__ __launch_bounds__ (THREADS) void k_cs_bilinear_tile (const CsParams p, int fast_nv12)
+{
+  __shared__ __attribute__ ((aligned (16))) uint32_t reg[CT_RH][CT_RW];   // converted source region
+  __shared__ uint32_t tmp[CT_RH * CT_TW];                             // first-pass result: [TH][rw] (V first) or [rh][CT_TW] (H first)
+  __shared__ int lxa[CT_TW], lxb[CT_TW];                              // this tile's horizontal taps: region-relative columns ...
+  __shared__ uint32_t lfw[CT_TW];                                     // ... and the weight f
+  __shared__ int lv0[TH], lv1[TH];                              // vertical taps: region-relative rows ...
+  __shared__ uint32_t lvw[TH];                                     // ... and the weight w
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * CT_TW, y0 = blockIdx.y * TH;
+  const int ow = p.out_w, oh = p.out_h;
+  const int tw = min (CT_TW, ow - x0), th = min (TH, oh - y0);
+  const uint8_t *in[3] = { p.in[0] + (size_t) blockIdx.z * p.in_pitch,
+                           p.in[1] ? p.in[1] + (size_t) blockIdx.z * p.in_pitch : nullptr,
+                           p.in[2] ? p.in[2] + (size_t) blockIdx.z * p.in_pitch : nullptr };
+  uint8_t *out = p.out + (size_t) blockIdx.z * p.out_pitch;
+  auto hx = [&] (int x, int &xa, int &xb, int &f) {
+    xa = x; xb = x; f = 0;
+    if (p.hscale_on) {
+      const uint32_t t = (uint32_t) x * p.hinc;
+      xa = min ((int) (t >> 16), p.in_w - 1); f = (int) ((t >> 8) & 0xff); xb = min (xa + 1, p.in_w - 1);
+    }
+  };
+  // source region of this tile (both tap sequences are non-decreasing)
+  int cx0, cx1, t0, t1;
+  hx (x0, cx0, t0, t1); hx (x0 + tw - 1, t0, cx1, t1);
+  const int ry0 = p.vtab[4 * y0], ry1 = p.vtab[4 * (y0 + th - 1) + 1];
+  const int rh = ry1 - ry0 + 1;
+  int rw = cx1 - cx0 + 1;
+  const int ga0 = fast_nv12 ? (cx0 & ~7) : cx0;                       // the region's first column (see below)
+  for (int i = tid; i < tw; i += THREADS) { int xa, xb, f; hx (x0 + i, xa, xb, f); lxa[i] = xa - ga0; lxb[i] = xb - ga0; lfw[i] = (uint32_t) f; }
+  for (int i = tid; i < th; i += THREADS) { lv0[i] = p.vtab[4 * (y0 + i)] - ry0; lv1[i] = p.vtab[4 * (y0 + i) + 1] - ry0; lvw[i] = (uint32_t) p.vtab[4 * (y0 + i) + 2]; }
+  if (fast_nv12) {
+    // region widened to whole 8-column groups; groups that would cross the right image edge fall back to cs_tap
+    const int groups = ((cx1 + 1 - ga0) + 7) >> 3;
+    for (int i = tid; i < groups * rh; i += THREADS) {
+      const int ry = i / groups, g = i - ry * groups, gx = ga0 + 8 * g;
+      uint32_t px8[8];
+      if (gx + 8 <= p.in_w) {
+        if (p.cosited) cs_convert8_nv12<true> (p, in, gx, ry0 + ry, px8);
+        else cs_convert8_nv12<false> (p, in, gx, ry0 + ry, px8);
+      } else {
+#pragma unroll 1
+        for (int k = 0; k < 8; k++) {
+          int px[4];
+          cs_tap (p, in, min (gx + k, p.in_w - 1), ry0 + ry, px);
+          px8[k] = (uint32_t) px[0] | ((uint32_t) px[1] << 8) | ((uint32_t) px[2] << 16) | ((uint32_t) px[3] << 24);
+        }
+      }
+      uint4 *d = reinterpret_cast<uint4 *> (&reg[ry][8 * g]);
+      d[0] = make_uint4 (px8[0], px8[1], px8[2], px8[3]); d[1] = make_uint4 (px8[4], px8[5], px8[6], px8[7]);
+    }
+    rw = 8 * groups;
+  } else {
+    for (int i = tid; i < rw * rh; i += THREADS) {
+      const int ry = i / rw, rx = i - ry * rw;
+      int px[4];
+      cs_tap (p, in, cx0 + rx, ry0 + ry, px);
+      reg[ry][rx] = (uint32_t) px[0] | ((uint32_t) px[1] << 8) | ((uint32_t) px[2] << 16) | ((uint32_t) px[3] << 24);
+    }
+  }
+  __syncthreads ();
+  if (p.vfirst || !p.hscale_on) {
+    // vertical first: tmp[ty][rx] over the region's columns, then the horizontal taps along each row
+    for (int i = tid; i < th * rw; i += THREADS) {
+      const int ty = i / rw, rx = i - ty * rw;
+      const uint32_t w = lvw[ty], ww = w | (w << 16);
+      tmp[ty * rw + rx] = bl_vtap (reg[lv0[ty]][rx], reg[lv1[ty]][rx], ww, 0x01000100u - ww);
+    }
+    __syncthreads ();
+    for (int i = tid; i < th * tw; i += THREADS) {
+      const int ty = i / tw, tx = i - ty * tw;
+      uint32_t q = tmp[ty * rw + lxa[tx]];
+      if (p.hscale_on) { const uint32_t f = lfw[tx], fw = f | (f << 16); q = bl_htap (q, tmp[ty * rw + lxb[tx]], fw, 0x01000100u - fw); }
+      *reinterpret_cast<uint32_t *> (out + (size_t) (y0 + ty) * p.os + 4 * (x0 + tx)) = q;
+    }
+  } else {
+    // horizontal first: tmp[ry][tx] over the region's rows, then the vertical taps down each column
+    for (int i = tid; i < rh * tw; i += THREADS) {
+      const int ry = i / tw, tx = i - ry * tw;
+      const uint32_t f = lfw[tx], fw = f | (f << 16);
+      tmp[ry * CT_TW + tx] = bl_htap (reg[ry][lxa[tx]], reg[ry][lxb[tx]], fw, 0x01000100u - fw);
+    }
+    __syncthreads ();
+    for (int i = tid; i < th * tw; i += THREADS) {
+      const int ty = i / tw, tx = i - ty * tw;
+      const uint32_t w = lvw[ty], ww = w | (w << 16);
+      *reinterpret_cast<uint32_t *> (out + (size_t) (y0 + ty) * p.os + 4 * (x0 + tx)) = bl_vtap (tmp[lv0[ty] * CT_TW + tx], tmp[lv1[ty] * CT_TW + tx], ww, 0x01000100u - ww);
+    }
+  }
+}
+
+
 }  // namespace vfhip

@@ -300,7 +300,7 @@ def test_golden_gstreamer_vectors_packed_inputs(vfhip, case):
     raw, want = ZP[case["name"] + "_in"], ZP[case["name"] + "_out"]
     got, kname = run(vfhip, case["in_format"], case["w"], case["h"], raw, case["colorimetry"], case["chroma_site"], case["method"],
                      case["out_format"], case["ow"], case["oh"])
-    assert kname in ("k_cs_generic", "k_cs_cubic_tile", "k_cs_ntap", "k_cs_uyvy_same", "k_cs_yuy2_same")            # never the metal arithmetic
+    assert kname in ("k_cs_generic", "k_cs_bilinear_tile", "k_cs_cubic_tile", "k_cs_ntap", "k_cs_uyvy_same", "k_cs_yuy2_same")            # never the metal arithmetic
     assert np.array_equal(got.reshape(-1), want), f"{kname}: {(got.reshape(-1) != want).sum()} bytes differ"
 
 
@@ -783,9 +783,13 @@ def test_yuv420_same_size_conversion(vfhip, oracle, ifmt, w, h, col, site, monke
             assert kname == f"k_cs_{ifmt.lower()}_same", kname
             assert np.array_equal(got, want), (ofmt, method)
         monkeypatch.setenv("VFHIP_NO_SAME", "1")
+        tile, kname = run(vfhip, ifmt, w, h, raw, col, site, "bilinear", ofmt, w, h)
+        assert kname == "k_cs_bilinear_tile" and np.array_equal(tile, want)
+        monkeypatch.setenv("VFHIP_NO_BILINEAR_TILE", "1")
         old, kname = run(vfhip, ifmt, w, h, raw, col, site, "bilinear", ofmt, w, h)
+        monkeypatch.delenv("VFHIP_NO_BILINEAR_TILE")
         monkeypatch.delenv("VFHIP_NO_SAME")
-        assert kname == ("k_cs_taps" if ifmt in ("NV12", "I420") else "k_cs_generic") and np.array_equal(old, want)
+        assert kname == ("k_cs_taps" if ifmt in ("NV12", "I420") and w >= 8 else "k_cs_generic") and np.array_equal(old, want)
 
 
 @pytest.mark.gpu
@@ -822,3 +826,23 @@ def test_nv12_same_size_batch_and_unaligned_fallback(vfhip, oracle):
     s.synchronize()
     assert np.array_equal(one.cpu().numpy().reshape(h, w, 4), want[0].reshape(h, w, 4))
     cs.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ifmt", ["NV12", "I420", "BGRA", "UYVY"])
+@pytest.mark.parametrize("w,h,ow,oh", [(192, 108, 384, 216), (192, 108, 128, 72), (200, 113, 333, 77), (64, 36, 640, 360), (1920, 1080, 1280, 720),
+                                       (130, 70, 61, 200), (96, 54, 96, 120), (96, 54, 150, 54), (17, 9, 40, 31), (640, 360, 1000, 700), (100, 100, 101, 100)])
+def test_bilinear_tile_against_oracle_and_per_pixel_kernels(vfhip, oracle, ifmt, w, h, ow, oh, monkeypatch):
+    """k_cs_bilinear_tile (conversion once per tile into LDS, then GStreamer's two 2-tap passes in its order) — up-scales, down-scales,
+    one axis only, both pass orders, odd sizes — against the oracle and against the per-pixel kernel it replaces"""
+    rng = np.random.default_rng(w * 31 + oh)
+    raw = rng.integers(0, 256, vfhip.plane_layout(ifmt, w, h)[1], dtype=np.uint8)
+    want = oracle.convertscale(ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", "RGBA", ow, oh)
+    got, kname = run(vfhip, ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", "RGBA", ow, oh)
+    tiled = ow >= w and oh >= h                                 # the tile kernel takes the shapes without minification
+    assert (kname == "k_cs_bilinear_tile") == tiled, kname
+    assert np.array_equal(got, want)
+    monkeypatch.setenv("VFHIP_NO_BILINEAR_TILE", "1")
+    old, kname = run(vfhip, ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", "RGBA", ow, oh)
+    monkeypatch.delenv("VFHIP_NO_BILINEAR_TILE")
+    assert kname in ("k_cs_taps", "k_cs_generic") and np.array_equal(old, want)
