@@ -455,10 +455,25 @@ __global__ __launch_bounds__ (THREADS) void k_cs_bilinear_tile (const CsParams p
       tmp[ry * CT_TW + tx] = bl_htap (reg[ry][lxa[tx]], reg[ry][lxb[tx]], fw, 0x01000100u - fw);
     }
     __syncthreads ();
-    for (int i = tid; i < th * tw; i += THREADS) {
-      const int ty = i / tw, tx = i - ty * tw;
-      const uint32_t w = lvw[ty], ww = w | (w << 16);
-      *reinterpret_cast<uint32_t *> (out + (size_t) (y0 + ty) * p.os + 4 * (x0 + tx)) = bl_vtap (tmp[lv0[ty] * CT_TW + tx], tmp[lv1[ty] * CT_TW + tx], ww, 0x01000100u - ww);
+    // four adjacent pixels per lane: two 16-byte LDS reads, one 16-byte store (dword stores when the frame is not 16-byte aligned)
+    const bool vec = !(((uintptr_t) out | (uintptr_t) p.os) & 15);
+    for (int i = tid; i < th * (CT_TW / 4); i += THREADS) {
+      const int ty = i / (CT_TW / 4), tx = 4 * (i - ty * (CT_TW / 4));
+      if (tx >= tw) continue;
+      const uint32_t w = lvw[ty], ww = w | (w << 16), wm = 0x01000100u - ww;
+      const uint4 a = *reinterpret_cast<const uint4 *> (&tmp[lv0[ty] * CT_TW + tx]), b = *reinterpret_cast<const uint4 *> (&tmp[lv1[ty] * CT_TW + tx]);
+      const uint4 v = make_uint4 (bl_vtap (a.x, b.x, ww, wm), bl_vtap (a.y, b.y, ww, wm), bl_vtap (a.z, b.z, ww, wm), bl_vtap (a.w, b.w, ww, wm));
+      uint32_t *d = reinterpret_cast<uint32_t *> (out + (size_t) (y0 + ty) * p.os + 4 * (x0 + tx));
+      if (vec && tx + 3 < tw) {
+        typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
+        const v4u q = { v.x, v.y, v.z, v.w };
+        __builtin_nontemporal_store (q, reinterpret_cast<v4u *> (d));
+      } else {
+        d[0] = v.x;
+        if (tx + 1 < tw) d[1] = v.y;
+        if (tx + 2 < tw) d[2] = v.z;
+        if (tx + 3 < tw) d[3] = v.w;
+      }
     }
   }
 }
