@@ -573,8 +573,12 @@ __global__ __launch_bounds__ (256) void k_compositor_quads (const CompParams p)
 // Here one lane = 4 x 2 pixels; the tap positions of the four columns and two rows are computed once per layer (metal::lin_taps on
 // the same texture coordinate: same operations), a row's sixteen texels (4 pixels x 2 x 2 taps, whole dwords) are loaded together,
 // and each pixel is then four byte-wise bilinear interpolations in plane_taps' order -> bit-identical to the general kernel.
+// YUV: the pads are NV12 / I420 instead (a multiviewer of decoder feeds): per pixel four luma taps (bytes) and four chroma taps (NV12: (U, V)
+// pairs as one 16-bit load; I420: a byte from each plane) at the half-size plane's own tap positions — metal::sample_rgba's plane_sample
+// calls with the loads of a row issued together — then metal::yuv_to_rgb.
 constexpr int COMP_SROWS = 2;
 
+template <bool YUV>
 __global__ __launch_bounds__ (256) void k_compositor_scaled (const CompParams p)
 {
   typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
@@ -621,43 +625,91 @@ __global__ __launch_bounds__ (256) void k_compositor_scaled (const CompParams p)
     if (xl + 3 < L.xpos || xl >= L.xpos + L.width) continue;       // (per lane) no column of the block inside the quad
     const uint8_t *base = L.img.p[0] + z * L.pitch;
     const int W = L.img.w, H = L.img.h;
-    const bool swap = (L.img.fmt == VFHIP_FORMAT_BGRA) != bgra_out;  // the pad's bytes 0 and 2 change places on the way into target order
-    // the quad's texture coordinate at a pixel centre and its two taps per axis (compositorVertex + the linear sampler: comp_sample)
-    uint32_t c0[4], c1[4];                                           // byte offsets of the two tap columns
-    float fx[4];
     bool cx[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      cx[i] = xl + i >= L.xpos && xl + i < L.xpos + L.width;
-      const float tu = (((float) (xl + i) + 0.5f) - (float) L.xpos) / (float) L.width;
-      const metal::Taps t = metal::lin_taps (W, tu);
-      c0[i] = 4u * (uint32_t) t.i0; c1[i] = 4u * (uint32_t) t.i1; fx[i] = t.f;
-    }
-#pragma unroll
-    for (int r = 0; r < COMP_SROWS; r++) {
-      if (!rowok[r] || y0 + r < L.ypos || y0 + r >= L.ypos + L.height) continue;      // wave-uniform
-      const float tv = (((float) (y0 + r) + 0.5f) - (float) L.ypos) / (float) L.height;
-      const metal::Taps ty = metal::lin_taps (H, tv);
-      const uint8_t *r0 = base + (size_t) ty.i0 * L.img.s[0], *r1 = base + (size_t) ty.i1 * L.img.s[0];
-      uint32_t t00[4], t10[4], t01[4], t11[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) {                               // the row's sixteen texels first (clamped taps: always inside the frame)
-        t00[i] = *reinterpret_cast<const uint32_t *> (r0 + c0[i]); t10[i] = *reinterpret_cast<const uint32_t *> (r0 + c1[i]);
-        t01[i] = *reinterpret_cast<const uint32_t *> (r1 + c0[i]); t11[i] = *reinterpret_cast<const uint32_t *> (r1 + c1[i]);
-      }
+    for (int i = 0; i < 4; i++) cx[i] = xl + i >= L.xpos && xl + i < L.xpos + L.width;
+    if (!YUV) {
+      const bool swap = (L.img.fmt == VFHIP_FORMAT_BGRA) != bgra_out;  // the pad's bytes 0 and 2 change places on the way into target order
+      // the quad's texture coordinate at a pixel centre and its two taps per axis (compositorVertex + the linear sampler: comp_sample)
+      uint32_t c0[4], c1[4];                                           // byte offsets of the two tap columns
+      float fx[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        float v[4];
+        const float tu = (((float) (xl + i) + 0.5f) - (float) L.xpos) / (float) L.width;
+        const metal::Taps t = metal::lin_taps (W, tu);
+        c0[i] = 4u * (uint32_t) t.i0; c1[i] = 4u * (uint32_t) t.i1; fx[i] = t.f;
+      }
 #pragma unroll
-        for (int c = 0; c < 4; c++) {                             // metal::plane_taps per byte: horizontal lerp of each tap row, then vertical
-          const float a = metal::lerp2 (metal::un8 ((t00[i] >> (8 * c)) & 0xffu), metal::un8 ((t10[i] >> (8 * c)) & 0xffu), fx[i]);
-          const float b = metal::lerp2 (metal::un8 ((t01[i] >> (8 * c)) & 0xffu), metal::un8 ((t11[i] >> (8 * c)) & 0xffu), fx[i]);
-          v[c] = metal::lerp2 (a, b, ty.f);
+      for (int r = 0; r < COMP_SROWS; r++) {
+        if (!rowok[r] || y0 + r < L.ypos || y0 + r >= L.ypos + L.height) continue;      // wave-uniform
+        const float tv = (((float) (y0 + r) + 0.5f) - (float) L.ypos) / (float) L.height;
+        const metal::Taps ty = metal::lin_taps (H, tv);
+        const uint8_t *r0 = base + (size_t) ty.i0 * L.img.s[0], *r1 = base + (size_t) ty.i1 * L.img.s[0];
+        uint32_t t00[4], t10[4], t01[4], t11[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {                               // the row's sixteen texels first (clamped taps: always inside the frame)
+          t00[i] = *reinterpret_cast<const uint32_t *> (r0 + c0[i]); t10[i] = *reinterpret_cast<const uint32_t *> (r0 + c1[i]);
+          t01[i] = *reinterpret_cast<const uint32_t *> (r1 + c0[i]); t11[i] = *reinterpret_cast<const uint32_t *> (r1 + c1[i]);
         }
-        F4 sc;
-        sc.r = swap ? v[2] : v[0]; sc.g = v[1]; sc.b = swap ? v[0] : v[2]; sc.a = v[3];      // target order
-        const uint32_t nv = comp_blend (L, sc, q[r][i], flat, bgc);
-        q[r][i] = cx[i] ? nv : q[r][i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          float v[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) {                             // metal::plane_taps per byte: horizontal lerp of each tap row, then vertical
+            const float a = metal::lerp2 (metal::un8 ((t00[i] >> (8 * c)) & 0xffu), metal::un8 ((t10[i] >> (8 * c)) & 0xffu), fx[i]);
+            const float b = metal::lerp2 (metal::un8 ((t01[i] >> (8 * c)) & 0xffu), metal::un8 ((t11[i] >> (8 * c)) & 0xffu), fx[i]);
+            v[c] = metal::lerp2 (a, b, ty.f);
+          }
+          F4 sc;
+          sc.r = swap ? v[2] : v[0]; sc.g = v[1]; sc.b = swap ? v[0] : v[2]; sc.a = v[3];      // target order
+          const uint32_t nv = comp_blend (L, sc, q[r][i], flat, bgc);
+          q[r][i] = cx[i] ? nv : q[r][i];
+        }
+      }
+    } else {
+      typedef uint16_t __attribute__ ((aligned (1))) u16_any;
+      const bool nv12 = L.img.fmt == VFHIP_FORMAT_NV12;
+      const uint8_t *cb_base = L.img.p[1] + z * L.pitch, *cr_base = nv12 ? cb_base : L.img.p[2] + z * L.pitch;
+      const int cw = (W + 1) / 2, chh = (H + 1) / 2;
+      const uint32_t cstep = nv12 ? 2u : 1u;
+      uint32_t y0c[4], y1c[4], k0c[4], k1c[4];                        // byte offsets of the luma / chroma tap columns
+      float fy_[4], fk[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float tu = (((float) (xl + i) + 0.5f) - (float) L.xpos) / (float) L.width;
+        const metal::Taps t = metal::lin_taps (W, tu), k = metal::lin_taps (cw, tu);
+        y0c[i] = (uint32_t) t.i0; y1c[i] = (uint32_t) t.i1; fy_[i] = t.f;
+        k0c[i] = cstep * (uint32_t) k.i0; k1c[i] = cstep * (uint32_t) k.i1; fk[i] = k.f;
+      }
+#pragma unroll
+      for (int r = 0; r < COMP_SROWS; r++) {
+        if (!rowok[r] || y0 + r < L.ypos || y0 + r >= L.ypos + L.height) continue;      // wave-uniform
+        const float tv = (((float) (y0 + r) + 0.5f) - (float) L.ypos) / (float) L.height;
+        const metal::Taps ty = metal::lin_taps (H, tv), tk = metal::lin_taps (chh, tv);
+        const uint8_t *l0 = base + (size_t) ty.i0 * L.img.s[0], *l1 = base + (size_t) ty.i1 * L.img.s[0];
+        const uint8_t *u0 = cb_base + (size_t) tk.i0 * L.img.s[1], *u1 = cb_base + (size_t) tk.i1 * L.img.s[1];
+        const uint8_t *v0 = cr_base + (size_t) tk.i0 * L.img.s[nv12 ? 1 : 2], *v1 = cr_base + (size_t) tk.i1 * L.img.s[nv12 ? 1 : 2];
+        uint32_t ya[4], yb[4], yc[4], yd[4], ca[4], cb_[4], cc[4], cd[4];      // c*: (U | V << 8) of the four chroma taps
+#pragma unroll
+        for (int i = 0; i < 4; i++) {                               // the row's loads first (clamped taps: always inside the planes)
+          ya[i] = l0[y0c[i]]; yb[i] = l0[y1c[i]]; yc[i] = l1[y0c[i]]; yd[i] = l1[y1c[i]];
+          if (nv12) {
+            ca[i] = *reinterpret_cast<const u16_any *> (u0 + k0c[i]); cb_[i] = *reinterpret_cast<const u16_any *> (u0 + k1c[i]);
+            cc[i] = *reinterpret_cast<const u16_any *> (u1 + k0c[i]); cd[i] = *reinterpret_cast<const u16_any *> (u1 + k1c[i]);
+          } else {
+            ca[i] = (uint32_t) u0[k0c[i]] | ((uint32_t) v0[k0c[i]] << 8); cb_[i] = (uint32_t) u0[k1c[i]] | ((uint32_t) v0[k1c[i]] << 8);
+            cc[i] = (uint32_t) u1[k0c[i]] | ((uint32_t) v1[k0c[i]] << 8); cd[i] = (uint32_t) u1[k1c[i]] | ((uint32_t) v1[k1c[i]] << 8);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          using metal::lerp2; using metal::un8;
+          const float yy = lerp2 (lerp2 (un8 (ya[i]), un8 (yb[i]), fy_[i]), lerp2 (un8 (yc[i]), un8 (yd[i]), fy_[i]), ty.f);
+          const float cb = lerp2 (lerp2 (un8 (ca[i] & 0xffu), un8 (cb_[i] & 0xffu), fk[i]), lerp2 (un8 (cc[i] & 0xffu), un8 (cd[i] & 0xffu), fk[i]), tk.f);
+          const float cr = lerp2 (lerp2 (un8 (ca[i] >> 8), un8 (cb_[i] >> 8), fk[i]), lerp2 (un8 (cc[i] >> 8), un8 (cd[i] >> 8), fk[i]), tk.f);
+          const uint32_t nv = comp_blend (L, comp_order (metal::yuv_to_rgb (yy, cb, cr, L.img.m709), bgra_out), q[r][i], flat, bgc);
+          q[r][i] = cx[i] ? nv : q[r][i];
+        }
       }
     }
   }
@@ -915,7 +967,12 @@ static bool comp_pad_rgba (const VfHipPadInput &in)
   return !comp_pad_unscaled (in) && (in.frame.info.format == VFHIP_FORMAT_RGBA || in.frame.info.format == VFHIP_FORMAT_BGRA) &&
       !(((uintptr_t) in.frame.data[0] | (uintptr_t) in.frame.stride[0]) & 3);
 }
-enum { COMP_KIND_LEAN, COMP_KIND_420, COMP_KIND_SCALED, COMP_KIND_HEAVY };
+// a pad k_compositor_scaled<true> can draw: NV12 / I420, scaled
+static bool comp_pad_yuv_scaled (const VfHipPadInput &in)
+{
+  return !comp_pad_unscaled (in) && (in.frame.info.format == VFHIP_FORMAT_NV12 || in.frame.info.format == VFHIP_FORMAT_I420);
+}
+enum { COMP_KIND_LEAN, COMP_KIND_420, COMP_KIND_SCALED, COMP_KIND_SCALED_YUV, COMP_KIND_HEAVY };
 
 static void comp_fill_layer (CompLayer &L, const VfHipPadInput &in, size_t pitch)
 {
@@ -944,6 +1001,7 @@ static int comp_launch_runs (VfHipCompositor *h, const VfHipPadInput *pads, int 
     if (!no_lean && comp_pad_lean (in)) return (int) COMP_KIND_LEAN;
     if (!no_420 && comp_pad_420 (in)) return (int) COMP_KIND_420;
     if (!no_scaled && comp_pad_rgba (in)) return (int) COMP_KIND_SCALED;
+    if (!no_scaled && comp_pad_yuv_scaled (in)) return (int) COMP_KIND_SCALED_YUV;
     return (int) COMP_KIND_HEAVY;
   };
   int k = 0;
@@ -995,7 +1053,7 @@ static int comp_launch_runs (VfHipCompositor *h, const VfHipPadInput *pads, int 
     first = false;
     if (!draw) continue;
     unscaled = unscaled && !force_general;
-    const int rows = kind == COMP_KIND_420 ? COMP420_ROWS : (kind == COMP_KIND_SCALED ? COMP_SROWS : ((kind == COMP_KIND_LEAN || unscaled) ? COMP_ROWS : 2));
+    const int rows = kind == COMP_KIND_420 ? COMP420_ROWS : ((kind == COMP_KIND_SCALED || kind == COMP_KIND_SCALED_YUV) ? COMP_SROWS : ((kind == COMP_KIND_LEAN || unscaled) ? COMP_ROWS : 2));
     // whole 64-lane groups from a 256-pixel boundary keep the 16-byte lanes of a wave on one 1 KiB-aligned run of a row
     p.bx0 = (rx0 / 256) * 64; p.by0 = ry0 / rows;
     const int bx1 = (rx1 + 3) / 4, by1 = (ry1 + rows - 1) / rows;
@@ -1009,7 +1067,8 @@ static int comp_launch_runs (VfHipCompositor *h, const VfHipPadInput *pads, int 
       if (p.background == COMP_BG_IN_PLACE ? opaque : flat_bg) hipLaunchKernelGGL (k_compositor_420<false>, grid, dim3 (64, 4), 0, s, p);
       else hipLaunchKernelGGL (k_compositor_420<true>, grid, dim3 (64, 4), 0, s, p);
     }
-    else if (kind == COMP_KIND_SCALED) hipLaunchKernelGGL (k_compositor_scaled, grid, dim3 (64, 4), 0, s, p);
+    else if (kind == COMP_KIND_SCALED) hipLaunchKernelGGL (k_compositor_scaled<false>, grid, dim3 (64, 4), 0, s, p);
+    else if (kind == COMP_KIND_SCALED_YUV) hipLaunchKernelGGL (k_compositor_scaled<true>, grid, dim3 (64, 4), 0, s, p);
     else if (unscaled) hipLaunchKernelGGL (k_compositor_unscaled, grid, dim3 (64, 4), 0, s, p);
     else hipLaunchKernelGGL (k_compositor, grid, dim3 (64, 4), 0, s, p);
     VFHIP_CHECK_HIP (hipGetLastError ());
