@@ -138,6 +138,20 @@ __device__ __forceinline__ void orc_pair (uint32_t ys, uint32_t uve, uint32_t uv
   rr = sat_pk_u8_i16 (perm_b32 ((uint32_t) tro, (uint32_t) tre, 0x07060302u));
 }
 
+// the same with the two luma terms (mulhs (splat (y), c0) + bias, low half already cleared) handed in: k_cs_nv12_half takes them from a
+// 256-entry table in LDS (half_row)
+__device__ __forceinline__ void orc_pair_wy (int wye, int wyo, uint32_t uve, uint32_t uvo, const int *c,
+    uint32_t &bb, uint32_t &gg, uint32_t &rr)
+{
+  const int tre = mad_i32_i16<1> (uve, c[1], wye), tro = mad_i32_i16<1> (uvo, c[1], wyo);
+  const int tbe = mad_i32_i16<0> (uve, c[2], wye), tbo = mad_i32_i16<0> (uvo, c[2], wyo);
+  const int tge = mad_i32_i16<1> (uve, c[4], mad_i32_i16<0> (uve, c[3], wye) & (int) 0xffff0000);
+  const int tgo = mad_i32_i16<1> (uvo, c[4], mad_i32_i16<0> (uvo, c[3], wyo) & (int) 0xffff0000);
+  bb = sat_pk_u8_i16 (perm_b32 ((uint32_t) tbo, (uint32_t) tbe, 0x07060302u));
+  gg = sat_pk_u8_i16 (perm_b32 ((uint32_t) tgo, (uint32_t) tge, 0x07060302u));
+  rr = sat_pk_u8_i16 (perm_b32 ((uint32_t) tro, (uint32_t) tre, 0x07060302u));
+}
+
 // per-lane constants of the fast path
 struct HalfCtx {
   const uint8_t *yp, *uvp;
@@ -146,6 +160,7 @@ struct HalfCtx {
   int ch, yend;
   int c[5];
   uint32_t wgt[4];
+  const uint32_t *wy;          // LDS: wy[b] = (mulhs (splat (b ^ 0x80), c0) + 128) << 16 for the RAW luma byte b
 };
 
 // 16 output bytes that nothing in the kernel reads again: a non-temporal store (measured on the headline config, three
@@ -175,23 +190,31 @@ __device__ __forceinline__ void half_row (const HalfCtx &k, int y, const CRow &h
   hn = hfilter<COSITED> (craw);
   mid_dn = { lerp_u8 (hc.e01, hn.e01, 0u), lerp_u8 (hc.e23, hn.e23, 0u), lerp_u8 (hc.o01, hn.o01, 0u), lerp_u8 (hc.o23, hn.o23, 0u) };
   const uint32_t K1 = 0x01010101u, X = 0x80808080u;
-  const int bias = 128 << 16;
   // vertical chroma filter (3a+b+2)>>2: source row 2y leans on chroma row y-1, row 2y+1 on chroma row y+1
   const uint32_t te01 = lerp_u8 (hc.e01, mid_up.e01, K1) ^ X, te23 = lerp_u8 (hc.e23, mid_up.e23, K1) ^ X;
   const uint32_t to01 = lerp_u8 (hc.o01, mid_up.o01, K1) ^ X, to23 = lerp_u8 (hc.o23, mid_up.o23, K1) ^ X;
   const uint32_t be01 = lerp_u8 (hc.e01, mid_dn.e01, K1) ^ X, be23 = lerp_u8 (hc.e23, mid_dn.e23, K1) ^ X;
   const uint32_t bo01 = lerp_u8 (hc.o01, mid_dn.o01, K1) ^ X, bo23 = lerp_u8 (hc.o23, mid_dn.o23, K1) ^ X;
-  const uint32_t yt0 = yt.x ^ X, yt1 = yt.y ^ X, yb0 = yb.x ^ X, yb1 = yb.y ^ X;
+  // the luma term of each of the 16 source pixels from the LDS table: byte -> dword address with one shift and one mask (full rate),
+  // the look-up on the LDS pipe — instead of xor + byte splat (v_perm) + v_mad_i32_i16 + mask per pixel on the VALU
+  int wt[8], wb[8];
+  {
+    const uint32_t a0 = yt.x, a1 = yt.y, b0 = yb.x, b1 = yb.y;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t m = 0x3fcu;
+      wt[j] = (int) k.wy[((j ? a0 >> (8 * j - 2) : a0 << 2) & m) >> 2]; wt[4 + j] = (int) k.wy[((j ? a1 >> (8 * j - 2) : a1 << 2) & m) >> 2];
+      wb[j] = (int) k.wy[((j ? b0 >> (8 * j - 2) : b0 << 2) & m) >> 2]; wb[4 + j] = (int) k.wy[((j ? b1 >> (8 * j - 2) : b1 << 2) & m) >> 2];
+    }
+  }
   uint32_t out[4];
 #pragma unroll
   for (int n = 0; n < 4; n++) {
-    const uint32_t sy = (n & 1) ? 0x03030202u : 0x01010000u;       // luma bytes (2n, 2n+1) of the row's 8
     const uint32_t su = (n & 1) ? 0x03030202u : 0x01010000u;       // chroma pair n within its dword
-    const uint32_t ytn = n < 2 ? yt0 : yt1, ybn = n < 2 ? yb0 : yb1;
     const uint32_t ten = n < 2 ? te01 : te23, ton = n < 2 ? to01 : to23, ben = n < 2 ? be01 : be23, bon = n < 2 ? bo01 : bo23;
     uint32_t bt, gt, rt, bbm, gbm, rbm;
-    orc_pair (perm_b32 (0u, ytn, sy), perm_b32 (0u, ten, su), perm_b32 (0u, ton, su), k.c, bias, bt, gt, rt);
-    orc_pair (perm_b32 (0u, ybn, sy), perm_b32 (0u, ben, su), perm_b32 (0u, bon, su), k.c, bias, bbm, gbm, rbm);
+    orc_pair_wy (wt[2 * n], wt[2 * n + 1], perm_b32 (0u, ten, su), perm_b32 (0u, ton, su), k.c, bt, gt, rt);
+    orc_pair_wy (wb[2 * n], wb[2 * n + 1], perm_b32 (0u, ben, su), perm_b32 (0u, bon, su), k.c, bbm, gbm, rbm);
     // vertical 2-tap, w = 128: s1 + (((s2-s1)*128+128)>>8) == (s1+s2+1)>>1 on the [even, odd] byte pairs
     const uint32_t vb = avg_rnd_u8 (bt, bbm), vg = avg_rnd_u8 (gt, gbm), vr = avg_rnd_u8 (rt, rbm);
     // horizontal 2-tap (e*(256-f) + o*f) >> 8.  256 - f does not fit a byte when f == 0, so in general the weights are
@@ -207,9 +230,10 @@ __device__ __forceinline__ void half_row (const HalfCtx &k, int y, const CRow &h
 // one lane's strip: set-up, prologue loads and the row loop.  F0: some lane of the wave has a horizontal tap with f == 0
 // (see half_row); the two instantiations are separate paths of the kernel so that each gets its own register allocation.
 template <bool COSITED, bool RGBA, bool F0>
-__device__ __forceinline__ void half_strip (const CsParams &p, int frame, int cg, int cgpr, int y0, int rows)
+__device__ __forceinline__ void half_strip (const CsParams &p, int frame, int cg, int cgpr, int y0, int rows, const uint32_t *wy)
 {
   HalfCtx k;
+  k.wy = wy;
   k.yp = p.in[0] + (size_t) frame * p.in_pitch;               // wave-uniform plane bases; per-lane parts are 32-bit offsets
   k.uvp = p.in[1] + (size_t) frame * p.in_pitch;         // (global_load with SGPR base + VGPR offset)
   k.op = p.out + (size_t) frame * p.out_pitch;
@@ -257,13 +281,21 @@ __global__ __launch_bounds__ (256, 8) void k_cs_nv12_half (const CsParams p)
   const int bpf = (cgpr * strips + 255) >> 8;                  // blocks per frame (wave-uniform scalar arithmetic)
   const int frame = b / bpf;
   const int t = (b % bpf) * 256 + threadIdx.x;
+  const uint32_t *wy = nullptr;
+  __shared__ uint32_t wy_lut[256];
+  {
+    const uint32_t v = (uint32_t) threadIdx.x ^ 0x80u;               // the luma byte as ORC sees it; splat: both bytes of the 16-bit lane
+    wy_lut[threadIdx.x] = (uint32_t) (mad_i32_i16<0> (v | (v << 8), p.c[0], 128 << 16) & (int) 0xffff0000);
+  }
+  __syncthreads ();
+  wy = wy_lut;
   if (t >= cgpr * strips) return;
   const int strip = t / cgpr, cg = t - strip * cgpr;
   bool lane_f0 = false;
 #pragma unroll
   for (int n = 0; n < 4; n++) lane_f0 |= ((((uint32_t) (cg * 4 + n) * p.hinc) >> 8) & 0xffu) == 0;
-  if (__builtin_amdgcn_ballot_w64 (lane_f0) != 0) half_strip<COSITED, RGBA, true> (p, frame, cg, cgpr, strip * rows, rows);      // wave-uniform
-  else half_strip<COSITED, RGBA, false> (p, frame, cg, cgpr, strip * rows, rows);
+  if (__builtin_amdgcn_ballot_w64 (lane_f0) != 0) half_strip<COSITED, RGBA, true> (p, frame, cg, cgpr, strip * rows, rows, wy);      // wave-uniform
+  else half_strip<COSITED, RGBA, false> (p, frame, cg, cgpr, strip * rows, rows, wy);
 }
 
 // ------------------------------------------------------------------------------------------------
