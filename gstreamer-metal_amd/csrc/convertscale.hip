@@ -15,7 +15,6 @@
 
 using namespace vfhip;
 
-static constexpr int BL_TH = 32;      // k_cs_bilinear_tile's tile height
 
 // videoconvert's RGB -> YUV 8-bit integer matrices (oracle/gst114.c RGB2YUV, pinned against the real element)
 // videoconvert's 8-bit YUV -> YUV matrices, [matrix in][matrix out][row (Y, U, V) x (a, b, c, d)]: out = clamp8 (((a Y + b U + c V) >> 8) + d)
@@ -58,6 +57,7 @@ struct VfHipConvertScale {
   int vfirst = 1, hscale_on = 0;
   uint32_t hinc = 0;
   enum Kernel { K_NONE, K_HALF, K_GENERIC, K_TAPS, K_METAL, K_STAGED, K_NTAP, K_SAME, K_BLTILE } kernel = K_NONE;
+  int bl_th = 32;                   // K_BLTILE: tile height (32, or 16 when a 32-row tile's source region does not fit)
   Kernel same_fallback = K_NONE;    // K_SAME: what runs instead when a frame misses k_cs_yuv_same's alignment contract
   const char *kernel_name = "none";
   // K_STAGED: videoconvert at the input size into `mid` (when the format changes), then per-plane videoscale
@@ -556,24 +556,33 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
   else if (taps) { h->kernel = VfHipConvertScale::K_TAPS; h->kernel_name = "k_cs_taps"; }
   else { h->kernel = VfHipConvertScale::K_GENERIC; h->kernel_name = "k_cs_generic"; }
   // bilinear without minification (up-scales, one axis only, conversion at the same size from RGB): the source region of a 64 x 32 output
-  // tile is smaller than the tile — k_cs_bilinear_tile converts each source pixel once per tile instead of four times per output pixel
+  // tile is smaller than the tile — k_cs_bilinear_tile converts each source pixel once per tile instead of four times per output pixel ...
+  // ... and, for NV12 (whose region is converted eight pixels at a time), every down-scale whose tile regions fit the LDS arrays as well
+  // (to ~2.2 : 1): 1080p -> 720p 5.46 -> 4.59 us.  I420 / packed / RGB inputs convert their region pixel by pixel and stay with the per-pixel kernels.
+  const bool bl_down = in->format == VFHIP_FORMAT_NV12 && in->width >= 16;
   if ((h->kernel == VfHipConvertScale::K_TAPS || h->kernel == VfHipConvertScale::K_GENERIC) && method == VFHIP_SCALE_BILINEAR &&
-      h->rw == out->width && h->rh == out->height && h->rx == 0 && h->ry == 0 && out->width >= in->width && out->height >= in->height &&
+      h->rw == out->width && h->rh == out->height && h->rx == 0 && h->ry == 0 && ((out->width >= in->width && out->height >= in->height) || bl_down) &&
       getenv ("VFHIP_NO_BILINEAR_TILE") == nullptr) {
     const int iw = in->width, ow = out->width, oh = out->height;
     auto xa_of = [&] (int x) { return h->hscale_on ? std::min ((int) (((uint32_t) x * h->hinc) >> 16), iw - 1) : x; };
-    int rwm = 0, rhm = 0;
+    int rwm = 0;
     for (int x0 = 0; x0 < ow; x0 += CT_TW) {
       const int x1 = std::min (x0 + CT_TW, ow) - 1;
       rwm = std::max (rwm, std::min (xa_of (x1) + (h->hscale_on ? 1 : 0), iw - 1) - xa_of (x0) + 1);
     }
-    for (int y0 = 0; y0 < oh; y0 += BL_TH) {
-      const int y1 = std::min (y0 + BL_TH, oh) - 1;
-      rhm = std::max (rhm, vt[4 * y1 + 1] - vt[4 * y0] + 1);
-    }
     const int rwa = rwm + 14;                          // 8-column alignment slack of the NV12 fast conversion on both sides
     const bool vf = h->vfirst || !h->hscale_on;
-    if (rwa <= CT_RW && rhm <= CT_RH && (vf ? BL_TH * rwa : rhm * CT_TW) <= CT_RH * CT_TW) { h->kernel = VfHipConvertScale::K_BLTILE; h->kernel_name = "k_cs_bilinear_tile"; }
+    for (int th : { 32, 16 }) {
+      int rhm = 0;
+      for (int y0 = 0; y0 < oh; y0 += th) {
+        const int y1 = std::min (y0 + th, oh) - 1;
+        rhm = std::max (rhm, vt[4 * y1 + 1] - vt[4 * y0] + 1);
+      }
+      if (rwa <= CT_RW && rhm <= CT_RH && (vf ? th * rwa : rhm * CT_TW) <= CT_RH * CT_TW) {
+        h->kernel = VfHipConvertScale::K_BLTILE; h->kernel_name = "k_cs_bilinear_tile"; h->bl_th = th;
+        break;
+      }
+    }
   }
   h->configured = true;
   return VFHIP_OK;
@@ -960,8 +969,9 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
   if (h->kernel == VfHipConvertScale::K_BLTILE) {
     const uintptr_t a = (uintptr_t) p.in[0] | (uintptr_t) p.in[1] | (uintptr_t) p.is[0] | (uintptr_t) p.is[1] | (uintptr_t) in_pitch;
     const int fast_nv12 = p.in_fmt == VFHIP_FORMAT_NV12 && !(a & 7) && p.in_w >= 16 && getenv ("VFHIP_CUBIC_SCALAR") == nullptr;
-    dim3 grid ((unsigned) ((p.out_w + CT_TW - 1) / CT_TW), (unsigned) ((p.out_h + BL_TH - 1) / BL_TH), (unsigned) n_frames);
-    hipLaunchKernelGGL ((k_cs_bilinear_tile<512, BL_TH>), grid, dim3 (512), 0, s, p, fast_nv12);
+    dim3 grid ((unsigned) ((p.out_w + CT_TW - 1) / CT_TW), (unsigned) ((p.out_h + h->bl_th - 1) / h->bl_th), (unsigned) n_frames);
+    if (h->bl_th == 32) hipLaunchKernelGGL ((k_cs_bilinear_tile<512, 32>), grid, dim3 (512), 0, s, p, fast_nv12);
+    else hipLaunchKernelGGL ((k_cs_bilinear_tile<512, 16>), grid, dim3 (512), 0, s, p, fast_nv12);
   } else if (half) {
     launch_half (p, n_frames, h->dev->n_cu, s);
   } else if (same) {

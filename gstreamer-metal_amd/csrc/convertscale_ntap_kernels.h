@@ -441,11 +441,30 @@ __global__ __launch_bounds__ (THREADS) void k_cs_bilinear_tile (const CsParams p
       tmp[ty * rw + rx] = bl_vtap (reg[lv0[ty]][rx], reg[lv1[ty]][rx], ww, 0x01000100u - ww);
     }
     __syncthreads ();
-    for (int i = tid; i < th * tw; i += THREADS) {
-      const int ty = i / tw, tx = i - ty * tw;
-      uint32_t q = tmp[ty * rw + lxa[tx]];
-      if (p.hscale_on) { const uint32_t f = lfw[tx], fw = f | (f << 16); q = bl_htap (q, tmp[ty * rw + lxb[tx]], fw, 0x01000100u - fw); }
-      *reinterpret_cast<uint32_t *> (out + (size_t) (y0 + ty) * p.os + 4 * (x0 + tx)) = q;
+    // four adjacent pixels per lane, one 16-byte store (dword stores when the frame is not 16-byte aligned)
+    const bool vec = !(((uintptr_t) out | (uintptr_t) p.os) & 15);
+    for (int i = tid; i < th * (CT_TW / 4); i += THREADS) {
+      const int ty = i / (CT_TW / 4), tx = 4 * (i - ty * (CT_TW / 4));
+      if (tx >= tw) continue;
+      uint32_t v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int txk = min (tx + k, tw - 1);
+        uint32_t q = tmp[ty * rw + lxa[txk]];
+        if (p.hscale_on) { const uint32_t f = lfw[txk], fw = f | (f << 16); q = bl_htap (q, tmp[ty * rw + lxb[txk]], fw, 0x01000100u - fw); }
+        v[k] = q;
+      }
+      uint32_t *d = reinterpret_cast<uint32_t *> (out + (size_t) (y0 + ty) * p.os + 4 * (x0 + tx));
+      if (vec && tx + 3 < tw) {
+        typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
+        const v4u q = { v[0], v[1], v[2], v[3] };
+        __builtin_nontemporal_store (q, reinterpret_cast<v4u *> (d));
+      } else {
+        d[0] = v[0];
+        if (tx + 1 < tw) d[1] = v[1];
+        if (tx + 2 < tw) d[2] = v[2];
+        if (tx + 3 < tw) d[3] = v[3];
+      }
     }
   } else {
     // horizontal first: tmp[ry][tx] over the region's rows, then the vertical taps down each column
