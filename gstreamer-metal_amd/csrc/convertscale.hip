@@ -557,9 +557,10 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
   else { h->kernel = VfHipConvertScale::K_GENERIC; h->kernel_name = "k_cs_generic"; }
   // bilinear without minification (up-scales, one axis only, conversion at the same size from RGB): the source region of a 64 x 32 output
   // tile is smaller than the tile — k_cs_bilinear_tile converts each source pixel once per tile instead of four times per output pixel ...
-  // ... and, for NV12 (whose region is converted eight pixels at a time), every down-scale whose tile regions fit the LDS arrays as well
-  // (to ~2.2 : 1): 1080p -> 720p 5.46 -> 4.59 us.  I420 / packed / RGB inputs convert their region pixel by pixel and stay with the per-pixel kernels.
-  const bool bl_down = in->format == VFHIP_FORMAT_NV12 && in->width >= 16;
+  // ... and, for NV12 and the packed 4:2:2 inputs (whose region is converted eight pixels at a time), every down-scale whose tile regions fit the
+  // LDS arrays as well (to ~2.2 : 1): NV12 1080p -> 720p 5.46 -> 4.59 us, UYVY 10.3 -> 4.5 us.  I420 (k_cs_taps<I420> is cheap: nearest chroma;
+  // 3.9 vs 4.3 us) and RGB inputs keep the per-pixel kernels for down-scales.
+  const bool bl_down = (in->format == VFHIP_FORMAT_NV12 || in_packed) && in->width >= 16;
   if ((h->kernel == VfHipConvertScale::K_TAPS || h->kernel == VfHipConvertScale::K_GENERIC) && method == VFHIP_SCALE_BILINEAR &&
       h->rw == out->width && h->rh == out->height && h->rx == 0 && h->ry == 0 && ((out->width >= in->width && out->height >= in->height) || bl_down) &&
       getenv ("VFHIP_NO_BILINEAR_TILE") == nullptr) {
@@ -967,11 +968,17 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
     if ((luma & (packed ? 15 : 7)) || (chroma & (i420 ? 3 : 7)) || (b & 15)) same = false;      // the generic kernels compute the same bytes
   }
   if (h->kernel == VfHipConvertScale::K_BLTILE) {
-    const uintptr_t a = (uintptr_t) p.in[0] | (uintptr_t) p.in[1] | (uintptr_t) p.is[0] | (uintptr_t) p.is[1] | (uintptr_t) in_pitch;
-    const int fast_nv12 = p.in_fmt == VFHIP_FORMAT_NV12 && !(a & 7) && p.in_w >= 16 && getenv ("VFHIP_CUBIC_SCALAR") == nullptr;
+    // the 8-pixel converters' alignment contracts (k_cs_yuv_same); a frame that misses its format's converts its regions pixel by pixel
+    const bool i420 = p.in_fmt == VFHIP_FORMAT_I420, packed = p.in_fmt == VFHIP_FORMAT_UYVY || p.in_fmt == VFHIP_FORMAT_YUY2;
+    const uintptr_t luma = (uintptr_t) p.in[0] | (uintptr_t) p.is[0] | (uintptr_t) in_pitch;
+    const uintptr_t chroma = packed ? 0 : ((uintptr_t) p.in[1] | (uintptr_t) p.is[1] | (i420 ? (uintptr_t) p.in[2] | (uintptr_t) p.is[2] : 0));
+    int fast = 0;
+    if ((p.in_fmt == VFHIP_FORMAT_NV12 || i420 || packed) && p.in_w >= 16 && !(luma & (packed ? 15 : 7)) && !(chroma & (i420 ? 3 : 7)) &&
+        getenv ("VFHIP_CUBIC_SCALAR") == nullptr)
+      fast = p.in_fmt == VFHIP_FORMAT_NV12 ? 1 : (i420 ? 2 : (p.in_fmt == VFHIP_FORMAT_UYVY ? 3 : 4));
     dim3 grid ((unsigned) ((p.out_w + CT_TW - 1) / CT_TW), (unsigned) ((p.out_h + h->bl_th - 1) / h->bl_th), (unsigned) n_frames);
-    if (h->bl_th == 32) hipLaunchKernelGGL ((k_cs_bilinear_tile<512, 32>), grid, dim3 (512), 0, s, p, fast_nv12);
-    else hipLaunchKernelGGL ((k_cs_bilinear_tile<512, 16>), grid, dim3 (512), 0, s, p, fast_nv12);
+    if (h->bl_th == 32) hipLaunchKernelGGL ((k_cs_bilinear_tile<512, 32>), grid, dim3 (512), 0, s, p, fast);
+    else hipLaunchKernelGGL ((k_cs_bilinear_tile<512, 16>), grid, dim3 (512), 0, s, p, fast);
   } else if (half) {
     launch_half (p, n_frames, h->dev->n_cu, s);
   } else if (same) {

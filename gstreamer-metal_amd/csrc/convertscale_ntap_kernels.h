@@ -371,7 +371,7 @@ __device__ __forceinline__ uint32_t bl_htap (uint32_t a, uint32_t b, uint32_t fw
 }
 
 template <int THREADS, int TH>
-__global__ __launch_bounds__ (THREADS) void k_cs_bilinear_tile (const CsParams p, int fast_nv12)
+__global__ __launch_bounds__ (THREADS) void k_cs_bilinear_tile (const CsParams p, int fast)
 {
   __shared__ __attribute__ ((aligned (16))) uint32_t reg[CT_RH][CT_RW];   // converted source region
   __shared__ uint32_t tmp[CT_RH * CT_TW];                             // first-pass result: [TH][rw] (V first) or [rh][CT_TW] (H first)
@@ -400,18 +400,21 @@ __global__ __launch_bounds__ (THREADS) void k_cs_bilinear_tile (const CsParams p
   const int ry0 = p.vtab[4 * y0], ry1 = p.vtab[4 * (y0 + th - 1) + 1];
   const int rh = ry1 - ry0 + 1;
   int rw = cx1 - cx0 + 1;
-  const int ga0 = fast_nv12 ? (cx0 & ~7) : cx0;                       // the region's first column (see below)
+  const int ga0 = fast ? (cx0 & ~7) : cx0;                            // the region's first column (see below)
   for (int i = tid; i < tw; i += THREADS) { int xa, xb, f; hx (x0 + i, xa, xb, f); lxa[i] = xa - ga0; lxb[i] = xb - ga0; lfw[i] = (uint32_t) f; }
   for (int i = tid; i < th; i += THREADS) { lv0[i] = p.vtab[4 * (y0 + i)] - ry0; lv1[i] = p.vtab[4 * (y0 + i) + 1] - ry0; lvw[i] = (uint32_t) p.vtab[4 * (y0 + i) + 2]; }
-  if (fast_nv12) {
-    // region widened to whole 8-column groups; groups that would cross the right image edge fall back to cs_tap
+  if (fast) {
+    // `fast`: the input meets the alignment contract of its 8-pixel converter (1 NV12, 2 I420, 3 UYVY, 4 YUY2).  The region is widened to
+    // whole 8-column groups; groups that would cross the right image edge fall back to cs_tap
     const int groups = ((cx1 + 1 - ga0) + 7) >> 3;
     for (int i = tid; i < groups * rh; i += THREADS) {
       const int ry = i / groups, g = i - ry * groups, gx = ga0 + 8 * g;
       uint32_t px8[8];
       if (gx + 8 <= p.in_w) {
-        if (p.cosited) cs_convert8_nv12<true> (p, in, gx, ry0 + ry, px8);
-        else cs_convert8_nv12<false> (p, in, gx, ry0 + ry, px8);
+        if (fast == 2) cs_convert8_i420 (p, in, gx, ry0 + ry, px8);
+        else if (fast == 1) { if (p.cosited) cs_convert8_nv12<true> (p, in, gx, ry0 + ry, px8); else cs_convert8_nv12<false> (p, in, gx, ry0 + ry, px8); }
+        else if (fast == 3) { if (p.cosited) cs_convert8_packed<false, true> (p, in, gx, ry0 + ry, px8); else cs_convert8_packed<false, false> (p, in, gx, ry0 + ry, px8); }
+        else { if (p.cosited) cs_convert8_packed<true, true> (p, in, gx, ry0 + ry, px8); else cs_convert8_packed<true, false> (p, in, gx, ry0 + ry, px8); }
       } else {
 #pragma unroll 1
         for (int k = 0; k < 8; k++) {

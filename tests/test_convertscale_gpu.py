@@ -841,10 +841,10 @@ def test_bilinear_tile_against_oracle_and_per_pixel_kernels(vfhip, oracle, ifmt,
     got, kname = run(vfhip, ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", "RGBA", ow, oh)
     if ow >= w and oh >= h:
         assert kname == "k_cs_bilinear_tile", kname             # no minification: always the tile kernel
-    elif ifmt != "NV12" or w < 16:
-        assert kname in ("k_cs_taps", "k_cs_generic"), kname    # down-scales of the other formats stay per pixel
+    elif ifmt in ("BGRA", "I420") or w < 16:
+        assert kname in ("k_cs_taps", "k_cs_generic"), kname    # down-scales of RGB and I420 inputs stay per pixel
     else:
-        assert kname in ("k_cs_bilinear_tile", "k_cs_taps"), kname      # NV12: the tile kernel while a tile's source region fits its LDS arrays
+        assert kname in ("k_cs_bilinear_tile", "k_cs_taps", "k_cs_generic"), kname      # YUV inputs: the tile kernel while a tile's source region fits its LDS arrays
         if w / ow <= 1.6 and h / oh <= 1.6:
             assert kname == "k_cs_bilinear_tile", kname
     assert np.array_equal(got, want)

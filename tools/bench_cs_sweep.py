@@ -14,6 +14,7 @@ CASES = [("NV12", 3840, 2160, "BGRA", 1920, 1080, "bilinear"), ("NV12", 3840, 21
          ("BGRA", 1920, 1080, "NV12", 1280, 720, "bilinear"), ("BGRA", 3840, 2160, "NV12", 1920, 1080, "bilinear"), ("NV12", 1920, 1080, "NV12", 1280, 720, "bilinear"),
          ("NV12", 3840, 2160, "NV12", 1920, 1080, "bilinear"), ("NV12", 1920, 1080, "I420", 1920, 1080, "bilinear"), ("UYVY", 1920, 1080, "BGRA", 1920, 1080, "bilinear"),
          ("YUY2", 1920, 1080, "NV12", 1920, 1080, "bilinear"), ("BGRA", 1920, 1080, "BGRA", 1280, 720, "bilinear"), ("BGRA", 1920, 1080, "RGBA", 1920, 1080, "bilinear"),
+         ("UYVY", 1920, 1080, "BGRA", 1280, 720, "bilinear"), ("I420", 1920, 1080, "BGRA", 3840, 2160, "bilinear"), ("NV12", 1280, 720, "BGRA", 1920, 1080, "bilinear"),
          ("NV12", 1920, 1080, "BGRA", 1280, 720, "nearest"), ("NV12", 1920, 1080, "BGRA", 1280, 720, "bicubic"), ("NV12", 1920, 1080, "NV12", 1280, 720, "bicubic")]
 for (ifmt, w, h, ofmt, ow, oh, method) in CASES:
     isz, osz = vfhip.plane_layout(ifmt, w, h)[1], vfhip.plane_layout(ofmt, ow, oh)[1]
