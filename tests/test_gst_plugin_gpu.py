@@ -96,9 +96,13 @@ def test_multi_element_chains():
        f"t. ! queue ! vfhipvideofilter invert=true ! vfhipconvertscale ! {caps('I420', 160, 120)} ! fakesink")
 
 
-@pytest.mark.parametrize("iw,ih,ow,oh,fmt", [(1920, 1080, 640, 480, "NV12"), (3840, 2160, 1920, 1080, "NV12"), (1280, 720, 1920, 1080, "I420"), (720, 576, 360, 288, "NV12")])
+@pytest.mark.parametrize("iw,ih,ow,oh,fmt", [(1920, 1080, 640, 480, "NV12"), (3840, 2160, 1920, 1080, "NV12"), (1280, 720, 1920, 1080, "I420"), (720, 576, 360, 288, "NV12"),
+                                             # round 2's new kernels inside real pipelines: conversion at the same size (k_cs_yuv_same: NV12, I420, UYVY, YUY2),
+                                             # up-scales and NV12 / UYVY down-scales through k_cs_bilinear_tile
+                                             (1920, 1080, 1920, 1080, "NV12"), (1280, 720, 1280, 720, "I420"), (1280, 720, 1280, 720, "UYVY"), (640, 480, 640, 480, "YUY2"),
+                                             (1280, 720, 1920, 1080, "NV12"), (1920, 1080, 1280, 720, "NV12"), (1920, 1080, 1280, 720, "UYVY"), (640, 360, 1280, 720, "YUY2")])
 def test_pixel_parity_with_cpu_videoconvert_videoscale(tmp_path, iw, ih, ow, oh, fmt):
-    """BASELINE configs[0] and [1] as real pipelines: vfhipconvertscale is byte-identical to videoconvert ! videoscale"""
+    """BASELINE configs[0] and [1] — and the shapes of round 2's kernels — as real pipelines: vfhipconvertscale is byte-identical to videoconvert ! videoscale"""
     a, b = tmp_path / "cpu.raw", tmp_path / "hip.raw"
     r = gst_env.launch(f"videotestsrc num-buffers=2 ! {caps(fmt, iw, ih)} ! tee name=t "
                        f"t. ! queue ! videoconvert ! videoscale ! {caps('BGRA', ow, oh)} ! filesink location={a} "
