@@ -198,7 +198,15 @@ __device__ __forceinline__ F4 fetch_1to1 (const Img &im, int x, int y, bool chro
   float cb, cr;
   if (chroma_linear) {
     const Taps tx = lin_taps_px (cw, 0.5f * (float) x - 0.25f), ty = lin_taps_px (chh, 0.5f * (float) y - 0.25f);
-    if (im.fmt == VFHIP_FORMAT_NV12) { cb = plane_taps (im.p[1], im.s[1], 2, 0, tx, ty); cr = plane_taps (im.p[1], im.s[1], 2, 1, tx, ty); }
+    if (im.fmt == VFHIP_FORMAT_NV12) {
+      // the (U, V) pair of a tap as one 16-bit load (4 loads instead of 8), then plane_taps' interpolation on each byte
+      typedef uint16_t __attribute__ ((aligned (1))) u16_any;
+      const uint8_t *r0 = im.p[1] + (size_t) ty.i0 * im.s[1], *r1 = im.p[1] + (size_t) ty.i1 * im.s[1];
+      const uint32_t t00 = *reinterpret_cast<const u16_any *> (r0 + 2 * tx.i0), t10 = *reinterpret_cast<const u16_any *> (r0 + 2 * tx.i1);
+      const uint32_t t01 = *reinterpret_cast<const u16_any *> (r1 + 2 * tx.i0), t11 = *reinterpret_cast<const u16_any *> (r1 + 2 * tx.i1);
+      cb = lerp2 (lerp2 (un8 (t00 & 0xffu), un8 (t10 & 0xffu), tx.f), lerp2 (un8 (t01 & 0xffu), un8 (t11 & 0xffu), tx.f), ty.f);
+      cr = lerp2 (lerp2 (un8 (t00 >> 8), un8 (t10 >> 8), tx.f), lerp2 (un8 (t01 >> 8), un8 (t11 >> 8), tx.f), ty.f);
+    }
     else { cb = plane_taps (im.p[1], im.s[1], 1, 0, tx, ty); cr = plane_taps (im.p[2], im.s[2], 1, 0, tx, ty); }
   } else {
     const int cx = iclamp (x >> 1, 0, cw - 1), cy = iclamp (y >> 1, 0, chh - 1);
