@@ -246,6 +246,35 @@ __device__ __forceinline__ uint32_t quant_rgb8 (float r, float g, float b)
   return __builtin_amdgcn_cvt_pk_u8_f32 (b * 255.0f, 2u, q);
 }
 
+// k_vf_point_rgba4: sharpness == 0, RGBA / BGRA in and out, 16-byte aligned rows (the filter on a decoded-to-RGB or rendered stream: by far the
+// most common way the element is used).  No 4:2:0 output means no 2 x 2 blocks: a lane takes four adjacent pixels of one row as ONE 16-byte
+// load and one 16-byte non-temporal store (k_vf_point moves 8 bytes per access); per pixel exactly vf_pass1's operations.
+__global__ __launch_bounds__ (256) void k_vf_point_rgba4 (const VfParams pp)
+{
+  const VfParams p = vf_frame (pp);
+  const int x4 = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (4 * x4 >= p.out.w || y >= p.out.h) return;                     // out.w is a multiple of 4
+  typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
+  const v4u t = *reinterpret_cast<const v4u *> (p.in.p[0] + (size_t) y * p.in.s[0] + 16 * (size_t) x4);
+  const bool rgba_in = p.in.fmt == VFHIP_FORMAT_RGBA, bgra_out = p.out.fmt == VFHIP_FORMAT_BGRA;
+  const float tv = ((float) y + 0.5f) * (1.0f / (float) p.out.h);
+  v4u o;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int x = 4 * x4 + i;
+    const float tu = ((float) x + 0.5f) * (1.0f / (float) p.out.w);
+    F4 c;                                                             // metal::fetch_1to1's RGBA / BGRA texel
+    c.g = metal::un8 ((t[i] >> 8) & 0xff); c.a = metal::un8 (t[i] >> 24);
+    if (rgba_in) { c.r = metal::un8 (t[i] & 0xff); c.b = metal::un8 ((t[i] >> 16) & 0xff); }
+    else { c.b = metal::un8 (t[i] & 0xff); c.r = metal::un8 ((t[i] >> 16) & 0xff); }
+    c = color_adjust (c, p.u, tu, tv, p.out.w, p.out.h);
+    if (p.lut) lut_sample (p.lut, p.lut_size, c);
+    const uint32_t q = metal::quant_rgba8 (c);
+    o[i] = bgra_out ? __builtin_amdgcn_perm (0u, q, 0x03000102u) : q;
+  }
+  __builtin_nontemporal_store (o, reinterpret_cast<v4u *> (p.out.p[0] + (size_t) y * p.out.s[0]) + x4);
+}
+
 __global__ __launch_bounds__ (VF_THREADS, 2) void k_vf_sharp (const VfParams pp)
 {
   const VfParams p = vf_frame (pp);
@@ -363,9 +392,17 @@ static int vf_launch (VfHipVideoFilter *h, const VfHipFrame *in, VfHipFrame *out
     dim3 grid ((unsigned) ((w + VF_TW - 1) / VF_TW), (unsigned) ((hh + VF_TH - 1) / VF_TH), (unsigned) n_frames);
     hipLaunchKernelGGL (k_vf_sharp, grid, dim3 (VF_THREADS), 0, s, p);
   } else {
-    const int bw = (w + 1) / 2, bh = (hh + 1) / 2;
-    dim3 grid ((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4), (unsigned) n_frames);
-    hipLaunchKernelGGL (k_vf_point, grid, dim3 (64, 4), 0, s, p);
+    const bool rgb_io = (in->info.format == VFHIP_FORMAT_RGBA || in->info.format == VFHIP_FORMAT_BGRA) &&
+                        (out->info.format == VFHIP_FORMAT_RGBA || out->info.format == VFHIP_FORMAT_BGRA);
+    const uintptr_t al = (uintptr_t) in->data[0] | (uintptr_t) in->stride[0] | (uintptr_t) in_pitch | (uintptr_t) out->data[0] | (uintptr_t) out->stride[0] | (uintptr_t) out_pitch;
+    if (rgb_io && !(w & 3) && !(al & 15) && getenv ("VFHIP_VF_BLOCKS") == nullptr) {
+      dim3 grid ((unsigned) ((w / 4 + 63) / 64), (unsigned) ((hh + 3) / 4), (unsigned) n_frames);
+      hipLaunchKernelGGL (k_vf_point_rgba4, grid, dim3 (64, 4), 0, s, p);
+    } else {
+      const int bw = (w + 1) / 2, bh = (hh + 1) / 2;
+      dim3 grid ((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4), (unsigned) n_frames);
+      hipLaunchKernelGGL (k_vf_point, grid, dim3 (64, 4), 0, s, p);
+    }
   }
   VFHIP_CHECK_HIP (hipGetLastError ());
   return VFHIP_OK;
