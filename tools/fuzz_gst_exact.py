@@ -26,6 +26,8 @@ for case in range(N):
     if rng.integers(5) == 0:
         ow, oh = max(w // 2, 1), max(h // 2, 1)                     # exact halves: the fast paths
         w, h = 2 * ow, 2 * oh
+    if rng.integers(8) == 0:
+        w = max(16, w & ~7); ow, oh = w, h                          # conversion at the same size, width % 8 == 0: the k_cs_*_same kernels (YUV in, RGB out)
     if ofmt in ("NV12", "I420"):
         h, oh = max(h, 8), max(oh, 8)                                # GStreamer 1.14 mishandles tiny 4:2:0 outputs
     if method == "bicubic" and not all(i == o or math.ceil(4 * max(1.0, i / o)) <= min(i, 64) for i, o in ((w, ow), (h, oh))):
