@@ -734,3 +734,30 @@ def test_compositor_multiviewer_scaled_pads(vfhip, metalref, ofmt, monkeypatch):
         monkeypatch.delenv(knob)
         assert np.array_equal(got, other), knob
     comp.close()
+
+
+def test_compositor_opaque_420_mosaic_batch(vfhip, metalref):
+    """a batch of frames of opaque NV12 / I420 tiles (first run over the frame with the later tiles' rectangles skipped, the others in place
+    without reading the target) plus a scaled BGRA inset: every frame of the batch against the oracle"""
+    import torch
+    ow, oh, n = 512, 128, 3
+    tiles = [("NV12", 256, 64, 0, 0), ("I420", 256, 64, 256, 0), ("NV12", 256, 64, 0, 64), ("NV12", 256, 64, 256, 64)]
+    frames = [[smooth(f, w, h, 900 + 10 * k + t) for k in range(n)] for t, (f, w, h, _, _) in enumerate(tiles)]
+    inset = [smooth("BGRA", 96, 54, 950 + k) for k in range(n)]
+    rings = [_ring(fr, (fr[0].size + 255) // 256 * 256) for fr in frames] + [_ring(inset, (inset[0].size + 255) // 256 * 256)]
+    pitches = [r.shape[1] for r in rings]
+    dout = torch.zeros((n, ow * oh * 4), dtype=torch.uint8, device="cuda")
+    comp = vfhip.Compositor(0)
+    comp.configure("BGRA", ow, oh)
+    pads = [comp.pad(f, w, h, rings[t].data_ptr(), x, y, w, h, 1.0, "over", "bt709" if t & 1 else "bt601") for t, (f, w, h, x, y) in enumerate(tiles)]
+    pads.append(comp.pad("BGRA", 96, 54, rings[4].data_ptr(), 200, 30, 144, 81, 0.8, "over"))
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    comp.composite_device(pads, dout.data_ptr(), background="checker", stream=s.cuda_stream, n_frames=n, pad_pitches=pitches, out_pitch=ow * oh * 4)
+    s.synchronize()
+    out = dout.cpu().numpy()
+    for k in range(n):
+        opads = [(f, w, h, frames[t][k], x, y, w, h, 1.0, 1, bool(t & 1)) for t, (f, w, h, x, y) in enumerate(tiles)]
+        opads.append(("BGRA", 96, 54, inset[k], 200, 30, 144, 81, 0.8, 1, False))
+        close(out[k], metalref.compositor("BGRA", ow, oh, opads, 0), f"opaque mosaic batch frame {k}", max_off_by_one=0.05)
+    comp.close()
