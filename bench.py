@@ -344,7 +344,7 @@ def main():
         fps = bd.whole_job_rate(frames_per_step, args.steps, world, t_max)
         if c5:
             de_ms, cs_ms = timed_launches(5, launch_de), timed_launches(5, lambda: launch_cs(ring_mid))
-            dom, dom_ms, dom_bytes = ("k_deinterlace_420", de_ms, ALG_DEINT * F) if de_ms >= cs_ms else (kernel, cs_ms, ALG_C2 * F)
+            dom, dom_ms, dom_bytes = ("k_deinterlace_420q", de_ms, ALG_DEINT * F) if de_ms >= cs_ms else (kernel, cs_ms, ALG_C2 * F)
             alg_frame = ALG_DEINT + ALG_C2
             workload = ("vfhipdeinterlace greedy-H NV12 3840x2160 -> vfhipconvertscale BGRA 1920x1080 bilinear gst-exact, one stream per GPU, "
                         "device-resident intermediate (BASELINE configs[4])")
@@ -359,7 +359,7 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_note, "kernel": dom, "kernel_ms": round(dom_ms, 4),
                 "algorithmic_bytes_per_launch": dom_bytes, "kernel_source_sha16": kernel_source_sha16()}
         if c5:
-            roof["legs_ms_per_launch"] = {"k_deinterlace_420": round(de_ms, 4), kernel: round(cs_ms, 4)}
+            roof["legs_ms_per_launch"] = {"k_deinterlace_420q": round(de_ms, 4), kernel: round(cs_ms, 4)}
         if not args.no_ceilings:
             ceil = stream_ceilings(torch, stream, ring_in, ring_out)
             if ceil:

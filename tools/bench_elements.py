@@ -101,7 +101,7 @@ def main():
     def c5():
         d.process_device(din.data_ptr(), dout.data_ptr(), method="greedyh", tff=True, threshold=0.1, stream=s.cuda_stream,
                          n_frames=R, in_pitch=dp, out_pitch=dp)
-    report("C5a deinterlace greedyh NV12 2160p (batch = one stream's consecutive frames)", "k_deinterlace_420", timed(c5, s, 5), R, 3 * size)
+    report("C5a deinterlace greedyh NV12 2160p (batch = one stream's consecutive frames)", "k_deinterlace_420q", timed(c5, s, 5), R, 3 * size)
     d.close()
     del din, dout
 
@@ -120,7 +120,7 @@ def main():
 
     def c4():
         comp.composite_device(pads, out.data_ptr(), background="black", stream=s.cuda_stream, n_frames=NC, pad_pitches=pitches, out_pitch=out.shape[1])
-    report("C4 compositor 4xBGRA1080p + NV12 720p -> BGRA 2160p", "k_compositor", timed(c4, s, 5), NC, 4 * 4 * 1920 * 1080 + 1280 * 720 * 3 // 2 + 4 * ow * oh)
+    report("C4 compositor 4xBGRA1080p + NV12 720p -> BGRA 2160p", "k_compositor_quads + k_compositor_420", timed(c4, s, 5), NC, 4 * 4 * 1920 * 1080 + 1280 * 720 * 3 // 2 + 4 * ow * oh)
     comp.close()
     del quads, nv, out
 
