@@ -3,8 +3,8 @@
 // (overlay/metaloverlay_shaders.h:60-151, `metal` numerics): the video is sampled 1:1, the image bilinearly inside its
 // rectangle, rgb = mix (video.rgb, image.rgb, image.a * alpha), one 8-bit render target, then the output format.  The
 // reference's render pass + RGBA->YUV pass are one kernel here (2x2 pixel blocks per lane, metal::store_block).
-// The image comes from csrc/host_parsers.hip (PNG only: the reference also takes JPEG through ImageIO, which needs a JPEG
-// decoder) and is premultiplied on load because the reference's decoder does so (metaloverlayrenderer.m:214-219) and
+// The image comes from csrc/host_parsers.hip (PNG) or csrc/host_jpeg.hip (baseline JPEG), chosen by the file's first bytes like the
+// reference's ImageIO loader does, and is premultiplied on load because the reference's decoder does so (metaloverlayrenderer.m:214-219) and
 // its shader then mixes the premultiplied colour as if it were straight — kept, it is what the reference renders.
 #include "vfhip_internal.h"
 #include "metal_common.h"
@@ -139,12 +139,9 @@ int vfhip_overlay_load_image (VfHipOverlay *h, const char *path)
 {
   if (!h) return set_error (VFHIP_ERR_INVALID, "null argument");
   if (!path || !*path) { vfhip_overlay_clear_image (h); return VFHIP_OK; }       // -loadImageFromFile: with an empty path clears
-  const size_t n = strlen (path);
-  if (n < 4 || strcasecmp (path + n - 4, ".png") != 0)
-    return set_error (VFHIP_ERR_UNSUPPORTED, "overlay images must be PNG files (got %s)", path);
   std::vector<uint8_t> px;
   int w = 0, hh = 0;
-  int rc = decode_png (path, px, &w, &hh);
+  int rc = decode_image (path, px, &w, &hh);       // PNG or JPEG
   if (rc) return rc;
   // premultiplied, like the bytes CoreGraphics hands the reference (kCGImageAlphaPremultipliedLast); its exact rounding is
   // unpinned — round to nearest here

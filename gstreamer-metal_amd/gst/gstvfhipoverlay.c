@@ -5,7 +5,7 @@
  * in/out caps { BGRA, RGBA, NV12, I420 }, properties location, x, y, width, height (0 = the image's own size), alpha,
  * relative-x / relative-y (fractions of the frame size that override x / y when >= 0) with the reference's ranges and
  * defaults (:375-420), passthrough until an image is loaded (:94-99), position resolved per frame from one snapshot taken
- * under the object lock (:176-200).  Images: PNG (libvfhip's decoder); the reference also reads JPEG through ImageIO. */
+ * under the object lock (:176-200).  Images: PNG and baseline JPEG (libvfhip's decoders; the reference reads them through ImageIO). */
 #ifdef HAVE_CONFIG_H
 #include "config.h"
 #endif
@@ -293,7 +293,7 @@ gst_vfhip_overlay_class_init (GstVfHipOverlayClass * klass)
   bc->sink_event = GST_DEBUG_FUNCPTR (ov_sink_event);
   bc->query = GST_DEBUG_FUNCPTR (ov_query);
 
-  g_object_class_install_property (oc, PROP_LOCATION, g_param_spec_string ("location", "Location", "Path to overlay image file (PNG)", NULL, f));
+  g_object_class_install_property (oc, PROP_LOCATION, g_param_spec_string ("location", "Location", "Path to overlay image file (PNG or JPEG)", NULL, f));
   g_object_class_install_property (oc, PROP_X, g_param_spec_int ("x", "X Position", "Overlay X position in pixels", 0, G_MAXINT, 0, f));
   g_object_class_install_property (oc, PROP_Y, g_param_spec_int ("y", "Y Position", "Overlay Y position in pixels", 0, G_MAXINT, 0, f));
   g_object_class_install_property (oc, PROP_WIDTH, g_param_spec_int ("width", "Width", "Overlay width in pixels (0 = original image width)", 0, G_MAXINT, 0, f));

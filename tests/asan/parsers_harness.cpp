@@ -1,4 +1,4 @@
-// tests/asan/parsers_harness.cpp — TEST INFRASTRUCTURE: libvfhip's file parsers (csrc/host_parsers.hip, compiled as plain
+// tests/asan/parsers_harness.cpp — TEST INFRASTRUCTURE: libvfhip's file parsers (csrc/host_parsers.hip, csrc/host_jpeg.hip, compiled as plain
 // C++) under AddressSanitizer + UBSan.  Reads every file named on the command line through the parser its extension selects
 // and prints one line per file; exits 0 whatever the parsers answer — only a sanitizer report (or a crash) fails the run.
 #include <cstdarg>
@@ -32,6 +32,10 @@ int main (int argc, char **argv)
       std::vector<float> lut;
       rc = vfhip::parse_png_lut (path, lut, &a);
       if (!rc && lut.size () != (size_t) a * a * a * 4) { printf ("%s: INCONSISTENT size %d table %zu\n", path, a, lut.size ()); return 3; }
+    } else if ((n >= 4 && !strcasecmp (path + n - 4, ".jpg")) || (n >= 4 && !strcasecmp (path + n - 4, ".img"))) {
+      std::vector<uint8_t> px;                            // .jpg: the JPEG decoder; .img: the sniffing loader (PNG or JPEG by content)
+      rc = !strcasecmp (path + n - 4, ".jpg") ? vfhip::decode_jpeg (path, px, &a, &b) : vfhip::decode_image (path, px, &a, &b);
+      if (!rc && px.size () != (size_t) a * b * 4) { printf ("%s: INCONSISTENT %dx%d pixels %zu\n", path, a, b, px.size ()); return 3; }
     } else {
       std::vector<uint8_t> px;
       rc = vfhip::decode_png (path, px, &a, &b);

@@ -293,6 +293,13 @@ def test_overlay_pipelines(tmp_path, fmt):
     ok(f"{SRC} ! {caps(fmt, 320, 240)} ! vfhipoverlay location={logo} relative-x=0.8 relative-y=0.05 width=60 height=40 alpha=0.5 ! fakesink")
     ok(f"{SRC} ! {caps(fmt, 320, 240)} ! vfhipoverlay ! fakesink")                                   # no image: passthrough
     ok(f"{SRC} ! {caps(fmt, 320, 240)} ! vfhipoverlay location={tmp_path / 'missing.png'} ! fakesink")   # warning, passthrough
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    jpg = tmp_path / "logo.jpg"                                                                       # a JPEG logo, as the reference's ImageIO loader takes
+    Image.fromarray((np.arange(48 * 64 * 3) % 251).astype(np.uint8).reshape(48, 64, 3)).save(jpg, quality=80)
+    ok(f"{SRC} ! {caps(fmt, 320, 240)} ! vfhipoverlay location={jpg} x=100 y=80 alpha=0.7 ! fakesink")
 
 
 def test_overlay_pixels_match_oracle(tmp_path):

@@ -560,7 +560,12 @@ def test_overlay_png_file_and_batch(vfhip, metalref, tmp_path):
     for k in range(n):
         close(out[k, :4 * w * h], metalref.overlay("BGRA", w, h, frames[k], "BGRA", pre, x=5, y=5, width=40, height=30, alpha=0.5), f"batch overlay {k}")
     with pytest.raises(vfhip.VfHipError) as e:
-        ov.load_image(str(tmp_path / "logo.jpg"))
+        ov.load_image(str(tmp_path / "missing.jpg"))             # a failed load keeps the current image
+    assert e.value.code == -1 and ov.image_size == (20, 20)
+    bad = tmp_path / "text.png"
+    bad.write_bytes(b"neither a PNG nor a JPEG file" * 4)
+    with pytest.raises(vfhip.VfHipError) as e:
+        ov.load_image(str(bad))
     assert e.value.code == -2 and ov.image_size == (20, 20)
     ov.load_image("")                                       # empty path clears, like the reference
     assert ov.image_size is None
@@ -761,3 +766,22 @@ def test_compositor_opaque_420_mosaic_batch(vfhip, metalref):
         opads.append(("BGRA", 96, 54, inset[k], 200, 30, 144, 81, 0.8, 1, False))
         close(out[k], metalref.compositor("BGRA", ow, oh, opads, 0), f"opaque mosaic batch frame {k}", max_off_by_one=0.05)
     comp.close()
+
+
+def test_overlay_jpeg_logo(vfhip, metalref, tmp_path):
+    """a JPEG logo through the overlay loader (csrc/host_jpeg.hip): the frame equals the oracle's overlay of the pixels Pillow decodes"""
+    Image = pytest.importorskip("PIL.Image")
+    w, h = 96, 64
+    rng = np.random.default_rng(4)
+    pic = np.clip(np.stack(np.meshgrid(np.arange(40) * 6, np.arange(24) * 10), axis=-1).sum(-1)[..., None] / 2 + rng.normal(0, 20, (24, 40, 3)), 0, 255).astype(np.uint8)
+    path = tmp_path / "logo.jpg"
+    Image.fromarray(pic).save(path, quality=85, subsampling=2)
+    with Image.open(path) as im:
+        ref = np.asarray(im.convert("RGBA")).copy()            # opaque: premultiplication leaves it as it is
+    ov = vfhip.Overlay(0)
+    ov.configure("NV12", w, h)
+    ov.load_image(str(path))
+    assert ov.image_size == (40, 24)
+    frame = smooth("NV12", w, h, 33)
+    close(ov.process(frame, x=20, y=12, alpha=0.8), metalref.overlay("NV12", w, h, frame, "NV12", ref, x=20, y=12, alpha=0.8), "jpeg overlay")
+    ov.close()

@@ -1,5 +1,5 @@
 """Sanitizer runs of the host-side code, on the CPU (no GPU sanitizer exists on this pool):
-  * libvfhip's file parsers (csrc/host_parsers.hip: PNG decoder, .cube parser, PNG-LUT slicer) built as plain C++ with
+  * libvfhip's file parsers (csrc/host_parsers.hip: PNG decoder, .cube parser, PNG-LUT slicer; csrc/host_jpeg.hip: JPEG decoder) built as plain C++ with
     -fsanitize=address,undefined and fed valid, truncated, bit-flipped and adversarial files — the answer may be an error
     code, never a sanitizer report, a crash or an exception escaping the C ABI;
   * oracle/metalref.c on awkward frame sizes in exactly sized heap buffers (tests/asan/oracle_harness.c);
@@ -33,7 +33,8 @@ pytestmark = pytest.mark.skipif(not (have("gcc") and have("g++")), reason="needs
 def parsers(tmp_path_factory):
     exe = tmp_path_factory.mktemp("asan") / "parsers_harness"
     subprocess.check_call(["g++"] + SAN + ["-x", "c++", "-o", str(exe), os.path.join(ROOT, "tests", "asan", "parsers_harness.cpp"),
-                                           os.path.join(ROOT, "gstreamer-metal_amd", "csrc", "host_parsers.hip"), "-lz"])
+                                           os.path.join(ROOT, "gstreamer-metal_amd", "csrc", "host_parsers.hip"),
+                                           os.path.join(ROOT, "gstreamer-metal_amd", "csrc", "host_jpeg.hip"), "-lz"])
     return str(exe)
 
 
@@ -166,3 +167,60 @@ def test_oracle_suites_under_asan(tmp_path):
                         os.path.join(ROOT, "tests", "test_metalref_cpu.py")], capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)
     assert r.returncode == 0 and "ERROR: AddressSanitizer" not in r.stdout + r.stderr and "runtime error:" not in r.stdout + r.stderr, (r.stdout[-3000:], r.stderr[-3000:])
     assert " passed" in r.stdout
+
+
+def test_jpeg_decoder_under_asan(parsers, tmp_path):
+    """valid JPEGs of every supported kind, every truncation point of a small one, 600 random byte flips (the entropy-coded data and the tables
+    reach the decoder unchecked), hand-made adversarial headers: error codes are fine, sanitizer reports are not"""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(17)
+    files, good = [], []
+    pic = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    pic[10:20, 10:30] = (250, 20, 40)
+    for k, kw in enumerate([dict(quality=75, subsampling=0), dict(quality=40, subsampling=1), dict(quality=90, subsampling=2), dict(quality=60, subsampling=2, optimize=True),
+                            dict(quality=100, subsampling=0)]):
+        p = tmp_path / f"ok{k}.jpg"
+        Image.fromarray(pic).save(p, **kw)
+        files.append(p); good.append(str(p))
+    g = tmp_path / "grey.jpg"
+    Image.fromarray(pic[..., 0], mode="L").save(g, quality=70)
+    files.append(g); good.append(str(g))
+    s = tmp_path / "sniff.img"
+    s.write_bytes(open(good[0], "rb").read())
+    files.append(s); good.append(str(s))
+    small = tmp_path / "small.jpg"
+    Image.fromarray(pic[:9, :11]).save(small, quality=50, subsampling=2)
+    base = small.read_bytes()
+    for n in range(0, len(base)):                                                    # every truncation point
+        q = tmp_path / f"trunc{n}.jpg"; q.write_bytes(base[:n]); files.append(q)
+    for j, gp in enumerate(good[:6]):
+        gb = open(gp, "rb").read()
+        for k in range(100):
+            b = bytearray(gb)
+            for _ in range(int(rng.integers(1, 5))):
+                b[int(rng.integers(2, len(b)))] = int(rng.integers(0, 256))
+            q = tmp_path / f"flip{j}_{k}.jpg"; q.write_bytes(bytes(b)); files.append(q)
+    soi = b"\xff\xd8"
+    def seg(m, d):
+        return bytes([0xff, m]) + struct.pack(">H", len(d) + 2) + d
+    adversarial = {
+        "huge.jpg": soi + seg(0xc0, struct.pack(">BHHB", 8, 65535, 65535, 3) + bytes([1, 0x22, 0, 2, 0x11, 1, 3, 0x11, 1])),
+        "zero.jpg": soi + seg(0xc0, struct.pack(">BHHB", 8, 0, 16, 1) + bytes([1, 0x11, 0])),
+        "nocomp.jpg": soi + seg(0xc0, struct.pack(">BHHB", 8, 16, 16, 0)),
+        "badsamp.jpg": soi + seg(0xc0, struct.pack(">BHHB", 8, 16, 16, 1) + bytes([1, 0x00, 0])),
+        "sos_first.jpg": soi + seg(0xda, bytes([1, 1, 0, 0, 63, 0])) + b"\x00" * 50,
+        "notables.jpg": soi + seg(0xc0, struct.pack(">BHHB", 8, 16, 16, 1) + bytes([1, 0x11, 0])) + seg(0xda, bytes([1, 1, 0, 0, 63, 0])) + b"\x12\x34" * 40 + b"\xff\xd9",
+        "dht_overflow.jpg": soi + seg(0xc4, bytes([0x00] + [255] * 16) + b"\x00" * 100),
+        "dht_kraft.jpg": soi + seg(0xc4, bytes([0x00, 3] + [0] * 15) + b"\x00\x01\x02"),
+        "dqt_short.jpg": soi + seg(0xdb, bytes([0x00]) + b"\x01" * 10),
+        "lenlie.jpg": soi + b"\xff\xe0\xff\xff" + b"\x00" * 30,
+        "len1.jpg": soi + b"\xff\xe0\x00\x01" + b"\x00" * 30,
+        "onlysoi.jpg": soi, "empty.jpg": b"",
+    }
+    for name, data in adversarial.items():
+        q = tmp_path / name; q.write_bytes(data); files.append(q)
+    rc = run(parsers, files)
+    assert all(rc[gp] == 0 for gp in good), {gp: rc[gp] for gp in good}
+    for name in adversarial:
+        assert rc[str(tmp_path / name)] < 0, name
+    assert rc[str(tmp_path / "trunc0.jpg")] < 0 and rc[str(tmp_path / f"trunc{len(base) // 2}.jpg")] < 0
