@@ -1,11 +1,11 @@
-// csrc/host_jpeg.hip — a baseline JPEG decoder for the overlay image loader.  Host code only and free of HIP headers (vfhip_host.h), so
+// csrc/host_jpeg.hip — a JPEG decoder (sequential and progressive) for the overlay image loader.  Host code only and free of HIP headers (vfhip_host.h), so
 // that it also builds as plain C++ under AddressSanitizer / UBSan for the corrupt-input tests (tests/test_parsers_asan.py).
 //
 // The reference hands overlay files to ImageIO (overlay/metaloverlayrenderer.m:166-245), which reads JPEG as well as PNG; logos and
-// watermarks do arrive as JPEG.  Supported: baseline and extended-sequential Huffman JPEG (SOF0 / SOF1), 8-bit samples, greyscale or
+// watermarks do arrive as JPEG.  Supported: baseline, extended-sequential and progressive Huffman JPEG (SOF0 / SOF1 / SOF2), 8-bit samples, greyscale or
 // three components (YCbCr per JFIF, or RGB when an Adobe marker says so), sampling factors 1 and 2 in either direction (others
-// replicate), interleaved or per-component scans, restart intervals.  Refused with VFHIP_ERR_UNSUPPORTED: progressive, arithmetic-coded,
-// lossless and 12-bit streams, CMYK.  The arithmetic is the Independent JPEG Group's published decoder, stage for stage — the "islow"
+// replicate), interleaved or per-component scans, restart intervals.  Refused with VFHIP_ERR_UNSUPPORTED: arithmetic-coded, lossless,
+// hierarchical and 12-bit streams, CMYK.  The arithmetic is the Independent JPEG Group's published decoder, stage for stage — the "islow"
 // integer inverse DCT (Loeffler / Ligtenberg / Moschytz, 13-bit constants), triangle ("fancy") chroma up-sampling for h2v1 and h2v2,
 // 16-bit fixed-point YCbCr -> RGB — so that the pixels equal libjpeg / libjpeg-turbo's (tests/test_jpeg_decode.py compares with Pillow);
 // what CoreGraphics produces for the same file is not pinned.  Output: RGBA8, alpha 255, row 0 first.
@@ -46,6 +46,7 @@ struct Component {
   std::vector<int16_t> coef;      // bw * bh blocks of 64, natural order
   std::vector<uint8_t> plane;     // (bw * 8) x (bh * 8) samples after the inverse DCT
   int pred = 0;
+  bool latched = false;           // qn holds the table (set by the component's first scan)
   uint16_t qn[64] = { 0 };        // the component's quantisation table in natural order
 };
 
@@ -106,6 +107,70 @@ static bool decode_block (BitReader &br, const HuffTable &dc, const HuffTable &a
     if (k > 63) return false;
     out[kZigzag[k]] = (int16_t) extend (br.bits (sz), sz);
     k++;
+  }
+  return true;
+}
+
+// ---- progressive scans (SOF2): every scan adds to the coefficients that earlier scans left in the component's array ---------------
+// DC scans (spectral band 0..0): the first sends the difference, shifted down by Al; each refinement one more bit per block.
+static bool prog_dc (BitReader &br, const HuffTable &dc, int &pred, int16_t *blk, int ah, int al)
+{
+  if (ah == 0) {
+    const int s = decode_symbol (br, dc);
+    if (s < 0 || s > 11) return false;
+    pred += s ? extend (br.bits (s), s) : 0;
+    if (pred < -32768 || pred > 32767) return false;
+    blk[0] = (int16_t) (pred * (1 << al));
+  } else if (br.bit ()) blk[0] = (int16_t) (blk[0] | (1 << al));
+  return true;
+}
+// AC scans (band ss..se of ONE component): first pass — run / size pairs with end-of-band runs that span blocks
+static bool prog_ac_first (BitReader &br, const HuffTable &ac, int16_t *blk, int ss, int se, int al, int &eobrun)
+{
+  if (eobrun > 0) { eobrun--; return true; }
+  for (int k = ss; k <= se;) {
+    const int rs = decode_symbol (br, ac);
+    if (rs < 0) return false;
+    const int r = rs >> 4, sz = rs & 15;
+    if (sz) {
+      k += r;
+      if (k > se) return false;
+      blk[kZigzag[k]] = (int16_t) (extend (br.bits (sz), sz) * (1 << al));
+      k++;
+    } else if (r == 15) k += 16;
+    else { eobrun = (1 << r) - 1 + (r ? br.bits (r) : 0); break; }
+  }
+  return true;
+}
+// ... refinement: one correction bit for every coefficient that is already non-zero, newly non-zero ones (+-1 << al) in between
+static bool prog_ac_refine (BitReader &br, const HuffTable &ac, int16_t *blk, int ss, int se, int al, int &eobrun)
+{
+  const int p1 = 1 << al, m1 = -(1 << al);
+  int k = ss;
+  auto correct = [&] (int16_t &c) { if (br.bit () && !(c & p1)) c = (int16_t) (c + (c >= 0 ? p1 : m1)); };
+  if (eobrun == 0) {
+    for (; k <= se; k++) {
+      const int rs = decode_symbol (br, ac);
+      if (rs < 0) return false;
+      int r = rs >> 4;
+      const int sz = rs & 15;
+      int value = 0;
+      if (sz) {
+        if (sz != 1) return false;
+        value = br.bit () ? p1 : m1;
+      } else if (r != 15) { eobrun = (1 << r) + (r ? br.bits (r) : 0); break; }
+      // skip r still-zero coefficients, correcting the non-zero ones on the way
+      for (; k <= se; k++) {
+        int16_t &c = blk[kZigzag[k]];
+        if (c) correct (c);
+        else if (--r < 0) break;
+      }
+      if (value) { if (k > se) return false; blk[kZigzag[k]] = (int16_t) value; }
+    }
+  }
+  if (eobrun > 0) {
+    for (; k <= se; k++) { int16_t &c = blk[kZigzag[k]]; if (c) correct (c); }
+    eobrun--;
   }
   return true;
 }
@@ -239,7 +304,7 @@ static int decode_jpeg_impl (const char *path, std::vector<uint8_t> &rgba, int *
   HuffTable hdc[4], hac[4];
   std::vector<Component> comp;
   int W = 0, H = 0, hmax = 1, vmax = 1, restart = 0, adobe_transform = -1;
-  bool have_sof = false, scans = false, eoi = false;
+  bool have_sof = false, scans = false, eoi = false, progressive = false;
   size_t pos = 2;
   const uint8_t *data = file.data ();
   const size_t size = file.size ();
@@ -281,7 +346,7 @@ static int decode_jpeg_impl (const char *path, std::vector<uint8_t> &rgba, int *
         if (!t.build ()) return set_error (VFHIP_ERR_INVALID, "%s: inconsistent Huffman table", path);
         t.present = true;
       }
-    } else if (m == 0xc0 || m == 0xc1) {                          // SOF0 / SOF1
+    } else if (m == 0xc0 || m == 0xc1 || m == 0xc2) {             // SOF0 / SOF1 / SOF2 (progressive)
       if (have_sof) return set_error (VFHIP_ERR_INVALID, "%s: two frame headers", path);
       if (sl < 6) return set_error (VFHIP_ERR_INVALID, "%s: bad frame header", path);
       if (s[0] != 8) return set_error (VFHIP_ERR_UNSUPPORTED, "%s: %d-bit JPEG samples are not supported", path, s[0]);
@@ -304,10 +369,9 @@ static int decode_jpeg_impl (const char *path, std::vector<uint8_t> &rgba, int *
         c.w = (W * c.h + hmax - 1) / hmax; c.hh = (H * c.v + vmax - 1) / vmax;
         c.coef.assign ((size_t) c.bw * c.bh * 64, 0);
       }
-      have_sof = true;
-    } else if (m == 0xc2 || m == 0xc3 || (m >= 0xc5 && m <= 0xcf && m != 0xc8 && m != 0xcc)) {
-      return set_error (VFHIP_ERR_UNSUPPORTED, "%s: only baseline / extended sequential Huffman JPEG is supported (frame type 0x%02x: %s)", path, m,
-          m == 0xc2 ? "progressive" : "lossless, hierarchical or arithmetic-coded");
+      have_sof = true; progressive = m == 0xc2;
+    } else if (m == 0xc3 || (m >= 0xc5 && m <= 0xcf && m != 0xc8 && m != 0xcc)) {
+      return set_error (VFHIP_ERR_UNSUPPORTED, "%s: only Huffman-coded sequential and progressive JPEG is supported (frame type 0x%02x: lossless, hierarchical or arithmetic-coded)", path, m);
     } else if (m == 0xcc) {
       return set_error (VFHIP_ERR_UNSUPPORTED, "%s: arithmetic-coded JPEG is not supported", path);
     } else if (m == 0xdd) {                                       // DRI
@@ -326,12 +390,20 @@ static int decode_jpeg_impl (const char *path, std::vector<uint8_t> &rgba, int *
         for (Component &c : comp) if (c.id == s[1 + 2 * k]) sc[k] = &c;
         if (!sc[k]) return set_error (VFHIP_ERR_INVALID, "%s: scan names an unknown component", path);
         sc[k]->td = s[2 + 2 * k] >> 4; sc[k]->ta = s[2 + 2 * k] & 15;
-        if (sc[k]->td > 3 || sc[k]->ta > 3 || !hdc[sc[k]->td].present || !hac[sc[k]->ta].present || !have_qt[sc[k]->tq])
-          return set_error (VFHIP_ERR_INVALID, "%s: scan uses a table the file does not define", path);
         sc[k]->pred = 0;
-        for (int z = 0; z < 64; z++) sc[k]->qn[kZigzag[z]] = qt[sc[k]->tq][z];        // (the table in force when the component's scan starts)
       }
-      if (s[1 + 2 * ns] != 0 || s[2 + 2 * ns] != 63) return set_error (VFHIP_ERR_UNSUPPORTED, "%s: spectral selection in a sequential JPEG", path);
+      const int ss = s[1 + 2 * ns], se = s[2 + 2 * ns], ah = s[3 + 2 * ns] >> 4, al = s[3 + 2 * ns] & 15;
+      if (!progressive) { if (ss != 0 || se != 63 || ah || al) return set_error (VFHIP_ERR_INVALID, "%s: spectral selection in a sequential JPEG", path); }
+      else if (ss > se || se > 63 || al > 13 || (ss == 0 && se != 0) || (ss > 0 && ns != 1) || (ah && ah != al + 1))
+        return set_error (VFHIP_ERR_INVALID, "%s: bad progressive scan parameters", path);
+      for (int k = 0; k < ns; k++) {
+        const bool need_dc = ss == 0 && ah == 0, need_ac = progressive ? ss > 0 : true;
+        if (sc[k]->td > 3 || sc[k]->ta > 3 || (need_dc && !hdc[sc[k]->td].present) || (need_ac && !hac[sc[k]->ta].present) || !have_qt[sc[k]->tq])
+          return set_error (VFHIP_ERR_INVALID, "%s: scan uses a table the file does not define", path);
+        if (!sc[k]->latched) for (int z = 0; z < 64; z++) sc[k]->qn[kZigzag[z]] = qt[sc[k]->tq][z];    // (the table in force when the component's FIRST scan starts)
+        sc[k]->latched = true;
+      }
+      int eobrun = 0;
       // the entropy-coded segment runs to the next marker that is not a restart marker
       BitReader br (data + pos, data + size);
       int mx, my;
@@ -350,6 +422,7 @@ static int decode_jpeg_impl (const char *path, std::vector<uint8_t> &rgba, int *
             br.p = q + 1; br.hit_marker = false;
             rst = (rst + 1) & 7; todo = restart;
             for (int k = 0; k < ns; k++) sc[k]->pred = 0;
+            eobrun = 0;
           }
           for (int k = 0; k < ns; k++) {
             Component &c = *sc[k];
@@ -358,8 +431,16 @@ static int decode_jpeg_impl (const char *path, std::vector<uint8_t> &rgba, int *
               for (int bx = 0; bx < nh; bx++) {
                 const int gx = x * nh + bx, gy = y * nv + by;
                 int16_t tmp[64];
-                if (!decode_block (br, hdc[c.td], hac[c.ta], c.pred, tmp)) return set_error (VFHIP_ERR_INVALID, "%s: corrupt JPEG data", path);
-                if (gx < c.bw && gy < c.bh) memcpy (&c.coef[((size_t) gy * c.bw + gx) * 64], tmp, sizeof tmp);
+                bool okb;
+                if (!progressive) {
+                  okb = decode_block (br, hdc[c.td], hac[c.ta], c.pred, tmp);
+                  if (okb && gx < c.bw && gy < c.bh) memcpy (&c.coef[((size_t) gy * c.bw + gx) * 64], tmp, sizeof tmp);
+                } else {
+                  int16_t *blk = (gx < c.bw && gy < c.bh) ? &c.coef[((size_t) gy * c.bw + gx) * 64] : (memset (tmp, 0, sizeof tmp), tmp);
+                  if (ss == 0) okb = prog_dc (br, hdc[c.td], c.pred, blk, ah, al);
+                  else okb = ah ? prog_ac_refine (br, hac[c.ta], blk, ss, se, al, eobrun) : prog_ac_first (br, hac[c.ta], blk, ss, se, al, eobrun);
+                }
+                if (!okb) return set_error (VFHIP_ERR_INVALID, "%s: corrupt JPEG data", path);
               }
           }
           if (restart) todo--;

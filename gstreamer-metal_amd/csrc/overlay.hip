@@ -3,7 +3,7 @@
 // (overlay/metaloverlay_shaders.h:60-151, `metal` numerics): the video is sampled 1:1, the image bilinearly inside its
 // rectangle, rgb = mix (video.rgb, image.rgb, image.a * alpha), one 8-bit render target, then the output format.  The
 // reference's render pass + RGBA->YUV pass are one kernel here (2x2 pixel blocks per lane, metal::store_block).
-// The image comes from csrc/host_parsers.hip (PNG) or csrc/host_jpeg.hip (baseline JPEG), chosen by the file's first bytes like the
+// The image comes from csrc/host_parsers.hip (PNG) or csrc/host_jpeg.hip (JPEG), chosen by the file's first bytes like the
 // reference's ImageIO loader does, and is premultiplied on load because the reference's decoder does so (metaloverlayrenderer.m:214-219) and
 // its shader then mixes the premultiplied colour as if it were straight — kept, it is what the reference renders.
 #include "vfhip_internal.h"

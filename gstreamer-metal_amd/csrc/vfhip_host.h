@@ -15,7 +15,7 @@ int set_error (int code, const char *fmt, ...) __attribute__ ((format (printf, 2
 
 // PNG -> straight RGBA8, row 0 first (zlib inflate; every colour type and bit depth, Adam7, at most 64 Mpixel)
 int decode_png (const char *path, std::vector<uint8_t> &rgba, int *width, int *height);
-// baseline JPEG -> RGBA8 (alpha 255), row 0 first (host_jpeg.hip); decode_image: PNG or JPEG by the file's first bytes
+// JPEG (sequential / progressive Huffman) -> RGBA8 (alpha 255), row 0 first (host_jpeg.hip); decode_image: PNG or JPEG by the file's first bytes
 int decode_jpeg (const char *path, std::vector<uint8_t> &rgba, int *width, int *height);
 int decode_image (const char *path, std::vector<uint8_t> &rgba, int *width, int *height);
 // .cube 3D LUT -> size^3 RGBA float entries, R fastest, alpha 1 (reference parse_cube_lut, videofilter/metalvideofilterrenderer.m:68-162)

@@ -5,7 +5,7 @@
  * in/out caps { BGRA, RGBA, NV12, I420 }, properties location, x, y, width, height (0 = the image's own size), alpha,
  * relative-x / relative-y (fractions of the frame size that override x / y when >= 0) with the reference's ranges and
  * defaults (:375-420), passthrough until an image is loaded (:94-99), position resolved per frame from one snapshot taken
- * under the object lock (:176-200).  Images: PNG and baseline JPEG (libvfhip's decoders; the reference reads them through ImageIO). */
+ * under the object lock (:176-200).  Images: PNG and JPEG (libvfhip's decoders; the reference reads them through ImageIO). */
 #ifdef HAVE_CONFIG_H
 #include "config.h"
 #endif

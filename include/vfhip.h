@@ -127,7 +127,7 @@ int vfhip_memcpy_d2h (int device, void *dst, const void *src, size_t bytes);
 /* PNG decoder used by the overlay image and PNG LUT loaders (host only; every colour type and bit depth, Adam7, tRNS; 16-bit samples keep their high byte):
  * straight RGBA8, row 0 first, malloc'ed — release with vfhip_image_free */
 int vfhip_image_decode_png (const char *path, uint8_t **rgba, int *width, int *height);
-/* the overlay's image loader: PNG as above, or baseline / extended-sequential JPEG (greyscale, YCbCr 4:4:4 / 4:2:2 / 4:2:0, restart intervals;
+/* the overlay's image loader: PNG as above, or sequential / progressive Huffman JPEG (greyscale, YCbCr 4:4:4 / 4:2:2 / 4:2:0, restart intervals;
  * libjpeg's integer arithmetic; alpha 255), chosen by the file's first bytes.  The reference loads both through ImageIO
  * (overlay/metaloverlayrenderer.m:166-245). */
 int vfhip_image_decode (const char *path, uint8_t **rgba, int *width, int *height);
@@ -320,7 +320,7 @@ typedef struct {
 typedef struct VfHipOverlay VfHipOverlay;
 VfHipOverlay *vfhip_overlay_new (int device);
 int vfhip_overlay_configure (VfHipOverlay *h, const VfHipVideoInfo *in, const VfHipVideoInfo *out);
-int vfhip_overlay_load_image (VfHipOverlay *h, const char *path);     /* -loadImageFromFile: (PNG or baseline JPEG; NULL / "" clears) */
+int vfhip_overlay_load_image (VfHipOverlay *h, const char *path);     /* -loadImageFromFile: (PNG or JPEG; NULL / "" clears) */
 int vfhip_overlay_set_image (VfHipOverlay *h, const uint8_t *rgba, int width, int height);   /* bytes as the shader sees them */
 void vfhip_overlay_clear_image (VfHipOverlay *h);
 int vfhip_overlay_image_size (VfHipOverlay *h, int *width, int *height);                     /* returns 1 when an image is loaded */

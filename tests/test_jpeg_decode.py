@@ -77,11 +77,52 @@ def test_greyscale_restart_intervals_optimised_tables(lib, tmp_path):
         assert np.array_equal(got, reference(p)), kw
 
 
+@pytest.mark.parametrize("subsampling", [0, 1, 2])
+@pytest.mark.parametrize("quality", [25, 75, 98])
+def test_progressive_equals_libjpeg(lib, tmp_path, subsampling, quality):
+    """SOF2: spectral selection and successive approximation (libjpeg's standard ten-scan script has DC and AC refinement scans and
+    end-of-band runs across blocks), with and without restart markers and optimised tables"""
+    for k, (w, h) in enumerate([(64, 48), (37, 23), (1, 1), (8, 8), (17, 9), (9, 17), (255, 3), (2, 130), (200, 120)]):
+        p = tmp_path / f"p{subsampling}_q{quality}_{w}x{h}.jpg"
+        kw = dict(quality=quality, subsampling=subsampling, progressive=True)
+        if k % 3 == 1:
+            kw["restart_marker_blocks"] = 2
+        if k % 2:
+            kw["optimize"] = True
+        try:
+            Image.fromarray(picture(w, h, w + h, 14.0)).save(p, **kw)
+        except TypeError:
+            kw.pop("restart_marker_blocks")
+            Image.fromarray(picture(w, h, w + h, 14.0)).save(p, **kw)
+        assert b"\xff\xc2" in p.read_bytes()
+        rc, got = decode(lib, p)
+        assert rc == 0, (kw, w, h, lib.vfhip_last_error_string())
+        ref = reference(p)
+        assert np.array_equal(got, ref), (kw, w, h, int(np.abs(got.astype(int) - ref.astype(int)).max()))
+    g = tmp_path / f"g{quality}.jpg"
+    Image.fromarray(picture(123, 77, 5, 20.0)[..., 0], mode="L").save(g, quality=quality, progressive=True)
+    rc, got = decode(lib, g)
+    assert rc == 0 and np.array_equal(got, reference(g))
+
+
+def test_progressive_truncated_or_damaged(lib, tmp_path):
+    p = tmp_path / "p.jpg"
+    Image.fromarray(picture(96, 64, 2, 10.0)).save(p, quality=85, progressive=True)
+    data = p.read_bytes()
+    for n in (len(data) // 4, len(data) // 2, len(data) - 5):
+        t = tmp_path / f"t{n}.jpg"
+        t.write_bytes(data[:n])
+        assert decode(lib, t)[0] < 0
+    # a sequential frame header in front of progressive scans: the scan parameters are refused, nothing is read out of range
+    b = bytearray(data)
+    b[data.index(b"\xff\xc2") + 1] = 0xc0
+    d = tmp_path / "d.jpg"
+    d.write_bytes(bytes(b))
+    assert decode(lib, d)[0] < 0
+
+
 def test_refusals_and_corrupt_files(lib, tmp_path):
     rgb = picture(64, 64, 3, 10.0)
-    p = tmp_path / "prog.jpg"
-    Image.fromarray(rgb).save(p, quality=80, progressive=True)
-    assert decode(lib, p)[0] == -2 and b"progressive" in lib.vfhip_last_error_string()
     c = tmp_path / "cmyk.jpg"
     Image.fromarray(np.dstack([rgb, rgb[..., :1]]), mode="CMYK").save(c, quality=80)
     assert decode(lib, c)[0] == -2 and b"CMYK" in lib.vfhip_last_error_string()
