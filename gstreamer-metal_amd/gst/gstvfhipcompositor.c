@@ -184,6 +184,7 @@ typedef struct
   VfHipCompositor *renderer;
   gint device_id, background;
   gboolean zero_size_is_unscaled;
+  gboolean ignore_inactive_pads;   /* handed to GstAggregator where it has the notion (>= 1.20), kept for the getter otherwise */
   GstVideoInfo out_info;
   gboolean have_out_info, out_is_device;
   guint64 n_frames;                             /* output frames since the last (re)start of the time line */
@@ -201,7 +202,7 @@ typedef struct
   GstAggregatorClass parent_class;
 } GstVfHipCompositorClass;
 
-enum { PROP_0, PROP_BACKGROUND, PROP_ZERO_SIZE_IS_UNSCALED, PROP_DEVICE_ID, PROP_ASYNC_DEPTH };
+enum { PROP_0, PROP_BACKGROUND, PROP_ZERO_SIZE_IS_UNSCALED, PROP_IGNORE_INACTIVE_PADS, PROP_DEVICE_ID, PROP_ASYNC_DEPTH };
 
 static GstStaticPadTemplate comp_src_template = GST_STATIC_PAD_TEMPLATE ("src", GST_PAD_SRC, GST_PAD_ALWAYS,
     GST_STATIC_CAPS (GST_VFHIP_CAPS (VFHIP_COMP_FORMATS)));
@@ -767,6 +768,18 @@ comp_set_property (GObject * object, guint id, const GValue * value, GParamSpec 
   switch (id) {
     case PROP_BACKGROUND: self->background = g_value_get_enum (value); break;
     case PROP_ZERO_SIZE_IS_UNSCALED: self->zero_size_is_unscaled = g_value_get_boolean (value); break;
+    case PROP_IGNORE_INACTIVE_PADS:
+      /* the reference forwards this to its base class (gstvfmetalcompositor.m:929-933): a live aggregator then stops waiting out its
+       * latency deadline for pads that never delivered a buffer.  It changes WHEN a frame is composed, never what is drawn (a pad without
+       * a buffer is skipped either way); base classes older than 1.20 have no such notion and keep waiting */
+      self->ignore_inactive_pads = g_value_get_boolean (value);
+#if GST_CHECK_VERSION (1, 20, 0)
+      gst_aggregator_set_ignore_inactive_pads (GST_AGGREGATOR (object), self->ignore_inactive_pads);
+#else
+      if (self->ignore_inactive_pads)
+        GST_INFO_OBJECT (object, "ignore-inactive-pads: this GStreamer's GstAggregator (< 1.20) always waits for its latency deadline");
+#endif
+      break;
     case PROP_DEVICE_ID: self->device_id = g_value_get_int (value); break;
     case PROP_ASYNC_DEPTH: self->async_depth = g_value_get_int (value); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
@@ -780,6 +793,7 @@ comp_get_property (GObject * object, guint id, GValue * value, GParamSpec * pspe
   switch (id) {
     case PROP_BACKGROUND: g_value_set_enum (value, self->background); break;
     case PROP_ZERO_SIZE_IS_UNSCALED: g_value_set_boolean (value, self->zero_size_is_unscaled); break;
+    case PROP_IGNORE_INACTIVE_PADS: g_value_set_boolean (value, self->ignore_inactive_pads); break;
     case PROP_DEVICE_ID: g_value_set_int (value, self->device_id); break;
     case PROP_ASYNC_DEPTH: g_value_set_int (value, self->async_depth); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
@@ -870,6 +884,8 @@ gst_vfhip_compositor_class_init (GstVfHipCompositorClass * klass)
   g_object_class_install_property (oc, PROP_ZERO_SIZE_IS_UNSCALED, g_param_spec_boolean ("zero-size-is-unscaled", "Zero size is unscaled",
           "If TRUE, then input video is unscaled in that dimension if width or height is 0 (for backwards compatibility)", TRUE,
           G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
+  g_object_class_install_property (oc, PROP_IGNORE_INACTIVE_PADS, g_param_spec_boolean ("ignore-inactive-pads", "Ignore inactive pads",
+          "Avoid timing out waiting for inactive pads", FALSE, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (oc, PROP_DEVICE_ID, g_param_spec_int ("device-id", "Device ID",
           "GPU ordinal to run on (-1: $VFHIP_DEVICE, else 0)", -1, 63, GST_VFHIP_DEFAULT_DEVICE_ID, G_PARAM_READWRITE | G_PARAM_STATIC_STRINGS));
   g_object_class_install_property (oc, PROP_ASYNC_DEPTH, gst_vfhip_async_depth_pspec ());

@@ -67,7 +67,7 @@ def test_transform_api():
 def test_compositor_api():
     """reference tests/test-compositor.sh:60-88: element + pad property surface (pad properties show on a requested pad)"""
     t = gst_env.inspect("vfhipcompositor").stdout
-    assert {"background", "zero-size-is-unscaled", "device-id", "async-depth"} <= props(t)
+    assert {"background", "zero-size-is-unscaled", "ignore-inactive-pads", "device-id", "async-depth"} <= props(t)
     for nick in ("checker", "black", "white", "transparent"):
         assert nick in t
     assert "GstAggregator" in t and "GstChildProxy" in t and "sink_%u" in t and "On request" in t
