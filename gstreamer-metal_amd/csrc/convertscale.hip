@@ -58,6 +58,8 @@ struct VfHipConvertScale {
   uint32_t hinc = 0;
   enum Kernel { K_NONE, K_HALF, K_GENERIC, K_TAPS, K_METAL, K_STAGED, K_NTAP, K_SAME, K_BLTILE } kernel = K_NONE;
   int bl_th = 32;                   // K_BLTILE: tile height (32, or 16 when a 32-row tile's source region does not fit)
+  int strip_rows = 4, strip_fill = 2;   // k_cs_taps_strip: rows per lane (1 = k_cs_taps), waves per SIMD a strip launch must give; $VFHIP_TAPS_ROWS / $VFHIP_TAPS_FILL at configure (A/B and test knobs)
+  bool taps_adjacent = false;       // bilinear: every row's two vertical taps are the same or adjacent source rows (k_cs_taps_strip's contract)
   Kernel same_fallback = K_NONE;    // K_SAME: what runs instead when a frame misses k_cs_yuv_same's alignment contract
   const char *kernel_name = "none";
   // K_STAGED: videoconvert at the input size into `mid` (when the format changes), then per-plane videoscale
@@ -521,15 +523,19 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
 
   // tap tables for the destination rectangle (host double arithmetic identical to GstVideoResampler's 2-tap/1-tap set-up)
   std::vector<int> vt ((size_t) h->rh * 4, 0), ht;
+  h->taps_adjacent = false;
+  { const char *e = getenv ("VFHIP_TAPS_ROWS"); h->strip_rows = (e && atoi (e) < 4) ? 1 : 4; e = getenv ("VFHIP_TAPS_FILL"); h->strip_fill = e ? std::max (0, atoi (e)) : 2; }
   if (method == VFHIP_SCALE_NEAREST) {
     for (int y = 0; y < h->rh; y++) vt[4 * y] = nearest_index (in->height, h->rh, y);
     ht.resize (h->rw);
     for (int x = 0; x < h->rw; x++) ht[x] = nearest_index (in->width, h->rw, x);
   } else {
+    h->taps_adjacent = true;
     for (int y = 0; y < h->rh; y++) {
       int i0 = y, i1 = y, w = 0;
       if (h->rh != in->height) { int t0; linear_taps (in->height, h->rh, y, 8, &i0, &i1, &t0, &w); }
       vt[4 * y] = i0; vt[4 * y + 1] = i1; vt[4 * y + 2] = w;
+      if (i1 - i0 < 0 || i1 - i0 > 1) h->taps_adjacent = false;
     }
   }
   h->hscale_on = (method == VFHIP_SCALE_BILINEAR && h->rw != in->width) ? 1 : 0;
@@ -559,8 +565,11 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
   // tile is smaller than the tile — k_cs_bilinear_tile converts each source pixel once per tile instead of four times per output pixel ...
   // ... and, for NV12 and the packed 4:2:2 inputs (whose region is converted eight pixels at a time), every down-scale whose tile regions fit the
   // LDS arrays as well (to ~2.2 : 1): NV12 1080p -> 720p 5.46 -> 4.59 us, UYVY 10.3 -> 4.5 us.  I420 (k_cs_taps<I420> is cheap: nearest chroma;
-  // 3.9 vs 4.3 us) and RGB inputs keep the per-pixel kernels for down-scales.
-  const bool bl_down = (in->format == VFHIP_FORMAT_NV12 || in_packed) && in->width >= 16;
+  // 3.9 vs 4.3 us, 3.3 in strips) and RGB inputs keep the per-pixel kernels for down-scales.
+  // ... except NV12 minified on BOTH axes: k_cs_taps_strip (shared chroma rows, strips of four rows) beats the tile there since round 2
+  // (1080p -> 720p 3.46 vs 5.03 us, 2160p -> 1920x1200 9.2 vs 14.4; profiles/r02x_taps_strip_ab.txt); one-axis down-scales stay with the tile
+  const bool strip_shape = in->format == VFHIP_FORMAT_NV12 && taps && h->taps_adjacent && h->hscale_on && out->width < in->width && out->height < in->height;
+  const bool bl_down = ((in->format == VFHIP_FORMAT_NV12 && !strip_shape) || in_packed) && in->width >= 16;
   if ((h->kernel == VfHipConvertScale::K_TAPS || h->kernel == VfHipConvertScale::K_GENERIC) && method == VFHIP_SCALE_BILINEAR &&
       h->rw == out->width && h->rh == out->height && h->rx == 0 && h->ry == 0 && ((out->width >= in->width && out->height >= in->height) || bl_down) &&
       getenv ("VFHIP_NO_BILINEAR_TILE") == nullptr) {
@@ -992,7 +1001,22 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
     // window loads need >= 2 luma columns and >= 4 chroma pairs per row; tiny frames and nearest / RGB inputs use k_cs_generic
     const VfHipConvertScale::Kernel kk = h->kernel == VfHipConvertScale::K_SAME ? h->same_fallback : h->kernel;
     const bool taps = kk == VfHipConvertScale::K_TAPS && p.in_w >= 8;
-    if (taps && p.in_fmt == VFHIP_FORMAT_I420) hipLaunchKernelGGL (k_cs_taps<true>, grid, dim3 (64, 4), 0, s, p);
+    // strips of output rows per lane (k_cs_taps_strip) when the shape allows and the launch still fills the chip
+    int rows = 1;
+    if (taps && h->taps_adjacent && p.hscale_on && p.rx == 0 && p.ry == 0 && p.rw == p.out_w && p.rh == p.out_h) {
+      rows = h->strip_rows;                   // (8-row strips measured the same as 4: profiles/r02x_taps_strip_ab.txt)
+      if ((size_t) grid.x * ((p.out_h + rows - 1) / rows) * n_frames < (size_t) h->strip_fill * 4 * h->dev->n_cu) rows = 1;      // the launch must still give that many waves per SIMD
+    }
+    if (rows > 1) {
+      dim3 sg (grid.x, (unsigned) (((p.out_h + rows - 1) / rows + 3) / 4), (unsigned) n_frames);
+      const bool i420 = p.in_fmt == VFHIP_FORMAT_I420;
+#define VF_STRIP(I, C, V) hipLaunchKernelGGL ((k_cs_taps_strip<I, C, V, 4>), sg, dim3 (64, 4), 0, s, p)
+      if (i420) { if (p.vfirst) VF_STRIP (true, false, true); else VF_STRIP (true, false, false); }
+      else if (p.cosited) { if (p.vfirst) VF_STRIP (false, true, true); else VF_STRIP (false, true, false); }
+      else { if (p.vfirst) VF_STRIP (false, false, true); else VF_STRIP (false, false, false); }
+#undef VF_STRIP
+    }
+    else if (taps && p.in_fmt == VFHIP_FORMAT_I420) hipLaunchKernelGGL (k_cs_taps<true>, grid, dim3 (64, 4), 0, s, p);
     else if (taps) hipLaunchKernelGGL (k_cs_taps<false>, grid, dim3 (64, 4), 0, s, p);
     else hipLaunchKernelGGL (k_cs_generic, grid, dim3 (64, 4), 0, s, p);
   }

@@ -17,6 +17,8 @@
 //                    [even, odd] byte pairs, v_dot4_u32_u8 for the horizontal tap.  DESIGN.md §5.1.
 //   k_cs_taps      : NV12 / I420 -> BGRA/RGBA, bilinear at any ratio: one output pixel per lane, window loads +
 //                    per-lane v_perm selectors, the same packed ORC pipeline.
+//   k_cs_taps_strip: the same for launches large enough to fill the chip with a quarter of the waves: four output rows per lane, the
+//                    chroma rows the two source rows share gathered and filtered once (its gathers, not its arithmetic, bound k_cs_taps).
 //   k_cs_generic   : everything else that is gst-exact with an RGB output (RGB inputs, nearest, tiny frames):
 //                    scalar, one output pixel per lane, 4 converted taps.
 // 4:2:0 outputs: convertscale_planar_kernels.h; `metal` numerics: convertscale_metal_kernels.h.
@@ -383,6 +385,7 @@ __global__ __launch_bounds__ (256, 8) void k_cs_i420_half (const CsParams p)
 // (orc_pair on the [xa, xa+1] pair), then the two taps in either pass order with GStreamer's 8-bit weights.
 typedef uint2 __attribute__ ((aligned (2))) uint2_a2;
 typedef uint16_t __attribute__ ((aligned (1))) uint16_a1;
+typedef uint32_t __attribute__ ((aligned (2))) uint32_a2;
 
 template <bool I420>
 __global__ __launch_bounds__ (256) void k_cs_taps (const CsParams p)
@@ -473,6 +476,150 @@ __global__ __launch_bounds__ (256) void k_cs_taps (const CsParams p)
     }
   }
   *o = p.out_rgba ? (ch[2] | (ch[1] << 8) | (ch[0] << 16) | 0xff000000u) : (ch[0] | (ch[1] << 8) | (ch[2] << 16) | 0xff000000u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_cs_taps_strip<I420, COSITED, VFIRST, ROWS>: k_cs_taps with a lane walking ROWS output rows of its column
+// ------------------------------------------------------------------------------------------------
+// k_cs_taps at one pixel per lane is bound by the texture-address unit, not by arithmetic: a gather whose lanes are 3 source pixels
+// apart costs 17 (2-byte) to 33 (8-byte) cycles per wave per CU against 6 for a coalesced load (tools/ubench/bperm_rate.hip), and an
+// output row took two luma and FOUR chroma-window gathers — 167 cycles per CU where its arithmetic needs ~100.  Here
+//   * the two source rows of a 2-tap output row are adjacent (i1 - i0 <= 1, host-checked), so their vertical chroma filters lean on
+//     two or three distinct chroma rows, not four: row j0 and its neighbour always, a third only when i0 is even — and the horizontal
+//     filter of a shared row is evaluated once (NV12: 2.5 instead of 4 window gathers on average, and 4-byte windows instead of 8-byte ones
+//     when the chroma is co-sited; I420: the four byte gathers per source row become one 2-byte gather per plane, shared when both rows
+//     sit on one chroma row);
+//   * what depends on the output COLUMN only (tap position, weights, window selectors: a third of k_cs_taps' instructions) is computed
+//     once per strip, and the next row's loads are issued before this row's arithmetic.
+// Same arithmetic as k_cs_taps, bit for bit.  Contract (host): bilinear with horizontal scaling, no borders, in_w >= 8, adjacent vertical
+// taps; the taps of a row are one 16-byte scalar load.
+struct TapRow { uint2 a, b, c; uint32_t yw[2]; };      // NV12: chroma windows of rows j0, jn0 and the third row; I420: a = {U, V} pairs of row j0, b = of row j1
+
+template <bool I420, bool COSITED, bool VFIRST, int ROWS>
+__global__ __launch_bounds__ (256) void k_cs_taps_strip (const CsParams p)
+{
+  const int x = blockIdx.x * 64 + threadIdx.x;
+  const int strip = __builtin_amdgcn_readfirstlane ((int) (blockIdx.y * 4 + threadIdx.y));
+  const int y0 = strip * ROWS, yend = min (y0 + ROWS, p.out_h);
+  if (x >= p.out_w || y0 >= p.out_h) return;
+  const uint8_t *yp = p.in[0] + (size_t) blockIdx.z * p.in_pitch;
+  const uint8_t *up = p.in[1] + (size_t) blockIdx.z * p.in_pitch;
+  const uint8_t *vp = I420 ? p.in[2] + (size_t) blockIdx.z * p.in_pitch : nullptr;
+  uint8_t *op = p.out + (size_t) blockIdx.z * p.out_pitch + 4 * (size_t) x;
+  const int4 *vt = reinterpret_cast<const int4 *> (p.vtab);
+  const uint32_t tt = (uint32_t) x * p.hinc;
+  const int xa = min ((int) (tt >> 16), p.in_w - 1), f = (int) ((tt >> 8) & 0xff), xb = min (xa + 1, p.in_w - 1);
+  const int cw = (p.in_w + 1) >> 1, chh = (p.in_h + 1) >> 1;
+  const uint32_t X = 0x80808080u, K1 = 0x01010101u;
+  const int bias = 128 << 16;
+  const int ybase = min (xa, p.in_w - 2);
+  const uint32_t oa = (uint32_t) (xa - ybase), ob = (uint32_t) (xb - ybase);
+  const uint32_t sely = oa | (oa << 8) | (ob << 16) | (ob << 24);
+  uint32_t sel_c = 0, sel_n = 0;
+  int cbase = 0;
+  const int ka = xa >> 1, kb = xb >> 1;
+  if (!I420) {
+    const int kna = (xa & 1) ? min (ka + 1, cw - 1) : (COSITED ? ka : max (ka - 1, 0));
+    const int knb = (xb & 1) ? min (kb + 1, cw - 1) : (COSITED ? kb : max (kb - 1, 0));
+    // co-sited chroma: an even column takes its own pair, an odd one averages it with the next — the two taps (one even, one odd column)
+    // touch pairs ka and ka + 1 only: a 4-byte window (half the gather cost of the 8-byte one the 3:1 filter of the other sitings needs)
+    cbase = COSITED ? min (ka, cw - 2) : max (min (ka - 1, cw - 4), 0);
+    const uint32_t fa = (uint32_t) (ka - cbase), fb = (uint32_t) (kb - cbase), ga = (uint32_t) (kna - cbase), gb = (uint32_t) (knb - cbase);
+    const uint32_t pc = (fa << 1) | (fb << 17), pn = (ga << 1) | (gb << 17);
+    sel_c = (pc | (pc << 8)) + 0x01000100u;
+    sel_n = (pn | (pn << 8)) + 0x01000100u;
+  } else {
+    // one 2-byte window per plane at column cbase holds the samples of both taps: [U(ka) V(ka) U(kb) V(kb)] = perm ({V window, U window})
+    cbase = min (ka, cw - 2);
+    const uint32_t fa = (uint32_t) (ka - cbase), fb = (uint32_t) (kb - cbase);
+    sel_c = fa | ((fa + 4u) << 8) | (fb << 16) | ((fb + 4u) << 24);
+  }
+  const uint32_t fw = (uint32_t) (256 - f) | ((uint32_t) f << 16);
+  const uint32_t cs1 = (uint32_t) p.is[1], cs2 = I420 ? (uint32_t) p.is[2] : 0u;
+
+  // chroma rows of a source row r: its own (j) and, for NV12's vertical filter, the one it leans on (jn)
+  auto jn_of = [&] (int r) { const int j = r >> 1; return (r & 1) ? min (j + 1, chh - 1) : max (j - 1, 0); };
+  auto win = [&] (int j) {
+    const uint8_t *a = up + ((uint32_t) j * cs1 + 2u * (uint32_t) cbase);
+    if (COSITED) return make_uint2 (*reinterpret_cast<const uint32_a2 *> (a), 0u);
+    return (uint2) *reinterpret_cast<const uint2_a2 *> (a);
+  };
+  auto win420 = [&] (int j) {
+    return make_uint2 ((uint32_t) *reinterpret_cast<const uint16_a1 *> (up + ((uint32_t) j * cs1 + (uint32_t) cbase)),
+                       (uint32_t) *reinterpret_cast<const uint16_a1 *> (vp + ((uint32_t) j * cs2 + (uint32_t) cbase)));
+  };
+  auto load = [&] (int i0, int i1, TapRow &L) {
+    const int j0 = i0 >> 1, j1 = i1 >> 1;
+    L.b = make_uint2 (0u, 0u); L.c = make_uint2 (0u, 0u);
+    if (I420) {
+      L.a = win420 (j0);
+      if (j1 != j0) L.b = win420 (j1);                                  // wave-uniform
+    } else {
+      const int jn0 = jn_of (i0), jn1 = jn_of (i1);
+      const int jc = (j1 != j0 && j1 != jn0) ? j1 : jn1;               // the one row (at most) that source row i0 does not already use
+      L.a = win (j0); L.b = win (jn0);
+      if (jc != j0 && jc != jn0) L.c = win (jc);                        // wave-uniform
+    }
+    L.yw[0] = (uint32_t) *reinterpret_cast<const uint16_a1 *> (yp + ((uint32_t) i0 * (uint32_t) p.is[0] + (uint32_t) ybase));
+    L.yw[1] = (uint32_t) *reinterpret_cast<const uint16_a1 *> (yp + ((uint32_t) i1 * (uint32_t) p.is[0] + (uint32_t) ybase));
+  };
+  auto hfilt = [&] (uint2 w) {                  // horizontal chroma filter of a window at this lane's two taps: co-sited even columns have n == a
+    const uint32_t a = perm_b32 (w.y, w.x, sel_c), n = perm_b32 (w.y, w.x, sel_n);
+    return COSITED ? lerp_u8 (a, n, K1) : filt31_u8 (a, n);
+  };
+  auto compute = [&] (const TapRow &L, int i0, int i1, int w, int y) {
+    uint32_t uv[2];                             // [U(xa) V(xa) U(xb) V(xb)] of source rows i0 / i1, already ^0x80
+    const int j0 = i0 >> 1, j1 = i1 >> 1;
+    if (I420) {
+      uv[0] = perm_b32 (L.a.y, L.a.x, sel_c) ^ X;
+      uv[1] = j1 != j0 ? perm_b32 (L.b.y, L.b.x, sel_c) ^ X : uv[0];
+    } else {
+      const int jn0 = jn_of (i0), jn1 = jn_of (i1);
+      const uint32_t ha = hfilt (L.a), hb = hfilt (L.b);
+      uint32_t hc = 0;
+      if ((j1 != j0 && j1 != jn0) || (jn1 != j0 && jn1 != jn0)) hc = hfilt (L.c);
+      const uint32_t h1 = j1 == j0 ? ha : (j1 == jn0 ? hb : hc), hn1 = jn1 == j0 ? ha : (jn1 == jn0 ? hb : hc);
+      uv[0] = filt31_u8 (ha, hb) ^ X;           // vertical (3a+b+2)>>2
+      uv[1] = filt31_u8 (h1, hn1) ^ X;
+    }
+    uint32_t bb[2], gg[2], rr[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+      orc_pair (perm_b32 (0u, L.yw[t] ^ 0x8080u, sely), perm_b32 (0u, uv[t], 0x01010000u), perm_b32 (0u, uv[t], 0x03030202u), p.c, bias, bb[t], gg[t], rr[t]);
+    const uint32_t ww = (uint32_t) w | ((uint32_t) w << 16), wm = 0x01000100u - ww;
+    uint32_t ch[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const uint32_t q0 = c == 0 ? bb[0] : (c == 1 ? gg[0] : rr[0]), q1 = c == 0 ? bb[1] : (c == 1 ? gg[1] : rr[1]);
+      const u16x2 e0 = as_u16x2 (perm_b32 (0u, q0, 0x0c010c00u)), e1 = as_u16x2 (perm_b32 (0u, q1, 0x0c010c00u));
+      if (VFIRST) {
+        u16x2 t = e0 * as_u16x2 (wm) + as_u16x2 (0x00800080u);
+        t = e1 * as_u16x2 (ww) + t;
+        const uint32_t v = (as_u32 (t) >> 8) & 0x00ff00ffu;
+        ch[c] = __builtin_amdgcn_udot2 (as_u16x2 (v), as_u16x2 (fw), 0u, false) >> 8;
+      } else {
+        const int h0 = (int) (__builtin_amdgcn_udot2 (e0, as_u16x2 (fw), 0u, false) >> 8);
+        const int h1 = (int) (__builtin_amdgcn_udot2 (e1, as_u16x2 (fw), 0u, false) >> 8);
+        ch[c] = (uint32_t) (h0 + (((h1 - h0) * w + 128) >> 8));
+      }
+    }
+    const uint32_t px = p.out_rgba ? (ch[2] | (ch[1] << 8) | (ch[0] << 16) | 0xff000000u) : (ch[0] | (ch[1] << 8) | (ch[2] << 16) | 0xff000000u);
+    *reinterpret_cast<uint32_t *> (op + (uint32_t) y * (uint32_t) p.os) = px;
+  };
+
+  // every row's taps up front: scalar loads (a load after the first store could alias it and would become a per-lane load)
+  int4 tp[ROWS + 1];
+#pragma unroll
+  for (int r = 0; r <= ROWS; r++) tp[r] = vt[min (y0 + r, p.out_h - 1)];
+  TapRow L[2];
+  load (tp[0].x, tp[0].y, L[0]);
+#pragma unroll
+  for (int r = 0; r < ROWS; r++) {
+    if (y0 + r >= yend) break;                                       // wave-uniform
+    load (tp[r + 1].x, tp[r + 1].y, L[(r + 1) & 1]);                 // the next row's loads are in flight during this row's arithmetic
+    __builtin_amdgcn_sched_barrier (0);                              // (the scheduler otherwise sinks them below the first waits)
+    compute (L[r & 1], tp[r].x, tp[r].y, tp[r].z, y0 + r);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

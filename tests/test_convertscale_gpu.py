@@ -843,6 +843,8 @@ def test_bilinear_tile_against_oracle_and_per_pixel_kernels(vfhip, oracle, ifmt,
         assert kname == "k_cs_bilinear_tile", kname             # no minification: always the tile kernel
     elif ifmt in ("BGRA", "I420") or w < 16:
         assert kname in ("k_cs_taps", "k_cs_generic"), kname    # down-scales of RGB and I420 inputs stay per pixel
+    elif ifmt == "NV12" and ow < w and oh < h:
+        assert kname == "k_cs_taps", kname                      # NV12 minified on both axes: k_cs_taps (in strips when the launch is large enough)
     else:
         assert kname in ("k_cs_bilinear_tile", "k_cs_taps", "k_cs_generic"), kname      # YUV inputs: the tile kernel while a tile's source region fits its LDS arrays
         if w / ow <= 1.6 and h / oh <= 1.6:
@@ -852,3 +854,28 @@ def test_bilinear_tile_against_oracle_and_per_pixel_kernels(vfhip, oracle, ifmt,
     old, kname = run(vfhip, ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", "RGBA", ow, oh)
     monkeypatch.delenv("VFHIP_NO_BILINEAR_TILE")
     assert kname in ("k_cs_taps", "k_cs_generic") and np.array_equal(old, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ifmt", ["NV12", "I420"])
+@pytest.mark.parametrize("site", ["mpeg2", "jpeg"])
+@pytest.mark.parametrize("w,h,ow,oh", [(192, 108, 128, 72), (200, 113, 67, 51), (1920, 1080, 640, 480), (130, 70, 61, 69), (130, 70, 129, 31), (64, 36, 21, 9), (96, 54, 95, 53),
+                                       (320, 180, 100, 179), (258, 258, 65, 65), (640, 360, 213, 120), (18, 10, 9, 5), (100, 64, 99, 200), (8, 8, 3, 3), (1000, 30, 64, 7)])
+def test_taps_strip_kernel(vfhip, oracle, ifmt, site, w, h, ow, oh, monkeypatch):
+    """k_cs_taps_strip (four output rows per lane, the two source rows' shared chroma rows fetched and filtered once, NV12 and I420 windows) at sizes
+    that leave partial strips, partial waves, clamped edge rows and both pass orders — forced on whatever the launch size — against the oracle
+    and against k_cs_taps at one row per lane"""
+    rng = np.random.default_rng(w * 13 + oh)
+    raw = rng.integers(0, 256, vfhip.plane_layout(ifmt, w, h)[1], dtype=np.uint8)
+    col = "bt601" if site == "jpeg" else "bt709"
+    for ofmt in ("BGRA", "RGBA"):
+        want = oracle.convertscale(ifmt, w, h, raw, col, site, "bilinear", ofmt, ow, oh)
+        monkeypatch.setenv("VFHIP_TAPS_FILL", "0")
+        got, kname = run(vfhip, ifmt, w, h, raw, col, site, "bilinear", ofmt, ow, oh)
+        assert kname in ("k_cs_taps", "k_cs_bilinear_tile"), kname
+        assert np.array_equal(got, want), (ofmt, "strips")
+        monkeypatch.setenv("VFHIP_TAPS_ROWS", "1")
+        one, kname1 = run(vfhip, ifmt, w, h, raw, col, site, "bilinear", ofmt, ow, oh)
+        monkeypatch.delenv("VFHIP_TAPS_ROWS")
+        monkeypatch.delenv("VFHIP_TAPS_FILL")
+        assert kname1 == kname and np.array_equal(one, want), (ofmt, "one row per lane")
