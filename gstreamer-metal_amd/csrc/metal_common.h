@@ -317,10 +317,145 @@ __device__ __forceinline__ void store_block (const OutImg &o, int bx, int by, co
   }
 }
 
+// ---- 4 x 2 pixels per lane on 4:2:0 frames: the same values as fetch_1to1 (linear chroma) / store_block, with dword accesses ---------------
+// fetch420_quad: pixels (x0 .. x0+3, y0 .. y0+1) of an NV12 / I420 frame, x0 = 4 * xq, y0 = 2 * by, as fetch_1to1 (im, x, y, true) returns them.
+// A linear sampler at texcoord (x + .5) / W sits at 0.5 x - 0.25 on the half-size plane: an even column 2k takes chroma columns (k - 1, k) with
+// weight .75 on the second, an odd one (k, k + 1) with .25 — so the eight pixels read chroma columns 2xq - 1 .. 2xq + 2 of rows by - 1 .. by + 1
+// (edge-clamped like lin_taps_px): three 8-byte windows (NV12; 4-byte per plane for I420) instead of 32 two-byte taps, every texel converted once,
+// the interpolation in fetch_1to1's order (horizontal, then vertical) with its weights.  Contract: W % 4 == 0, W >= 8, even H, 4-byte aligned
+// luma rows, 2-byte aligned NV12 chroma rows.
+__device__ __forceinline__ void fetch420_quad (const Img &im, int xq, int by, F4 out[2][4])
+{
+  typedef uint2 __attribute__ ((aligned (2))) uint2_a2;
+  typedef uint32_t __attribute__ ((aligned (1))) uint32_a1;
+  const int cw = im.w >> 1, chh = im.h >> 1;
+  const int cbase = iclamp (2 * xq - 1, 0, cw - 4);
+  uint32_t sel = 0;                                        // byte t: window index of chroma column clamp (2xq - 1 + t)
+#pragma unroll
+  for (int t = 0; t < 4; t++) sel |= (uint32_t) (iclamp (2 * xq - 1 + t, 0, cw - 1) - cbase) << (8 * t);
+  const int jr[3] = { max (by - 1, 0), by, min (by + 1, chh - 1) };
+  float cu[3][4], cv[3][4];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    uint32_t uq, vq;                                       // [c0 c1 c2 c3] of this row
+    if (im.fmt == VFHIP_FORMAT_NV12) {
+      const uint2 w = *reinterpret_cast<const uint2_a2 *> (im.p[1] + ((uint32_t) jr[r] * (uint32_t) im.s[1] + 2u * (uint32_t) cbase));
+      const uint32_t su = sel << 1;                        // pair i = bytes (2i, 2i + 1)
+      uq = __builtin_amdgcn_perm (w.y, w.x, su); vq = __builtin_amdgcn_perm (w.y, w.x, su + 0x01010101u);
+    } else {
+      const uint32_t wu = *reinterpret_cast<const uint32_a1 *> (im.p[1] + ((uint32_t) jr[r] * (uint32_t) im.s[1] + (uint32_t) cbase));
+      const uint32_t wv = *reinterpret_cast<const uint32_a1 *> (im.p[2] + ((uint32_t) jr[r] * (uint32_t) im.s[2] + (uint32_t) cbase));
+      uq = __builtin_amdgcn_perm (0u, wu, sel); vq = __builtin_amdgcn_perm (0u, wv, sel);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) { cu[r][t] = un8 ((uq >> (8 * t)) & 0xffu); cv[r][t] = un8 ((vq >> (8 * t)) & 0xffu); }
+  }
+  float hu[3][4], hv[3][4];                                // horizontal taps of the four pixel columns, per chroma row
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int dx = 0; dx < 4; dx++) {
+      const int ta = (dx + 1) >> 1;                        // dx 0: (0, 1) .75 | 1: (1, 2) .25 | 2: (1, 2) .75 | 3: (2, 3) .25
+      const float f = (dx & 1) ? 0.25f : 0.75f;
+      hu[r][dx] = lerp2 (cu[r][ta], cu[r][ta + 1], f); hv[r][dx] = lerp2 (cv[r][ta], cv[r][ta + 1], f);
+    }
+#pragma unroll
+  for (int dy = 0; dy < 2; dy++) {
+    const uint32_t yq = *reinterpret_cast<const uint32_t *> (im.p[0] + ((uint32_t) (2 * by + dy) * (uint32_t) im.s[0] + 4u * (uint32_t) xq));
+#pragma unroll
+    for (int dx = 0; dx < 4; dx++) {
+      // row 2j leans on chroma rows (j - 1, j) with .75, row 2j + 1 on (j, j + 1) with .25
+      const float cb = dy ? lerp2 (hu[1][dx], hu[2][dx], 0.25f) : lerp2 (hu[0][dx], hu[1][dx], 0.75f);
+      const float cr = dy ? lerp2 (hv[1][dx], hv[2][dx], 0.25f) : lerp2 (hv[0][dx], hv[1][dx], 0.75f);
+      out[dy][dx] = yuv_to_rgb (un8 ((yq >> (8 * dx)) & 0xffu), cb, cr, im.m709);
+    }
+  }
+}
+
+// the same 4 x 2 pixels of any of the four element formats (BGRA / RGBA: one 16-byte load per row; contract: 16-byte aligned rows)
+__device__ __forceinline__ void fetch_quad (const Img &im, int xq, int by, F4 out[2][4])
+{
+  if (im.fmt == VFHIP_FORMAT_NV12 || im.fmt == VFHIP_FORMAT_I420) { fetch420_quad (im, xq, by, out); return; }
+  typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
+  const bool rgba = im.fmt == VFHIP_FORMAT_RGBA;
+#pragma unroll
+  for (int dy = 0; dy < 2; dy++) {
+    const v4u t = *(reinterpret_cast<const v4u *> (im.p[0] + (size_t) (2 * by + dy) * im.s[0]) + xq);
+#pragma unroll
+    for (int dx = 0; dx < 4; dx++) {
+      F4 o;
+      o.g = un8 ((t[dx] >> 8) & 0xff); o.a = un8 (t[dx] >> 24);
+      if (rgba) { o.r = un8 (t[dx] & 0xff); o.b = un8 ((t[dx] >> 16) & 0xff); }
+      else { o.b = un8 (t[dx] & 0xff); o.r = un8 ((t[dx] >> 16) & 0xff); }
+      out[dy][dx] = o;
+    }
+  }
+}
+
+// store_quad: what store_block (o, 2 * xq, by, left half) + store_block (o, 2 * xq + 1, by, right half) write, as one dword per luma row and one
+// (NV12) chroma dword, or two 16-byte RGBA rows.  Contract: BGRA / RGBA / NV12 / I420 output, W % 4 == 0, even H, rows aligned for those stores.
+__device__ __forceinline__ void store_quad (const OutImg &o, int xq, int by, const uint32_t q[2][4])
+{
+  typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
+  if (o.fmt == VFHIP_FORMAT_BGRA || o.fmt == VFHIP_FORMAT_RGBA) {
+#pragma unroll
+    for (int dy = 0; dy < 2; dy++) {
+      v4u v = { q[dy][0], q[dy][1], q[dy][2], q[dy][3] };
+      if (o.fmt == VFHIP_FORMAT_BGRA) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = __builtin_amdgcn_perm (0u, v[k], 0x03000102u);
+      }
+      __builtin_nontemporal_store (v, reinterpret_cast<v4u *> (o.p[0] + (size_t) (2 * by + dy) * o.s[0]) + xq);
+    }
+    return;
+  }
+  uint32_t yrow[2] = { 0, 0 }, uu[2], vv[2];
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    float sr = 0.0f, sg = 0.0f, sb = 0.0f;
+#pragma unroll
+    for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+      for (int dx = 0; dx < 2; dx++) {
+        const F4 px = unpack_rgba8 (q[dy][2 * c + dx]);
+        sr += px.r; sg += px.g; sb += px.b;
+        float y, u, v; rgb_to_yuv (px.r, px.g, px.b, o.m709, &y, &u, &v);
+        yrow[dy] |= quant8 (y) << (8 * (2 * c + dx));
+      }
+    sr *= 0.25f; sg *= 0.25f; sb *= 0.25f;
+    float y, u, v; rgb_to_yuv (sr, sg, sb, o.m709, &y, &u, &v);
+    uu[c] = quant8 (u); vv[c] = quant8 (v);
+  }
+#pragma unroll
+  for (int dy = 0; dy < 2; dy++)
+    __builtin_nontemporal_store (yrow[dy], reinterpret_cast<uint32_t *> (o.p[0] + (size_t) (2 * by + dy) * o.s[0]) + xq);
+  if (o.fmt == VFHIP_FORMAT_NV12)
+    __builtin_nontemporal_store (uu[0] | (vv[0] << 8) | (uu[1] << 16) | (vv[1] << 24), reinterpret_cast<uint32_t *> (o.p[1] + (size_t) by * o.s[1]) + xq);
+  else {
+    *reinterpret_cast<uint16_t *> (o.p[1] + (size_t) by * o.s[1] + 2 * xq) = (uint16_t) (uu[0] | (uu[1] << 8));
+    *reinterpret_cast<uint16_t *> (o.p[2] + (size_t) by * o.s[2] + 2 * xq) = (uint16_t) (vv[0] | (vv[1] << 8));
+  }
+}
+
 // host helpers: VfHipFrame -> device image descriptors
 // frame k of a batch: every plane pointer advanced by k * frame pitch (wave-uniform, scalar arithmetic)
 __device__ __forceinline__ Img img_at (const Img &im, size_t off) { Img r = im; r.p[0] += off; r.p[1] += off; r.p[2] += off; return r; }
 __device__ __forceinline__ OutImg out_at (const OutImg &im, size_t off) { OutImg r = im; r.p[0] += off; r.p[1] += off; r.p[2] += off; return r; }
+
+// the contract of fetch_quad / store_quad for a (frame, batch pitch) pair: BGRA / RGBA / NV12 / I420, W % 4 == 0, W >= 8, even H, rows aligned for the
+// 16-byte (RGB), dword (luma, NV12 chroma out), 2-byte (NV12 chroma in, I420 chroma out) accesses
+static inline bool quad_frame_ok (const VfHipFrame *f, size_t pitch, bool is_output)
+{
+  const int fmt = f->info.format, w = f->info.width, h = f->info.height;
+  if ((w & 3) || (h & 1) || w < 8) return false;
+  const uintptr_t a0 = (uintptr_t) f->data[0] | (uintptr_t) f->stride[0] | (uintptr_t) pitch;
+  if (fmt == VFHIP_FORMAT_BGRA || fmt == VFHIP_FORMAT_RGBA) return !(a0 & 15);
+  if (fmt != VFHIP_FORMAT_NV12 && fmt != VFHIP_FORMAT_I420) return false;
+  if (a0 & 3) return false;
+  const uintptr_t a1 = (uintptr_t) f->data[1] | (uintptr_t) f->stride[1], a2 = (uintptr_t) f->data[2] | (uintptr_t) f->stride[2];
+  if (fmt == VFHIP_FORMAT_NV12) return !(a1 & (is_output ? 3 : 1));
+  return is_output ? !((a1 | a2) & 1) : true;
+}
 
 static inline Img make_img (const VfHipFrame *f)
 {

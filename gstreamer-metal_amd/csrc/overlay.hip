@@ -47,6 +47,38 @@ __global__ __launch_bounds__ (256) void k_overlay (const OverlayKParams pp)
   metal::store_block (p.out, bx, by, q);
 }
 
+// k_overlay_quad: the same per-pixel operations with 4 x 2 pixels per lane (metal::fetch_quad / store_quad: window loads for a 4:2:0 input's
+// linear chroma, 16-byte RGB rows, dword luma / chroma stores) for frames that meet their alignment contract — NV12 1080p 8.0 -> see DESIGN §5.3.
+// Only the lanes under the image sample it (a per-lane branch like k_overlay's).
+__global__ __launch_bounds__ (256) void k_overlay_quad (const OverlayKParams pp)
+{
+  OverlayKParams p = pp;
+  p.in = metal::img_at (pp.in, blockIdx.z * pp.in_pitch); p.out = metal::out_at (pp.out, blockIdx.z * pp.out_pitch);
+  const int xq = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
+  if (4 * xq >= p.out.w || 2 * by >= p.out.h) return;
+  metal::F4 c[2][4];
+  metal::fetch_quad (p.in, xq, by, c);
+  uint32_t q[2][4];
+#pragma unroll
+  for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+    for (int dx = 0; dx < 4; dx++) {
+      const int x = 4 * xq + dx, y = 2 * by + dy;
+      metal::F4 v = c[dy][dx];
+      if (p.ov.p[0]) {
+        const float tu = ((float) x + 0.5f) / (float) p.out.w, tv = ((float) y + 0.5f) / (float) p.out.h;
+        const float px = tu * (float) p.out.w, py = tv * (float) p.out.h;
+        if (px >= p.x && px < p.x + p.w && py >= p.y && py < p.y + p.h) {
+          const metal::F4 o = metal::sample_rgba (p.ov, (px - p.x) / p.w, (py - p.y) / p.h, true);
+          const float a = o.a * p.alpha;
+          v.r = v.r + (o.r - v.r) * a; v.g = v.g + (o.g - v.g) * a; v.b = v.b + (o.b - v.b) * a;
+        }
+      }
+      q[dy][dx] = metal::quant_rgba8 (v);
+    }
+  metal::store_quad (p.out, xq, by, q);
+}
+
 }  // namespace vfhip
 
 struct VfHipOverlay {
@@ -72,9 +104,14 @@ static int ov_launch (VfHipOverlay *h, const VfHipFrame *in, VfHipFrame *out, co
     p.w = prm->width > 0.0f ? prm->width : (float) h->img_w;        // 0 = the image's own size (metaloverlayrenderer.m:268-269)
     p.h = prm->height > 0.0f ? prm->height : (float) h->img_h;
   }
-  const int bw = (h->out.width + 1) / 2, bh = (h->out.height + 1) / 2;
-  dim3 grid ((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4), (unsigned) n_frames);
-  hipLaunchKernelGGL (k_overlay, grid, dim3 (64, 4), 0, s, p);
+  if (getenv ("VFHIP_OV_BLOCKS") == nullptr && metal::quad_frame_ok (in, in_pitch, false) && metal::quad_frame_ok (out, out_pitch, true)) {      // (knob: A/B and tests)
+    dim3 grid ((unsigned) ((h->out.width / 4 + 63) / 64), (unsigned) ((h->out.height / 2 + 3) / 4), (unsigned) n_frames);
+    hipLaunchKernelGGL (k_overlay_quad, grid, dim3 (64, 4), 0, s, p);
+  } else {
+    const int bw = (h->out.width + 1) / 2, bh = (h->out.height + 1) / 2;
+    dim3 grid ((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4), (unsigned) n_frames);
+    hipLaunchKernelGGL (k_overlay, grid, dim3 (64, 4), 0, s, p);
+  }
   VFHIP_CHECK_HIP (hipGetLastError ());
   return VFHIP_OK;
 }

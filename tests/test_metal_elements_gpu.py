@@ -785,3 +785,57 @@ def test_overlay_jpeg_logo(vfhip, metalref, tmp_path):
     frame = smooth("NV12", w, h, 33)
     close(ov.process(frame, x=20, y=12, alpha=0.8), metalref.overlay("NV12", w, h, frame, "NV12", ref, x=20, y=12, alpha=0.8), "jpeg overlay")
     ov.close()
+
+
+@pytest.mark.parametrize("ifmt", ["NV12", "I420"])
+@pytest.mark.parametrize("ofmt", ["NV12", "I420", "BGRA", "RGBA"])
+@pytest.mark.parametrize("w,h", [(96, 40), (8, 2), (200, 114), (12, 6), (1920, 1080)])
+def test_videofilter_420_quad_kernel(vfhip, metalref, ifmt, ofmt, w, h, monkeypatch):
+    """k_vf_point_420q (4 x 2 pixels per lane: the block's chroma neighbourhood as three window loads, dword / 16-byte stores) writes the
+    bytes k_vf_point's 2 x 2 blocks write — EQUAL, not close: the same operations on the same inputs — and both sit on the oracle; edge
+    lanes (clamped chroma columns and rows), the smallest frame and 1080p"""
+    rng = np.random.default_rng(w + h)
+    raw = rng.integers(0, 256, ol.raw_layout(ifmt, w, h)[1], dtype=np.uint8) if (w, h) != (1920, 1080) else smooth(ifmt, w, h, 3)
+    vf = vfhip.VideoFilter(0)
+    vf.configure(ifmt, w, h, ofmt, colorimetry="bt709")
+    n = 5
+    g = np.linspace(0, 1, n, dtype=np.float32)
+    lut = np.ones((n, n, n, 4), np.float32)
+    lut[..., 0] = g[None, None, :] * 0.8; lut[..., 1] = g[None, :, None] ** 1.3; lut[..., 2] = g[:, None, None]
+    for name, kw, use_lut in (("identity", {}, False), ("colour", dict(brightness=0.1, contrast=1.2, saturation=1.3, hue=0.4, gamma=1.6, sepia=0.3, vignette=0.4), True)):
+        prm = vfhip.filter_params(**kw)
+        if use_lut:
+            vf.set_lut(lut)
+        quad = vf.process(raw, prm)
+        monkeypatch.setenv("VFHIP_VF_BLOCKS", "1")
+        blocks = vf.process(raw, prm)
+        monkeypatch.delenv("VFHIP_VF_BLOCKS")
+        assert np.array_equal(quad, blocks), (name, int(np.abs(quad.astype(int) - blocks.astype(int)).max()))
+        if (w, h) != (1920, 1080):
+            close(quad, metalref.videofilter(ifmt, w, h, raw, ofmt, ol.mr_filter_params(prm), lut=lut if use_lut else None, m709=True), f"{name} {ifmt}->{ofmt}", max_off_by_one=0.08)
+    vf.close()
+
+
+@pytest.mark.parametrize("ifmt,ofmt", [("BGRA", "BGRA"), ("RGBA", "NV12"), ("NV12", "NV12"), ("I420", "BGRA"), ("NV12", "I420"), ("I420", "I420"), ("BGRA", "RGBA")])
+@pytest.mark.parametrize("w,h", [(96, 54), (8, 2), (200, 114), (1920, 1080)])
+def test_overlay_quad_kernel(vfhip, metalref, ifmt, ofmt, w, h, monkeypatch):
+    """k_overlay_quad (4 x 2 pixels per lane) writes the bytes k_overlay's 2 x 2 blocks write — equal, not close — with and without an image,
+    the image hanging over the frame's edges; and sits on the oracle"""
+    rng = np.random.default_rng(w * 3 + h)
+    raw = rng.integers(0, 256, ol.raw_layout(ifmt, w, h)[1], dtype=np.uint8) if (w, h) != (1920, 1080) else smooth(ifmt, w, h, 4)
+    img = _logo(24, 16)
+    ov = vfhip.Overlay(0)
+    ov.configure(ifmt, w, h, ofmt, colorimetry="bt709")
+    for kw in (None, dict(x=w / 3, y=h / 4, alpha=0.8), dict(x=-5, y=h - 9, width=50, height=30, alpha=1.0), dict(x=w - 10.5, y=-3.25, width=33.3, height=20.7, alpha=0.6)):
+        if kw is None:
+            ov.clear_image(); kw = {}
+        else:
+            ov.set_image(img)
+        quad = ov.process(raw, **kw)
+        monkeypatch.setenv("VFHIP_OV_BLOCKS", "1")
+        blocks = ov.process(raw, **kw)
+        monkeypatch.delenv("VFHIP_OV_BLOCKS")
+        assert np.array_equal(quad, blocks), (kw, int(np.abs(quad.astype(int) - blocks.astype(int)).max()))
+        if (w, h) != (1920, 1080):
+            close(quad, metalref.overlay(ifmt, w, h, raw, ofmt, img if kw else None, m709=True, **kw), f"overlay {ifmt}->{ofmt} {kw}", max_off_by_one=0.03)
+    ov.close()
