@@ -1095,7 +1095,7 @@ static int comp_launch (VfHipCompositor *h, const VfHipPadInput *pads, int count
   const int passes = count <= COMP_MAX_LAYERS ? 1 : (count + COMP_MAX_LAYERS - 1) / COMP_MAX_LAYERS;
   if (passes > 1)
     for (int k = 0; k < 2; k++)
-      if (!h->scratch[k]) VFHIP_CHECK_HIP (hipMalloc (&h->scratch[k], (size_t) w * hh * 4));
+      if (!h->scratch[k]) VFHIP_CHECK_HIP (dev_malloc (&h->scratch[k], (size_t) w * hh * 4));
   for (int pass = 0; pass < passes; pass++) {
     CompParams p {};
     const int first = pass * COMP_MAX_LAYERS, n = count - first < COMP_MAX_LAYERS ? count - first : COMP_MAX_LAYERS;

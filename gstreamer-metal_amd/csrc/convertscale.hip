@@ -196,10 +196,13 @@ static int ntap_table (int kernel, int in, int out, std::vector<int2> &tab)
 
 static int cubic_table (int in, int out, std::vector<int2> &tab) { return ntap_table (0, in, out, tab); }
 
+// the stream of the handle being configured (configure holds the handle's mutex; one handle per thread at a time)
+static thread_local hipStream_t t_upload_stream = nullptr;
+
 static int upload_int2 (const std::vector<int2> &v, int2 **dst)
 {
-  VFHIP_CHECK_HIP (hipMalloc (dst, v.size () * sizeof (int2)));
-  VFHIP_CHECK_HIP (hipMemcpy (*dst, v.data (), v.size () * sizeof (int2), hipMemcpyHostToDevice));
+  VFHIP_CHECK_HIP (dev_malloc (dst, v.size () * sizeof (int2)));
+  VFHIP_CHECK_HIP (upload_in_stream (*dst, v.data (), v.size () * sizeof (int2), t_upload_stream));
   return VFHIP_OK;
 }
 
@@ -207,8 +210,8 @@ static int upload_ints (const std::vector<int> &v, int **dst)
 {
   *dst = nullptr;
   if (v.empty ()) return VFHIP_OK;
-  VFHIP_CHECK_HIP (hipMalloc (dst, v.size () * sizeof (int)));
-  VFHIP_CHECK_HIP (hipMemcpy (*dst, v.data (), v.size () * sizeof (int), hipMemcpyHostToDevice));
+  VFHIP_CHECK_HIP (dev_malloc (dst, v.size () * sizeof (int)));
+  VFHIP_CHECK_HIP (upload_in_stream (*dst, v.data (), v.size () * sizeof (int), t_upload_stream));
   return VFHIP_OK;
 }
 
@@ -371,6 +374,7 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
   if (!h || !in || !out) return set_error (VFHIP_ERR_INVALID, "null argument");
   std::lock_guard<std::mutex> lk (h->mu);
   if (h->fl.count) return set_error (VFHIP_ERR_INVALID, "configure with %d submitted frame(s) still in flight: wait for them first", h->fl.count);
+  t_upload_stream = h->st.s_compute;
   if (in->width <= 0 || in->height <= 0 || out->width <= 0 || out->height <= 0 || in->width > 32768 || in->height > 32768 ||
       out->width > 32768 || out->height > 32768)
     return set_error (VFHIP_ERR_INVALID, "bad frame size %dx%d -> %dx%d", in->width, in->height, out->width, out->height);
@@ -451,9 +455,9 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
         mid.width = iw; mid.height = ih;
         int rc = vfhip_convertscale_configure (h->conv, in, &mid, VFHIP_SCALE_BILINEAR, 0, 0, VFHIP_NUMERICS_GST_EXACT);
         if (rc) return rc;
-        VFHIP_CHECK_HIP (hipMalloc (&h->nt_mid0, (size_t) iw * ih * 4 + 256));
+        VFHIP_CHECK_HIP (dev_malloc (&h->nt_mid0, (size_t) iw * ih * 4 + 256));
       }
-      if (h->nt_h && h->nt_v) VFHIP_CHECK_HIP (hipMalloc (&h->nt_mid1, (h->vfirst ? (size_t) iw * oh : (size_t) ow * ih) * 4 + 256));
+      if (h->nt_h && h->nt_v) VFHIP_CHECK_HIP (dev_malloc (&h->nt_mid1, (h->vfirst ? (size_t) iw * oh : (size_t) ow * ih) * 4 + 256));
     }
     h->kernel = VfHipConvertScale::K_NTAP; h->kernel_name = h->nt_tile ? "k_cs_cubic_tile" : "k_cs_ntap";
     h->configured = true;
@@ -482,7 +486,7 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
       if (kern < 0) for (int k = 0; k < 3; k++) h->plane[k].vfirst = !nn && ih > oh + 2;
       if (h->need_convert && h->need_scale) {
         h->mid_bytes = (((size_t) 4 * ((iw + 1) / 2) + 15) / 16 * 16) * ih + 1024;
-        VFHIP_CHECK_HIP (hipMalloc (&h->mid, h->mid_bytes));
+        VFHIP_CHECK_HIP (dev_malloc (&h->mid, h->mid_bytes));
         h->mid_frames = 1;
       }
       h->kernel = VfHipConvertScale::K_STAGED; h->kernel_name = "k_cs_staged_422";
@@ -501,7 +505,7 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
     if (h->need_convert && h->need_scale) {        // intermediate frame: output format at the input size
       const size_t ys = ((size_t) iw + 15) / 16 * 16, cs = ((size_t) 2 * ((iw + 1) / 2) + 15) / 16 * 16;
       h->mid_bytes = ys * ih + 3 * cs * ((ih + 1) / 2) + 1024;
-      VFHIP_CHECK_HIP (hipMalloc (&h->mid, h->mid_bytes));
+      VFHIP_CHECK_HIP (dev_malloc (&h->mid, h->mid_bytes));
       h->mid_frames = 1;
     }
     h->kernel = VfHipConvertScale::K_STAGED; h->kernel_name = "k_cs_staged_420";
@@ -541,11 +545,11 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
   h->hscale_on = (method == VFHIP_SCALE_BILINEAR && h->rw != in->width) ? 1 : 0;
   h->hinc = (h->rw > 1 && in->width > 1) ? (uint32_t) ((((uint64_t) (in->width - 1)) << 16) / (uint64_t) (h->rw - 1)) - 1 : 0;   // a one-pixel line is replicated
   h->vfirst = in->height > h->rh + 2 ? 1 : 0;      // GstVideoScaler pass order (oracle/gst114.c rule 3)
-  VFHIP_CHECK_HIP (hipMalloc (&h->d_vtab, vt.size () * sizeof (int)));
-  VFHIP_CHECK_HIP (hipMemcpy (h->d_vtab, vt.data (), vt.size () * sizeof (int), hipMemcpyHostToDevice));
+  VFHIP_CHECK_HIP (dev_malloc (&h->d_vtab, vt.size () * sizeof (int)));
+  VFHIP_CHECK_HIP (upload_in_stream (h->d_vtab, vt.data (), vt.size () * sizeof (int), h->st.s_compute));
   if (!ht.empty ()) {
-    VFHIP_CHECK_HIP (hipMalloc (&h->d_htab, ht.size () * sizeof (int)));
-    VFHIP_CHECK_HIP (hipMemcpy (h->d_htab, ht.data (), ht.size () * sizeof (int), hipMemcpyHostToDevice));
+    VFHIP_CHECK_HIP (dev_malloc (&h->d_htab, ht.size () * sizeof (int)));
+    VFHIP_CHECK_HIP (upload_in_stream (h->d_htab, ht.data (), ht.size () * sizeof (int), h->st.s_compute));
   }
 
   const bool half = in_yuv && method == VFHIP_SCALE_BILINEAR && !h->add_borders &&
@@ -663,7 +667,7 @@ static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
     if (h->mid_frames < n_frames) {              // intermediate frames of the batch (grown on demand; hipFree waits for the device)
       if (h->mid) (void) hipFree (h->mid);
       h->mid = nullptr; h->mid_frames = 0;
-      VFHIP_CHECK_HIP (hipMalloc (&h->mid, h->mid_bytes * (size_t) n_frames));
+      VFHIP_CHECK_HIP (dev_malloc (&h->mid, h->mid_bytes * (size_t) n_frames));
       h->mid_frames = n_frames;
     }
     mid_pitch = h->mid_bytes;
@@ -811,7 +815,7 @@ static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
       if (h->nt_tmp_bytes < tbytes * (size_t) n_frames) {
         if (h->nt_tmp) (void) hipFree (h->nt_tmp);
         h->nt_tmp = nullptr; h->nt_tmp_bytes = 0;
-        VFHIP_CHECK_HIP (hipMalloc (&h->nt_tmp, tbytes * (size_t) n_frames));
+        VFHIP_CHECK_HIP (dev_malloc (&h->nt_tmp, tbytes * (size_t) n_frames));
         h->nt_tmp_bytes = tbytes * (size_t) n_frames;
       }
       PlaneTapParams a {}, b {};

@@ -570,7 +570,7 @@ static int deint_device_locked (VfHipDeinterlace *h, const VfHipFrame *in0, VfHi
   if (h->hist_bytes < total) {
     for (int k = 0; k < 2; k++) { if (h->hist[k]) (void) hipFree (h->hist[k]); h->hist[k] = nullptr; }
     h->hist_bytes = 0; h->has_prev = false;
-    for (int k = 0; k < 2; k++) VFHIP_CHECK_HIP (hipMalloc (&h->hist[k], total));
+    for (int k = 0; k < 2; k++) VFHIP_CHECK_HIP (dev_malloc (&h->hist[k], total));
     h->hist_bytes = total;
   }
   VfHipFrame next = *in0;

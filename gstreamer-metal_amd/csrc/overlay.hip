@@ -165,8 +165,8 @@ int vfhip_overlay_set_image (VfHipOverlay *h, const uint8_t *rgba, int width, in
   std::lock_guard<std::mutex> lk (h->mu);
   ov_drop_image (h);
   const size_t bytes = (size_t) width * height * 4;
-  VFHIP_CHECK_HIP (hipMalloc (&h->d_img, bytes + 256));
-  hipError_t e = hipMemcpy (h->d_img, rgba, bytes, hipMemcpyHostToDevice);
+  VFHIP_CHECK_HIP (dev_malloc (&h->d_img, bytes + 256));
+  hipError_t e = upload_in_stream (h->d_img, rgba, bytes, h->st.s_compute);
   if (e != hipSuccess) { (void) hipFree (h->d_img); h->d_img = nullptr; return set_error (VFHIP_ERR_HIP, "image upload failed: %s", hipGetErrorString (e)); }
   h->img_w = width; h->img_h = height;
   return VFHIP_OK;

@@ -92,7 +92,7 @@ int Staging::ensure_slot (size_t slot, size_t bytes)
   if (b.devp) (void) hipFree (b.devp);
   b = Buf ();
   VFHIP_CHECK_HIP (hipHostMalloc (&b.host, bytes, hipHostMallocDefault));
-  VFHIP_CHECK_HIP (hipMalloc (&b.devp, bytes));
+  VFHIP_CHECK_HIP (dev_malloc (&b.devp, bytes));
   b.bytes = bytes;
   return VFHIP_OK;
 }
@@ -372,7 +372,7 @@ void *vfhip_device_malloc (int device, size_t bytes)
   Device *d = get_device (device);
   if (!d) return nullptr;
   void *p = nullptr;
-  if (hipSetDevice (d->ordinal) != hipSuccess || hipMalloc (&p, bytes) != hipSuccess) {
+  if (hipSetDevice (d->ordinal) != hipSuccess || dev_malloc (&p, bytes) != hipSuccess) {
     set_error (VFHIP_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
     return nullptr;
   }

@@ -1,6 +1,7 @@
 // csrc/vfhip_internal.h — shared internals of libvfhip (device singleton, errors, staging).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <mutex>
 #include "vfhip_host.h"
 
@@ -12,6 +13,28 @@ namespace vfhip {
     if (_e != hipSuccess)                                                                         \
       return vfhip::set_error (VFHIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString (_e), __FILE__, __LINE__); \
   } while (0)
+
+// every device allocation of the library.  With $VFHIP_DEBUG_POISON set the new memory is filled with 0xA5: a kernel that reads an intermediate or
+// staging byte nothing wrote then fails its parity test on every run instead of only when the allocator hands back dirty memory (fresh
+// allocations are zeroed by the driver, recycled ones are not) — the GPU tests and fuzzers are run once with it (tools/gpu_check.sh).
+template <typename T> static inline hipError_t dev_malloc (T **p, size_t bytes)
+{
+  hipError_t e = hipMalloc (reinterpret_cast<void **> (p), bytes);
+  static const bool poison = getenv ("VFHIP_DEBUG_POISON") != nullptr;
+  if (e == hipSuccess && poison) { e = hipMemset (*p, 0xA5, bytes); if (e == hipSuccess) e = hipDeviceSynchronize (); }      // (hipMemset returns before the fill has run)
+  return e;
+}
+
+// host tables / images that kernels of stream `s` read (tap tables, the filter's LUT, the overlay image): copied IN that stream and waited for, so the
+// copy is ordered — and its result made visible — like any other work of the queue the kernels run in.  (A blocking hipMemcpy is a null-stream
+// operation and the handles' streams are non-blocking; the host-side wait orders it, but a fuzz run that re-created thousands of handles — tables
+// re-allocated at addresses just freed — once saw a table's 16 to 32 bytes as the previous owner had left them, twice in 3000 cases and never
+// again in 21000: this removes the one place where data reached the device outside the kernels' own queue.)
+static inline hipError_t upload_in_stream (void *dst, const void *src, size_t bytes, hipStream_t s)
+{
+  hipError_t e = hipMemcpyAsync (dst, src, bytes, hipMemcpyHostToDevice, s);
+  return e != hipSuccess ? e : hipStreamSynchronize (s);
+}
 
 // One per GPU ordinal, created once (std::call_once) — the HIP analogue of VfMetalDevice +sharedDevice
 // (reference common/vfmetaldevice.m:30-38).

@@ -471,8 +471,8 @@ static int vf_upload_lut (VfHipVideoFilter *h, const float *rgba, int size)
       }
   const size_t bytes = faces.size () * sizeof (float);
   float4 *d = nullptr;
-  VFHIP_CHECK_HIP (hipMalloc (&d, bytes));
-  hipError_t e = hipMemcpy (d, faces.data (), bytes, hipMemcpyHostToDevice);
+  VFHIP_CHECK_HIP (dev_malloc (&d, bytes));
+  hipError_t e = upload_in_stream (d, faces.data (), bytes, h->st.s_compute);
   if (e != hipSuccess) { (void) hipFree (d); return set_error (VFHIP_ERR_HIP, "LUT upload failed: %s", hipGetErrorString (e)); }
   // swap after the device is idle for this handle's streams: a frame in flight may still read the old table
   (void) hipStreamSynchronize (h->st.s_compute);

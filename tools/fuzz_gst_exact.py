@@ -78,6 +78,15 @@ for case in range(N):
     if not np.array_equal(np.asarray(got).reshape(-1), np.asarray(want).reshape(-1)):
         bad += 1
         d = (np.asarray(got).reshape(-1) != np.asarray(want).reshape(-1)).sum()
-        print("MISMATCH", ifmt, (w, h), "->", ofmt, (ow, oh), method, col, site, k, d, "bytes", flush=True)
+        # which side is it?  run both again: a deterministic difference shows again on both, a one-off points at whichever side changed
+        cs2 = vfhip.ConvertScale(0)
+        cs2.configure(ifmt, w, h, ofmt, ow, oh, method=method, colorimetry=col, chroma_site=site, add_borders=bool(borders), border_color=0xC0123456)
+        got2 = cs2.process(raw); cs2.close()
+        want2 = (oracle_lib.convertscale_with_borders(orc, ifmt, w, h, raw, col, site, method, ofmt, ow, oh, 0xC0123456) if borders
+                 else orc.convertscale(ifmt, w, h, raw, col, site, method, ofmt, ow, oh))
+        print("MISMATCH", ifmt, (w, h), "->", ofmt, (ow, oh), method, col, site, k, d, "bytes", "borders" if borders else "",
+              "| library repeats itself:", bool(np.array_equal(np.asarray(got).reshape(-1), np.asarray(got2).reshape(-1))),
+              "| oracle repeats itself:", bool(np.array_equal(np.asarray(want).reshape(-1), np.asarray(want2).reshape(-1))),
+              "| second run equal:", bool(np.array_equal(np.asarray(got2).reshape(-1), np.asarray(want2).reshape(-1))), flush=True)
 print("cases", N, "mismatches", bad, "kernels", kernels)
 sys.exit(1 if bad else 0)
