@@ -59,6 +59,7 @@ struct VfHipConvertScale {
   enum Kernel { K_NONE, K_HALF, K_GENERIC, K_TAPS, K_METAL, K_STAGED, K_NTAP, K_SAME, K_BLTILE } kernel = K_NONE;
   int bl_th = 32;                   // K_BLTILE: tile height (32, or 16 when a 32-row tile's source region does not fit)
   int strip_rows = 4, strip_fill = 2;   // k_cs_taps_strip: rows per lane (1 = k_cs_taps), waves per SIMD a strip launch must give; $VFHIP_TAPS_ROWS / $VFHIP_TAPS_FILL at configure (A/B and test knobs)
+  bool rgb_same = false;            // BGRA / RGBA -> BGRA / RGBA at the same size, no borders: k_cs_rgb_same when the frames meet its alignment contract
   bool taps_adjacent = false;       // bilinear: every row's two vertical taps are the same or adjacent source rows (k_cs_taps_strip's contract)
   Kernel same_fallback = K_NONE;    // K_SAME: what runs instead when a frame misses k_cs_yuv_same's alignment contract
   const char *kernel_name = "none";
@@ -388,7 +389,7 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
   if (in->color_matrix < 0 || in->color_matrix > 2 || out->color_matrix < 0 || out->color_matrix > 2)
     return set_error (VFHIP_ERR_INVALID, "bad colour matrix");
   VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
-  h->configured = false; h->lb = false;
+  h->configured = false; h->lb = false; h->rgb_same = false;
   free_tables (h);
   h->in = *in; h->out = *out; h->method = method; h->add_borders = add_borders ? 1 : 0;
   h->border_color = border_color; h->numerics = numerics;
@@ -422,6 +423,9 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
   const bool staged = numerics == VFHIP_NUMERICS_GST_EXACT && lb_ok &&
                       ((in_420_or_rgb && out_420) || out_packed || (in_packed && out_420)) &&
                       !(out_packed && in->width == 2 && h->rw != 2);
+  // RGB -> RGB at the same size (whatever the method: videoscale passes through): a copy or the R <-> B swap, chosen at launch when the frames are aligned
+  h->rgb_same = numerics == VFHIP_NUMERICS_GST_EXACT && (in->format == VFHIP_FORMAT_BGRA || in->format == VFHIP_FORMAT_RGBA) && out_rgb &&
+                in->width == out->width && in->height == out->height && h->rw == out->width && h->rh == out->height && !(in->width & 3) && getenv ("VFHIP_NO_SAME") == nullptr;
   if (method == VFHIP_SCALE_BICUBIC && !staged) {
     const int iw = in->width, ih = in->height, ow = h->rw, oh = h->rh;      // the destination rectangle (= the frame without borders)
     if (numerics != VFHIP_NUMERICS_GST_EXACT || !(in_420_or_rgb || in_packed) || !out_rgb)
@@ -602,7 +606,7 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
   return VFHIP_OK;
 }
 
-const char *vfhip_convertscale_kernel_name (VfHipConvertScale *h) { return h ? h->kernel_name : "none"; }
+const char *vfhip_convertscale_kernel_name (VfHipConvertScale *h) { return h ? (h->rgb_same ? "k_cs_rgb_same" : h->kernel_name) : "none"; }
 
 int vfhip_convertscale_numerics_in_effect (VfHipConvertScale *h)
 {
@@ -775,6 +779,14 @@ static int staged_launch (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
       p.ou = (uint8_t *) mid.data[1]; p.ous = mid.stride[1];
       p.ov = (uint8_t *) mid.data[2]; p.ovs = mid.stride[2];
       p.w = iw; p.h = ih; p.in_planar = h->in.format == VFHIP_FORMAT_I420; p.out_planar = out_planar;
+      // 16-byte accesses when the frames allow (k_repack_420_vec's contract)
+      const uintptr_t ya = (uintptr_t) p.iy | (uintptr_t) p.iys | (uintptr_t) p.oy | (uintptr_t) p.oys | (uintptr_t) in_pitch | (uintptr_t) mid_pitch;
+      const uintptr_t ica = (uintptr_t) p.iu | (uintptr_t) p.ius | (p.in_planar ? (uintptr_t) p.iv | (uintptr_t) p.ivs : 0);
+      const uintptr_t oca = (uintptr_t) p.ou | (uintptr_t) p.ous | (p.out_planar ? (uintptr_t) p.ov | (uintptr_t) p.ovs : 0);
+      if (!(iw & 15) && !(ih & 1) && !(ya & 15) && !(ica & (p.in_planar ? 7 : 15)) && !(oca & (p.out_planar ? 7 : 15)) && getenv ("VFHIP_PLANE_SCALAR") == nullptr) {
+        dim3 vg ((unsigned) ((iw / 16 + 63) / 64), (unsigned) ((chh + 3) / 4), nz);
+        hipLaunchKernelGGL (k_repack_420_vec, vg, dim3 (64, 4), 0, s, p);
+      } else
       hipLaunchKernelGGL (k_repack_420, grid, dim3 (64, 4), 0, s, p);
     }
     VFHIP_CHECK_HIP (hipGetLastError ());
@@ -895,6 +907,15 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
 {
   if (n_frames <= 0) return VFHIP_OK;
   if (n_frames > 65535) return set_error (VFHIP_ERR_INVALID, "batch of %d frames exceeds 65535", n_frames);
+  if (h->rgb_same && !(((uintptr_t) in->data[0] | (uintptr_t) in->stride[0] | (uintptr_t) in_pitch | (uintptr_t) out->data[0] | (uintptr_t) out->stride[0] | (uintptr_t) out_pitch) & 15)) {
+    CsParams p {};
+    p.in[0] = (const uint8_t *) in->data[0]; p.is[0] = in->stride[0]; p.out = (uint8_t *) out->data[0]; p.os = out->stride[0];
+    p.in_pitch = in_pitch; p.out_pitch = out_pitch; p.in_w = h->in.width; p.in_h = h->in.height;
+    dim3 grid ((unsigned) (((size_t) (p.in_w >> 2) * p.in_h + 255) / 256), (unsigned) n_frames);
+    hipLaunchKernelGGL (k_cs_rgb_same, grid, dim3 (256), 0, s, p, h->in.format != h->out.format ? 1 : 0);
+    VFHIP_CHECK_HIP (hipGetLastError ());
+    return VFHIP_OK;
+  }
   VfHipFrame rect_view;
   if (h->kernel == VfHipConvertScale::K_NTAP && (h->rw != h->out.width || h->rh != h->out.height)) {
     // add-borders: the border colour everywhere outside the rectangle, then the bicubic path writes the rectangle through a view

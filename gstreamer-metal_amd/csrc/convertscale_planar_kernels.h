@@ -166,6 +166,40 @@ __global__ __launch_bounds__ (256) void k_repack_420 (const RepackParams p0)
     }
 }
 
+// the same with 16-byte accesses: a lane moves 16 luma columns of two rows and the eight chroma samples under them (NV12 side: one 16-byte
+// load / store of interleaved pairs; I420 side: 8 bytes per plane), the (de)interleave is two v_perm per dword.  NV12 <-> I420 at the same size is
+// what the element does between a decoder and an encoder that disagree on the layout: 3.8 -> see DESIGN §5.2 per 1080p frame.
+// Contract (host): w % 16 == 0, even h, 16-byte aligned luma and NV12 chroma rows, 8-byte aligned I420 chroma rows.
+__global__ __launch_bounds__ (256) void k_repack_420_vec (const RepackParams p0)
+{
+  typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
+  typedef uint32_t v2u __attribute__ ((ext_vector_type (2)));
+  RepackParams p = p0;
+  p.iy += (size_t) blockIdx.z * p.in_pitch; p.iu += (size_t) blockIdx.z * p.in_pitch; if (p.iv) p.iv += (size_t) blockIdx.z * p.in_pitch;
+  p.oy += (size_t) blockIdx.z * p.out_pitch; p.ou += (size_t) blockIdx.z * p.out_pitch; if (p.ov) p.ov += (size_t) blockIdx.z * p.out_pitch;
+  const int g = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+  if (16 * g >= p.w || 2 * j >= p.h) return;
+  const v4u y0 = *(reinterpret_cast<const v4u *> (p.iy + (size_t) (2 * j) * p.iys) + g), y1 = *(reinterpret_cast<const v4u *> (p.iy + (size_t) (2 * j + 1) * p.iys) + g);
+  v2u u, v;                                      // eight U and eight V samples
+  if (p.in_planar) {
+    u = *(reinterpret_cast<const v2u *> (p.iu + (size_t) j * p.ius) + g); v = *(reinterpret_cast<const v2u *> (p.iv + (size_t) j * p.ivs) + g);
+  } else {
+    const v4u c = *(reinterpret_cast<const v4u *> (p.iu + (size_t) j * p.ius) + g);
+    u.x = __builtin_amdgcn_perm (c.y, c.x, 0x06040200u); u.y = __builtin_amdgcn_perm (c.w, c.z, 0x06040200u);
+    v.x = __builtin_amdgcn_perm (c.y, c.x, 0x07050301u); v.y = __builtin_amdgcn_perm (c.w, c.z, 0x07050301u);
+  }
+  __builtin_nontemporal_store (y0, reinterpret_cast<v4u *> (p.oy + (size_t) (2 * j) * p.oys) + g);
+  __builtin_nontemporal_store (y1, reinterpret_cast<v4u *> (p.oy + (size_t) (2 * j + 1) * p.oys) + g);
+  if (p.out_planar) {
+    __builtin_nontemporal_store (u, reinterpret_cast<v2u *> (p.ou + (size_t) j * p.ous) + g);
+    __builtin_nontemporal_store (v, reinterpret_cast<v2u *> (p.ov + (size_t) j * p.ovs) + g);
+  } else {
+    const v4u c = { __builtin_amdgcn_perm (v.x, u.x, 0x05010400u), __builtin_amdgcn_perm (v.x, u.x, 0x07030602u),
+                    __builtin_amdgcn_perm (v.y, u.y, 0x05010400u), __builtin_amdgcn_perm (v.y, u.y, 0x07030602u) };
+    __builtin_nontemporal_store (c, reinterpret_cast<v4u *> (p.ou + (size_t) j * p.ous) + g);
+  }
+}
+
 // ---- stage 1 for YUV -> YUV with a MATRIX change (NV12 / I420 / UYVY / YUY2 either side) or NV12 <-> I420 with a SITING change ----
 // videoconvert's generic path (oracle/gst114.c gst114_yuv_to_yuv; 50 real-pipeline vectors, tests/golden/convertscale_gst114_remat.npz):
 //   same siting and the same subsampling on both sides: every luma sample is matrixed with its nearest chroma sample, every output

@@ -879,3 +879,43 @@ def test_taps_strip_kernel(vfhip, oracle, ifmt, site, w, h, ow, oh, monkeypatch)
         monkeypatch.delenv("VFHIP_TAPS_ROWS")
         monkeypatch.delenv("VFHIP_TAPS_FILL")
         assert kname1 == kname and np.array_equal(one, want), (ofmt, "one row per lane")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ifmt,ofmt", [("NV12", "I420"), ("I420", "NV12")])
+@pytest.mark.parametrize("w,h,ow,oh", [(64, 36, 64, 36), (1920, 1080, 1920, 1080), (32, 2, 32, 2), (16, 4, 16, 4), (40, 20, 40, 20), (64, 37, 64, 37),
+                                       (64, 36, 48, 20), (1920, 1080, 1280, 720)])
+def test_nv12_i420_repack(vfhip, oracle, ifmt, ofmt, w, h, ow, oh, monkeypatch):
+    """NV12 <-> I420 (the same matrix and siting): the (de)interleave with 16-byte accesses (k_repack_420_vec) where the frame allows, the
+    byte-wise kernel elsewhere (width % 16 != 0, odd height), alone and as stage 1 of a scale — against the oracle and against each other"""
+    rng = np.random.default_rng(w + 3 * oh)
+    raw = rng.integers(0, 256, vfhip.plane_layout(ifmt, w, h)[1], dtype=np.uint8)
+    want = oracle.convertscale(ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", ofmt, ow, oh)
+    got, kname = run(vfhip, ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", ofmt, ow, oh)
+    assert kname == "k_cs_staged_420", kname
+    assert np.array_equal(meaningful(ofmt, ow, oh, got), meaningful(ofmt, ow, oh, want))
+    monkeypatch.setenv("VFHIP_PLANE_SCALAR", "1")
+    scalar, _ = run(vfhip, ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", ofmt, ow, oh)
+    monkeypatch.delenv("VFHIP_PLANE_SCALAR")
+    assert np.array_equal(meaningful(ofmt, ow, oh, scalar), meaningful(ofmt, ow, oh, want))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ifmt,ofmt", [("BGRA", "RGBA"), ("RGBA", "BGRA"), ("BGRA", "BGRA"), ("RGBA", "RGBA")])
+@pytest.mark.parametrize("w,h", [(64, 36), (4, 1), (1920, 1080), (200, 113), (66, 5)])
+@pytest.mark.parametrize("method", ["bilinear", "nearest", "bicubic"])
+def test_rgb_same_size(vfhip, oracle, ifmt, ofmt, w, h, method, monkeypatch):
+    """BGRA / RGBA -> BGRA / RGBA at the same size: a copy or the R <-> B swap (k_cs_rgb_same, 16 bytes per lane) for every method — videoscale
+    passes through — against the oracle and against the kernels it replaces; a width that is not a multiple of 4 keeps those"""
+    rng = np.random.default_rng(w + h)
+    raw = rng.integers(0, 256, vfhip.plane_layout(ifmt, w, h)[1], dtype=np.uint8)
+    want = oracle.convertscale(ifmt, w, h, raw, "bt709", "mpeg2", method, ofmt, w, h)
+    got, kname = run(vfhip, ifmt, w, h, raw, "bt709", "mpeg2", method, ofmt, w, h)
+    assert (kname == "k_cs_rgb_same") == (w % 4 == 0), kname
+    assert np.array_equal(got, want)
+    px = raw.reshape(h, w, 4)
+    assert np.array_equal(got, px if ifmt == ofmt else px[..., [2, 1, 0, 3]])
+    monkeypatch.setenv("VFHIP_NO_SAME", "1")
+    old, kold = run(vfhip, ifmt, w, h, raw, "bt709", "mpeg2", method, ofmt, w, h)
+    monkeypatch.delenv("VFHIP_NO_SAME")
+    assert kold != "k_cs_rgb_same" and np.array_equal(old, want)
