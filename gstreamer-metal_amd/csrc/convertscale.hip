@@ -1043,7 +1043,20 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
     }
     else if (taps && p.in_fmt == VFHIP_FORMAT_I420) hipLaunchKernelGGL (k_cs_taps<true>, grid, dim3 (64, 4), 0, s, p);
     else if (taps) hipLaunchKernelGGL (k_cs_taps<false>, grid, dim3 (64, 4), 0, s, p);
-    else hipLaunchKernelGGL (k_cs_generic, grid, dim3 (64, 4), 0, s, p);
+    else {
+      // RGB -> RGB bilinear down-scales: k_cs_rgb_taps_strip under the same launch-size rule
+      const bool rgb_in = p.in_fmt == VFHIP_FORMAT_BGRA || p.in_fmt == VFHIP_FORMAT_RGBA;
+      const size_t strips = ((size_t) p.out_h + 3) / 4;
+      if (rgb_in && !p.nearest && h->method == VFHIP_SCALE_BILINEAR && h->taps_adjacent && h->strip_rows > 1 && p.in_w >= 2 &&
+          p.rx == 0 && p.ry == 0 && p.rw == p.out_w && p.rh == p.out_h && !(((uintptr_t) p.in[0] | (uintptr_t) p.is[0] | (uintptr_t) in_pitch) & 3) &&
+          (size_t) grid.x * strips * n_frames >= (size_t) h->strip_fill * 4 * h->dev->n_cu) {
+        dim3 sg (grid.x, (unsigned) ((strips + 3) / 4), (unsigned) n_frames);
+        const int swap = (p.in_fmt == VFHIP_FORMAT_RGBA) != (p.out_rgba != 0) ? 1 : 0;
+        if (p.vfirst) hipLaunchKernelGGL ((k_cs_rgb_taps_strip<true, 4>), sg, dim3 (64, 4), 0, s, p, swap);
+        else hipLaunchKernelGGL ((k_cs_rgb_taps_strip<false, 4>), sg, dim3 (64, 4), 0, s, p, swap);
+      }
+      else hipLaunchKernelGGL (k_cs_generic, grid, dim3 (64, 4), 0, s, p);
+    }
   }
   VFHIP_CHECK_HIP (hipGetLastError ());
   return VFHIP_OK;

@@ -388,6 +388,59 @@ __device__ __forceinline__ uint32_t bl_htap (uint32_t a, uint32_t b, uint32_t fw
   return ((as_u32 (tl) >> 8) & 0x00ff00ffu) | (as_u32 (th) & 0xff00ff00u);
 }
 
+// ---- k_cs_rgb_taps_strip<VFIRST, ROWS>: BGRA / RGBA -> BGRA / RGBA, 2-tap bilinear with minification on an axis (a capture or a render scaled down) ----
+// k_cs_generic gathered four dwords per output pixel and ran the two passes channel by channel with its format switches: 6.2 us for 1080p -> 720p.
+// Like k_cs_taps_strip: the two taps of a row are adjacent pixels — ONE 8-byte window per source row (half the gathers) —, a lane walks ROWS
+// output rows of its column with the column-only work done once, the rows' taps as scalar loads up front and the next row's windows in flight;
+// both passes on whole pixels as two u16 pairs (bl_vtap / bl_htap: the tile kernel's arithmetic, k_cs_generic's bit for bit), the R <-> B swap
+// of a format change applied to the finished pixel (the passes treat the channels alike).
+// Contract (host): bilinear, no borders, in_w >= 2, adjacent vertical taps, 4-byte aligned rows.
+template <bool VFIRST, int ROWS>
+__global__ __launch_bounds__ (256) void k_cs_rgb_taps_strip (const CsParams p, int swap)
+{
+  typedef uint2 __attribute__ ((aligned (4))) uint2_a4;
+  const int x = blockIdx.x * 64 + threadIdx.x;
+  const int strip = __builtin_amdgcn_readfirstlane ((int) (blockIdx.y * 4 + threadIdx.y));
+  const int y0 = strip * ROWS, yend = min (y0 + ROWS, p.out_h);
+  if (x >= p.out_w || y0 >= p.out_h) return;
+  const uint8_t *ip = p.in[0] + (size_t) blockIdx.z * p.in_pitch;
+  uint8_t *op = p.out + (size_t) blockIdx.z * p.out_pitch + 4 * (size_t) x;
+  const int4 *vt = reinterpret_cast<const int4 *> (p.vtab);
+  int xa = x, xb = x, f = 0;
+  if (p.hscale_on) {
+    const uint32_t tt = (uint32_t) x * p.hinc;
+    xa = min ((int) (tt >> 16), p.in_w - 1); f = (int) ((tt >> 8) & 0xff); xb = min (xa + 1, p.in_w - 1);
+  }
+  const int base = min (xa, p.in_w - 2);                            // the 8-byte window [base, base + 1] holds both taps
+  const bool a_hi = xa != base, b_hi = xb != base;
+  const uint32_t fw = (uint32_t) f | ((uint32_t) f << 16), fm = 0x01000100u - fw;
+  auto load = [&] (int i0, int i1, uint2 &a, uint2 &b) {
+    a = *reinterpret_cast<const uint2_a4 *> (ip + ((uint32_t) i0 * (uint32_t) p.is[0] + 4u * (uint32_t) base));
+    b = *reinterpret_cast<const uint2_a4 *> (ip + ((uint32_t) i1 * (uint32_t) p.is[0] + 4u * (uint32_t) base));
+  };
+  auto compute = [&] (uint2 r0, uint2 r1, int w, int y) {
+    const uint32_t a0 = a_hi ? r0.y : r0.x, b0 = b_hi ? r0.y : r0.x, a1 = a_hi ? r1.y : r1.x, b1 = b_hi ? r1.y : r1.x;
+    const uint32_t ww = (uint32_t) w | ((uint32_t) w << 16), wm = 0x01000100u - ww;
+    uint32_t q;
+    if (VFIRST) q = bl_htap (bl_vtap (a0, a1, ww, wm), bl_vtap (b0, b1, ww, wm), fw, fm);
+    else q = bl_vtap (bl_htap (a0, b0, fw, fm), bl_htap (a1, b1, fw, fm), ww, wm);
+    if (swap) q = perm_b32 (0u, q, 0x03000102u);
+    __builtin_nontemporal_store (q, reinterpret_cast<uint32_t *> (op + (uint32_t) y * (uint32_t) p.os));
+  };
+  int4 tp[ROWS + 1];                                                  // scalar loads, all before the first store (see k_cs_taps_strip)
+#pragma unroll
+  for (int r = 0; r <= ROWS; r++) tp[r] = vt[min (y0 + r, p.out_h - 1)];
+  uint2 A[2], B[2];
+  load (tp[0].x, tp[0].y, A[0], B[0]);
+#pragma unroll
+  for (int r = 0; r < ROWS; r++) {
+    if (y0 + r >= yend) break;
+    load (tp[r + 1].x, tp[r + 1].y, A[(r + 1) & 1], B[(r + 1) & 1]);
+    __builtin_amdgcn_sched_barrier (0);
+    compute (A[r & 1], B[r & 1], tp[r].z, y0 + r);
+  }
+}
+
 template <int THREADS, int TH>
 __global__ __launch_bounds__ (THREADS) void k_cs_bilinear_tile (const CsParams p, int fast)
 {

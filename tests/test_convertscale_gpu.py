@@ -919,3 +919,25 @@ def test_rgb_same_size(vfhip, oracle, ifmt, ofmt, w, h, method, monkeypatch):
     old, kold = run(vfhip, ifmt, w, h, raw, "bt709", "mpeg2", method, ofmt, w, h)
     monkeypatch.delenv("VFHIP_NO_SAME")
     assert kold != "k_cs_rgb_same" and np.array_equal(old, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ifmt,ofmt", [("BGRA", "BGRA"), ("RGBA", "BGRA"), ("BGRA", "RGBA")])
+@pytest.mark.parametrize("w,h,ow,oh", [(192, 108, 128, 72), (200, 113, 67, 51), (1920, 1080, 1280, 720), (130, 70, 61, 69), (130, 70, 129, 31), (64, 36, 21, 9), (96, 54, 95, 53),
+                                       (320, 180, 100, 179), (258, 258, 65, 65), (2, 2, 1, 1), (100, 64, 99, 200), (100, 64, 100, 30), (100, 64, 40, 64), (1000, 30, 64, 7), (3, 9, 2, 4)])
+def test_rgb_taps_strip_kernel(vfhip, oracle, ifmt, ofmt, w, h, ow, oh, monkeypatch):
+    """k_cs_rgb_taps_strip (RGB -> RGB bilinear with minification on an axis: one 8-byte window per source row, four output rows per lane) forced on
+    whatever the launch size — partial strips and waves, the clamped last column, both pass orders, one axis only, the R <-> B swap — against
+    the oracle and against k_cs_generic"""
+    rng = np.random.default_rng(w * 17 + oh)
+    raw = rng.integers(0, 256, vfhip.plane_layout(ifmt, w, h)[1], dtype=np.uint8)
+    want = oracle.convertscale(ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", ofmt, ow, oh)
+    monkeypatch.setenv("VFHIP_TAPS_FILL", "0")
+    got, kname = run(vfhip, ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", ofmt, ow, oh)
+    assert kname == "k_cs_generic", kname                      # (the name of the cell; strips are a launch-time choice)
+    assert np.array_equal(got, want), "strips"
+    monkeypatch.setenv("VFHIP_TAPS_ROWS", "1")
+    one, _ = run(vfhip, ifmt, w, h, raw, "bt709", "mpeg2", "bilinear", ofmt, ow, oh)
+    monkeypatch.delenv("VFHIP_TAPS_ROWS")
+    monkeypatch.delenv("VFHIP_TAPS_FILL")
+    assert np.array_equal(one, want), "one pixel per lane"
