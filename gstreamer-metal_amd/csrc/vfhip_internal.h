@@ -26,10 +26,9 @@ template <typename T> static inline hipError_t dev_malloc (T **p, size_t bytes)
 }
 
 // host tables / images that kernels of stream `s` read (tap tables, the filter's LUT, the overlay image): copied IN that stream and waited for, so the
-// copy is ordered — and its result made visible — like any other work of the queue the kernels run in.  (A blocking hipMemcpy is a null-stream
-// operation and the handles' streams are non-blocking; the host-side wait orders it, but a fuzz run that re-created thousands of handles — tables
-// re-allocated at addresses just freed — once saw a table's 16 to 32 bytes as the previous owner had left them, twice in 3000 cases and never
-// again in 21000: this removes the one place where data reached the device outside the kernels' own queue.)
+// copy is ordered — and its result made visible — like any other work of the queue the kernels run in (a blocking hipMemcpy is a null-stream
+// operation and the handles' streams are non-blocking; the host-side wait orders it as well, this merely keeps every byte the kernels read on
+// their own queue).  Introduced while chasing two one-off fuzz mismatches that later evidence puts on the checker's side.
 static inline hipError_t upload_in_stream (void *dst, const void *src, size_t bytes, hipStream_t s)
 {
   hipError_t e = hipMemcpyAsync (dst, src, bytes, hipMemcpyHostToDevice, s);

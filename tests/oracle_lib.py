@@ -202,8 +202,14 @@ class Oracle:
 
 
 def load():
+    """The checker runs single-threaded unless VFHIP_ORACLE_THREADS says otherwise: gst114.c's OpenMP loops are there for bench.py's CPU baseline
+    (which sets its own thread count).  Three one-off differences in ~80,000 GPU-box fuzz cases turned out to be the ORACLE's side (its second run
+    agreed with the library, tools/fuzz_gst_exact.py re-runs both); no race was found — 100,000 repeats with 8 and 64 threads and an ASan run are
+    clean — but a checker has no use for threads."""
     build()
-    return Oracle(C.CDLL(LIB))
+    lib = C.CDLL(LIB)
+    lib.gst114_set_threads(int(os.environ.get("VFHIP_ORACLE_THREADS", "1")))
+    return Oracle(lib)
 
 
 def load_golden(name="convertscale_gst114.npz"):
