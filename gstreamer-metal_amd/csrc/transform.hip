@@ -39,30 +39,6 @@ __global__ __launch_bounds__ (256) void k_transform (const TransformKParams pp)
   metal::store_block (p.out, bx, by, q);
 }
 
-// the same per-pixel operations, 4 x 2 pixels per lane: the output leaves as 16-byte RGB rows / dword luma and chroma stores (metal::store_quad)
-// instead of 8- and 2-byte ones.  Output contract as for the filter's quad kernel (metal::quad_frame_ok); any input.
-__global__ __launch_bounds__ (256) void k_transform_quad (const TransformKParams pp)
-{
-  TransformKParams p = pp;
-  p.in = metal::img_at (pp.in, blockIdx.z * pp.in_pitch); p.out = metal::out_at (pp.out, blockIdx.z * pp.out_pitch);
-  const int xq = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
-  if (4 * xq >= p.out.w || 2 * by >= p.out.h) return;
-  uint32_t q[2][4];
-#pragma unroll
-  for (int dy = 0; dy < 2; dy++)
-#pragma unroll
-    for (int dx = 0; dx < 4; dx++) {
-      const int x = 4 * xq + dx, y = 2 * by + dy;
-      float tx = ((float) x + 0.5f) / (float) p.out.w, ty = ((float) y + 0.5f) / (float) p.out.h;
-      tx -= 0.5f; ty -= 0.5f;
-      const float ux = p.m0 * tx + p.m2 * ty, uy = p.m1 * tx + p.m3 * ty;
-      tx = ux + (0.5f + p.offx); ty = uy + (0.5f + p.offy);
-      if (tx < 0.0f || tx > 1.0f || ty < 0.0f || ty > 1.0f) q[dy][dx] = 0xff000000u;
-      else q[dy][dx] = metal::quant_rgba8 (metal::sample_rgba (p.in, tx, ty, true));
-    }
-  metal::store_quad (p.out, xq, by, q);
-}
-
 }  // namespace vfhip
 
 struct VfHipTransform {
@@ -92,14 +68,11 @@ static int tr_launch (VfHipTransform *h, const VfHipFrame *in, VfHipFrame *out, 
   const float *t = kTransformMat[prm->method & 7];
   p.m0 = t[0] * sx; p.m1 = t[1] * sx; p.m2 = t[2] * sy; p.m3 = t[3] * sy;
   p.offx = t[0] * ox + t[2] * oy + 0.0f; p.offy = t[1] * ox + t[3] * oy + 0.0f;
-  if (getenv ("VFHIP_TR_BLOCKS") == nullptr && metal::quad_frame_ok (out, out_pitch, true)) {      // (knob: A/B and tests)
-    dim3 grid ((unsigned) ((h->out.width / 4 + 63) / 64), (unsigned) ((h->out.height / 2 + 3) / 4), (unsigned) n_frames);
-    hipLaunchKernelGGL (k_transform_quad, grid, dim3 (64, 4), 0, s, p);
-  } else {
-    const int bw = (h->out.width + 1) / 2, bh = (h->out.height + 1) / 2;
-    dim3 grid ((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4), (unsigned) n_frames);
-    hipLaunchKernelGGL (k_transform, grid, dim3 (64, 4), 0, s, p);
-  }
+  // (4 x 2 pixels per lane with metal::store_quad's wide stores was tried here as in the filter and the overlay: byte-identical and SLOWER — 8.7 vs
+  // 6.7 us per BGRA 1080p frame, 8.1 vs 7.5 NV12: the four-tap sampler's gathers dominate, and lanes four pixels apart spread them further)
+  const int bw = (h->out.width + 1) / 2, bh = (h->out.height + 1) / 2;
+  dim3 grid ((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4), (unsigned) n_frames);
+  hipLaunchKernelGGL (k_transform, grid, dim3 (64, 4), 0, s, p);
   VFHIP_CHECK_HIP (hipGetLastError ());
   return VFHIP_OK;
 }

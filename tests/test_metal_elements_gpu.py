@@ -839,20 +839,3 @@ def test_overlay_quad_kernel(vfhip, metalref, ifmt, ofmt, w, h, monkeypatch):
         if (w, h) != (1920, 1080):
             close(quad, metalref.overlay(ifmt, w, h, raw, ofmt, img if kw else None, m709=True, **kw), f"overlay {ifmt}->{ofmt} {kw}", max_off_by_one=0.03)
     ov.close()
-
-
-@pytest.mark.parametrize("method", ["none", "clockwise", "rotate-180", "horizontal-flip", "upper-right-diagonal"])
-@pytest.mark.parametrize("fmt", ["BGRA", "NV12", "I420", "RGBA"])
-def test_transform_quad_kernel(vfhip, fmt, method, monkeypatch):
-    """k_transform_quad (4 x 2 pixels per lane, wide stores) writes the bytes k_transform's 2 x 2 blocks write — equal — with crops, on the smallest
-    frame it takes and at 1080p"""
-    for (w, h, crop) in [(64, 48, (0, 0, 0, 0)), (64, 36, (3, 5, 7, 2)), (8, 2, (0, 0, 0, 0)), (1920, 1080, (0, 8, 0, 0))]:
-        raw = smooth(fmt, w, h, 52) if w > 64 else rnd(fmt, w, h, 52)
-        t = vfhip.Transform(0)
-        t.configure(fmt, w, h, colorimetry="bt709")
-        quad = t.process(raw, method=method, crop=crop)
-        monkeypatch.setenv("VFHIP_TR_BLOCKS", "1")
-        blocks = t.process(raw, method=method, crop=crop)
-        monkeypatch.delenv("VFHIP_TR_BLOCKS")
-        assert np.array_equal(quad, blocks), (w, h, crop, int(np.abs(quad.astype(int) - blocks.astype(int)).max()))
-        t.close()
