@@ -839,3 +839,21 @@ def test_overlay_quad_kernel(vfhip, metalref, ifmt, ofmt, w, h, monkeypatch):
         if (w, h) != (1920, 1080):
             close(quad, metalref.overlay(ifmt, w, h, raw, ofmt, img if kw else None, m709=True, **kw), f"overlay {ifmt}->{ofmt} {kw}", max_off_by_one=0.03)
     ov.close()
+
+
+@pytest.mark.parametrize("method", ["none", "clockwise", "rotate-180", "counterclockwise", "horizontal-flip", "vertical-flip", "upper-left-diagonal", "upper-right-diagonal"])
+@pytest.mark.parametrize("ifmt,ofmt", [("BGRA", "BGRA"), ("RGBA", "BGRA")])
+def test_transform_permutation_kernel(vfhip, metalref, method, ifmt, ofmt, monkeypatch):
+    """RGB frames, no crop: k_transform_perm (the frame as a permutation of the input's pixels, chosen only when the host has proved that every tap of
+    the sampler rounds back to one texel) writes the bytes the four-tap kernel writes — equal — for all eight methods, square and not, up to 2160p
+    wide rows; with a crop, or a width that is not a multiple of 4, the four-tap kernel runs (same result either way by construction of the test)"""
+    for (w, h, crop) in [(64, 48, (0, 0, 0, 0)), (48, 48, (0, 0, 0, 0)), (1920, 1080, (0, 0, 0, 0)), (3840, 16, (0, 0, 0, 0)), (64, 36, (3, 5, 7, 2)), (62, 36, (0, 0, 0, 0))]:
+        raw = rnd(ifmt, w, h, 53)
+        t = vfhip.Transform(0)
+        t.configure(ifmt, w, h, ofmt)          # (the wrapper keeps the size: an axis-swapping method on a non-square frame scales — the four-tap kernel)
+        perm = t.process(raw, method=method, crop=crop)
+        monkeypatch.setenv("VFHIP_TR_GENERAL", "1")
+        general = t.process(raw, method=method, crop=crop)
+        monkeypatch.delenv("VFHIP_TR_GENERAL")
+        assert np.array_equal(perm, general), (w, h, crop, int(np.abs(perm.astype(int) - general.astype(int)).max()))
+        t.close()
