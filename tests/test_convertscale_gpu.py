@@ -941,3 +941,32 @@ def test_rgb_taps_strip_kernel(vfhip, oracle, ifmt, ofmt, w, h, ow, oh, monkeypa
     monkeypatch.delenv("VFHIP_TAPS_ROWS")
     monkeypatch.delenv("VFHIP_TAPS_FILL")
     assert np.array_equal(one, want), "one pixel per lane"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ifmt,ofmt,w,h,ow,oh", [("NV12", "BGRA", 640, 360, 214, 160), ("I420", "RGBA", 640, 360, 426, 240), ("BGRA", "RGBA", 640, 360, 426, 240),
+                                                  ("NV12", "I420", 640, 360, 640, 360), ("I420", "NV12", 640, 360, 640, 360), ("BGRA", "RGBA", 640, 360, 640, 360)])
+def test_round2_late_kernels_on_the_batched_device_path(vfhip, oracle, ifmt, ofmt, w, h, ow, oh):
+    """the strip kernels (NV12 / I420 / RGB down-scales), the 16-byte NV12 <-> I420 repack and the RGB same-size kernel on a batch of frames at a
+    pitch, frame by frame against the oracle — large enough that the strips are the launch's own choice"""
+    import torch
+    n = 5
+    rng = np.random.default_rng(w + ow)
+    isz, osz = vfhip.plane_layout(ifmt, w, h)[1], vfhip.plane_layout(ofmt, ow, oh)[1]
+    frames = [rng.integers(0, 256, isz, dtype=np.uint8) for _ in range(n)]
+    want = [np.asarray(oracle.convertscale(ifmt, w, h, f, "bt709", "mpeg2", "bilinear", ofmt, ow, oh)).reshape(-1) for f in frames]
+    cs = vfhip.ConvertScale(0)
+    cs.configure(ifmt, w, h, ofmt, ow, oh, colorimetry="bt709", chroma_site="mpeg2")
+    ip, op = (isz + 255) // 256 * 256, (osz + 255) // 256 * 256
+    ring = np.zeros((n, ip), np.uint8)
+    for k, f in enumerate(frames):
+        ring[k, :isz] = f
+    din, dout = torch.from_numpy(ring).cuda(), torch.zeros((n, op), dtype=torch.uint8, device="cuda")
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    cs.process_device(din.data_ptr(), dout.data_ptr(), stream=s.cuda_stream, n_frames=n, in_pitch=ip, out_pitch=op)
+    s.synchronize()
+    out = dout.cpu().numpy()
+    for k in range(n):
+        assert np.array_equal(meaningful(ofmt, ow, oh, out[k, :osz]), meaningful(ofmt, ow, oh, want[k])), k
+    cs.close()
