@@ -29,6 +29,7 @@ struct VfParams {
   VfHipVideoFilterParams u;
   const float4 *lut;
   int lut_size;
+  int quad_in;                     // k_vf_sharp: a 4:2:0 input that meets metal::fetch420_quad's contract (the region fill takes 4 x 2 pixels at a time)
   size_t in_pitch, out_pitch;      // batch: frame blockIdx.z at base + z * pitch, frame_index + z
 };
 
@@ -311,6 +312,33 @@ __global__ __launch_bounds__ (VF_THREADS, 2) void k_vf_sharp (const VfParams pp)
   const int x0 = blockIdx.x * VF_TW, y0 = blockIdx.y * VF_TH;
   const int tid = threadIdx.x;
   const int w = p.out.w, h = p.out.h;
+  if (p.quad_in) {
+    // 4:2:0 input: the region (its corner sits on the 4 x 2 grid) in quads — the chroma neighbourhood of eight pixels as three window loads instead
+    // of 32 taps; quads off the frame's edge (the halo of an edge tile) are clamped duplicates and go pixel by pixel
+    const float inv_w = 1.0f / (float) p.out.w, inv_h = 1.0f / (float) p.out.h;
+    for (int i = tid; i < (VF_RW / 4) * (VF_RH / 2); i += VF_THREADS) {
+      const int qx = i % (VF_RW / 4), qy = i / (VF_RW / 4);
+      const int gx = x0 - VF_HALO + 4 * qx, gy = y0 - VF_HALO + 2 * qy;
+      uint32_t *d = rt + (2 * qy) * VF_RS + 4 * qx;
+      if (gx >= 0 && gx + 3 < w && gy >= 0 && gy + 1 < h) {
+        F4 c[2][4];
+        metal::fetch420_quad (p.in, gx >> 2, gy >> 1, c);
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++) {
+          const float tv = ((float) (gy + dy) + 0.5f) * inv_h;
+#pragma unroll
+          for (int dx = 0; dx < 4; dx++) {
+            F4 v = color_adjust (c[dy][dx], p.u, ((float) (gx + dx) + 0.5f) * inv_w, tv, p.out.w, p.out.h);
+            if (p.lut) lut_sample (p.lut, p.lut_size, v);
+            d[dy * VF_RS + dx] = metal::quant_rgba8 (v);
+          }
+        }
+      } else {
+#pragma unroll 1
+        for (int k = 0; k < 8; k++) d[(k >> 2) * VF_RS + (k & 3)] = vf_pass1 (p, gx + (k & 3), gy + (k >> 2));
+      }
+    }
+  } else
   for (int i = tid; i < VF_RW * VF_RH; i += VF_THREADS) {
     const int rx = i % VF_RW, ry = i / VF_RW;
     rt[ry * VF_RS + rx] = vf_pass1 (p, x0 - VF_HALO + rx, y0 - VF_HALO + ry);
@@ -415,6 +443,7 @@ static int vf_launch (VfHipVideoFilter *h, const VfHipFrame *in, VfHipFrame *out
   p.in_pitch = in_pitch; p.out_pitch = out_pitch;
   p.in = metal::make_img (in); p.out = metal::make_out (out);
   p.u = *prm; p.lut = h->d_lut; p.lut_size = h->lut_size;
+  p.quad_in = (in->info.format == VFHIP_FORMAT_NV12 || in->info.format == VFHIP_FORMAT_I420) && metal::quad_frame_ok (in, in_pitch, false) && getenv ("VFHIP_VF_BLOCKS") == nullptr;
   const int w = h->out.width, hh = h->out.height;
   if (prm->sharpness < -0.001f || prm->sharpness > 0.001f) {
     dim3 grid ((unsigned) ((w + VF_TW - 1) / VF_TW), (unsigned) ((hh + VF_TH - 1) / VF_TH), (unsigned) n_frames);

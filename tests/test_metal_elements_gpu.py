@@ -802,10 +802,13 @@ def test_videofilter_420_quad_kernel(vfhip, metalref, ifmt, ofmt, w, h, monkeypa
     g = np.linspace(0, 1, n, dtype=np.float32)
     lut = np.ones((n, n, n, 4), np.float32)
     lut[..., 0] = g[None, None, :] * 0.8; lut[..., 1] = g[None, :, None] ** 1.3; lut[..., 2] = g[:, None, None]
-    for name, kw, use_lut in (("identity", {}, False), ("colour", dict(brightness=0.1, contrast=1.2, saturation=1.3, hue=0.4, gamma=1.6, sepia=0.3, vignette=0.4), True)):
+    for name, kw, use_lut in (("identity", {}, False), ("colour", dict(brightness=0.1, contrast=1.2, saturation=1.3, hue=0.4, gamma=1.6, sepia=0.3, vignette=0.4), True),
+                              ("sharpen", dict(sharpness=0.6, contrast=1.1), True), ("blur", dict(sharpness=-0.5), False)):   # k_vf_sharp: its region fill in quads
         prm = vfhip.filter_params(**kw)
         if use_lut:
             vf.set_lut(lut)
+        else:
+            vf.clear_lut()
         quad = vf.process(raw, prm)
         monkeypatch.setenv("VFHIP_VF_BLOCKS", "1")
         blocks = vf.process(raw, prm)
