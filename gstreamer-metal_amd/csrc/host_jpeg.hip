@@ -247,12 +247,13 @@ static void upsample (const Component &c, int hmax, int vmax, int W, int H, std:
   const size_t cs = (size_t) c.bw * 8;
   const int cw = c.w, ch = c.hh;
   const uint8_t *src = c.plane.data ();
-  const int fh = hmax / c.h, fv = vmax / c.v;
-  if (fh == 1 && fv == 1) {
+  const int fv = vmax / c.v;
+  // (the frame header refuses fractional ratios; the 1:1 copy reads W x H samples and so must never be taken for a component plane that is smaller)
+  if (c.h == hmax && c.v == vmax) {
     for (int y = 0; y < H; y++) memcpy (&full[(size_t) y * W], src + cs * (size_t) y, (size_t) W);
     return;
   }
-  if (fh == 2 && (fv == 1 || fv == 2) && hmax % c.h == 0 && vmax % c.v == 0 && cw > 2) {       // (libjpeg filters only components wider than two samples)
+  if (hmax == 2 * c.h && (vmax == c.v || vmax == 2 * c.v) && cw > 2) {       // (libjpeg filters only components wider than two samples)
     // triangle filter: each output sample is 3/4 of the nearer and 1/4 of the farther input sample (h2v2: in both directions, 16ths)
     std::vector<int> sum ((size_t) cw);
     for (int y = 0; y < H; y++) {
@@ -303,7 +304,8 @@ static int decode_jpeg_impl (const char *path, std::vector<uint8_t> &rgba, int *
   bool have_qt[4] = { false, false, false, false };
   HuffTable hdc[4], hac[4];
   std::vector<Component> comp;
-  int W = 0, H = 0, hmax = 1, vmax = 1, restart = 0, adobe_transform = -1;
+  int W = 0, H = 0, hmax = 1, vmax = 1, restart = 0, adobe_transform = -1, n_scans = 0;
+  const int kMaxScans = 128;
   bool have_sof = false, scans = false, eoi = false, progressive = false;
   size_t pos = 2;
   const uint8_t *data = file.data ();
@@ -363,6 +365,10 @@ static int decode_jpeg_impl (const char *path, std::vector<uint8_t> &rgba, int *
         if (c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4 || c.tq > 3) return set_error (VFHIP_ERR_INVALID, "%s: bad component in the frame header", path);
         hmax = c.h > hmax ? c.h : hmax; vmax = c.v > vmax ? c.v : vmax;
       }
+      // fractional ratios (3:2, 4:3): libjpeg has no up-sampler for them either (JERR_FRACT_SAMPLE_NOTIMPL)
+      for (const Component &c : comp)
+        if (hmax % c.h || vmax % c.v)
+          return set_error (VFHIP_ERR_UNSUPPORTED, "%s: fractional sampling ratio %d:%d x %d:%d is not supported", path, hmax, c.h, vmax, c.v);
       const int mcux = (W + 8 * hmax - 1) / (8 * hmax), mcuy = (H + 8 * vmax - 1) / (8 * vmax);
       for (Component &c : comp) {
         c.bw = mcux * c.h; c.bh = mcuy * c.v;
@@ -381,6 +387,11 @@ static int decode_jpeg_impl (const char *path, std::vector<uint8_t> &rgba, int *
       if (sl >= 12 && !memcmp (s, "Adobe", 5)) adobe_transform = s[11];
     } else if (m == 0xda) {                                       // SOS + entropy-coded data
       if (!have_sof) return set_error (VFHIP_ERR_INVALID, "%s: scan before the frame header", path);
+      // every scan walks all blocks of its components whatever its size in the file: bound the scans (libjpeg-turbo's scan limit, same reason) and
+      // refuse one that carries no entropy-coded byte at all
+      if (++n_scans > kMaxScans) return set_error (VFHIP_ERR_UNSUPPORTED, "%s: more than %d scans", path, kMaxScans);
+      if (pos >= size || (data[pos] == 0xff && (pos + 1 >= size || data[pos + 1] != 0x00)))
+        return set_error (VFHIP_ERR_INVALID, "%s: scan without entropy-coded data", path);
       if (sl < 1) return set_error (VFHIP_ERR_INVALID, "%s: bad scan header", path);
       const int ns = s[0];
       if (ns < 1 || ns > (int) comp.size () || sl < (size_t) 1 + 2 * (size_t) ns + 3) return set_error (VFHIP_ERR_INVALID, "%s: bad scan header", path);

@@ -215,28 +215,37 @@ int vfhip_transform_configure (VfHipTransform *h, const VfHipVideoInfo *in, cons
     return set_error (VFHIP_ERR_INVALID, "bad frame size");
   if (in->format < VFHIP_FORMAT_BGRA || in->format > VFHIP_FORMAT_I420 || out->format < VFHIP_FORMAT_BGRA || out->format > VFHIP_FORMAT_I420)
     return set_error (VFHIP_ERR_UNSUPPORTED, "transform: format not supported");
-  h->in = *in; h->out = *out; h->configured = true;
-  // RGB frames whose rows take four pixels per lane: the permutation tables of the methods for which the proof holds (tr_build_perm)
+  // a failed configure leaves the handle unconfigured: nothing is published before the last step that can fail has succeeded
+  h->configured = false;
   VFHIP_CHECK_HIP (hipSetDevice (h->dev->ordinal));
   if (h->d_perm) { (void) hipStreamSynchronize (h->st.s_compute); (void) hipFree (h->d_perm); h->d_perm = nullptr; }
   for (bool &ok : h->perm_ok) ok = false;
+  // RGB frames whose rows take four pixels per lane: the permutation tables of the methods for which the proof holds (tr_build_perm)
   const bool rgb = (in->format == VFHIP_FORMAT_BGRA || in->format == VFHIP_FORMAT_RGBA) && (out->format == VFHIP_FORMAT_BGRA || out->format == VFHIP_FORMAT_RGBA);
   if (rgb && !(out->width & 3)) {
     const size_t per = (size_t) out->width + (((size_t) out->height + 3) & ~(size_t) 3);          // (both parts multiples of 4 ints: every method's a[] starts 16-byte aligned)
     std::vector<int> all (8 * per, 0), a, b;
-    bool any = false;
+    bool ok[8] = { false, false, false, false, false, false, false, false }, any = false;
     for (int m = 0; m < 8; m++) {
       // (a method that swaps the axes maps a W x H frame onto H x W; the reference scales whatever the sizes are — only the provable cases come here)
       if (!tr_build_perm (m, in->width, in->height, out->width, out->height, a, b)) continue;
       std::copy (a.begin (), a.end (), all.begin () + (size_t) m * per);
       std::copy (b.begin (), b.end (), all.begin () + (size_t) m * per + (size_t) out->width);
-      h->perm_ok[m] = any = true;
+      ok[m] = any = true;
     }
     if (any) {
-      VFHIP_CHECK_HIP (dev_malloc (&h->d_perm, all.size () * sizeof (int)));
-      VFHIP_CHECK_HIP (upload_in_stream (h->d_perm, all.data (), all.size () * sizeof (int), h->st.s_compute));
+      int *d_perm = nullptr;
+      VFHIP_CHECK_HIP (dev_malloc (&d_perm, all.size () * sizeof (int)));
+      const hipError_t e = upload_in_stream (d_perm, all.data (), all.size () * sizeof (int), h->st.s_compute);
+      if (e != hipSuccess) {                       // a table that may hold anything must never reach k_transform_perm (its entries are source indices)
+        (void) hipFree (d_perm);
+        return set_error (VFHIP_ERR_HIP, "transform: uploading the permutation tables failed: %s", hipGetErrorString (e));
+      }
+      h->d_perm = d_perm;
+      for (int m = 0; m < 8; m++) h->perm_ok[m] = ok[m];
     }
   }
+  h->in = *in; h->out = *out; h->configured = true;
   return VFHIP_OK;
 }
 

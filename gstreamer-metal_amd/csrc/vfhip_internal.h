@@ -21,7 +21,11 @@ template <typename T> static inline hipError_t dev_malloc (T **p, size_t bytes)
 {
   hipError_t e = hipMalloc (reinterpret_cast<void **> (p), bytes);
   static const bool poison = getenv ("VFHIP_DEBUG_POISON") != nullptr;
-  if (e == hipSuccess && poison) { e = hipMemset (*p, 0xA5, bytes); if (e == hipSuccess) e = hipDeviceSynchronize (); }      // (hipMemset returns before the fill has run)
+  if (e == hipSuccess && poison) {
+    e = hipMemset (*p, 0xA5, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize ();                  // (hipMemset returns before the fill has run)
+    if (e != hipSuccess) { (void) hipFree (*p); *p = nullptr; }        // an error never leaves the caller with memory it does not know about
+  }
   return e;
 }
 

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvfhip.so")
+# $VFHIP_LIB: another build of the SAME library (tools/exp A/B variants) — never a fallback: the file must exist, and the choice is printed
+LIB_PATH = os.environ.get("VFHIP_LIB") or os.path.join(_HERE, "libvfhip.so")
 
 FORMATS = {"BGRA": 0, "RGBA": 1, "NV12": 2, "I420": 3, "UYVY": 4, "YUY2": 5}
 MATRICES = {"bt601": 0, "bt709": 1, "bt2020": 2}
@@ -48,6 +49,9 @@ def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `make -C {_HERE}` (or __graft_entry__.build()); "
                           "vfhip has no CPU fallback")
+    if os.environ.get("VFHIP_LIB"):
+        import sys
+        print(f"vfhip: using $VFHIP_LIB = {LIB_PATH} instead of the product library", file=sys.stderr)
     lib = C.CDLL(LIB_PATH)
     lib.vfhip_last_error_string.restype = C.c_char_p
     for n in ("vfhip_pinned_alloc", "vfhip_device_malloc", "vfhip_convertscale_new", "vfhip_deinterlace_new",

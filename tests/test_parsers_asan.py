@@ -234,11 +234,49 @@ def test_jpeg_decoder_under_asan(parsers, tmp_path):
         "prog_refine_first.jpg": soi + seg(0xdb, bytes([0] + [1] * 64)) + seg(0xc2, struct.pack(">BHHB", 8, 16, 16, 1) + bytes([1, 0x11, 0]))
                                  + seg(0xda, bytes([1, 1, 0, 0, 0, 0x10])) + b"\xaa" * 40 + b"\xff\xd9",
     }
-    for name, data in adversarial.items():
+    # sampling factors the encoders above never produce (round-2 advisor finding: a 3:2 ratio took the 1:1 copy over a smaller plane).  Hand-built streams:
+    # all-ones quantisation table, one-code Huffman tables (DC size 0 / AC end-of-block), so every block is the two bits "00" and zero bytes are valid data
+    dqt = seg(0xdb, bytes([0] + [1] * 64))
+    dht = seg(0xc4, bytes([0x00, 1] + [0] * 15 + [0])) + seg(0xc4, bytes([0x10, 1] + [0] * 15 + [0]))
+    def frame(w, h, samp, prog):
+        sof = seg(0xc2 if prog else 0xc0, struct.pack(">BHHB", 8, h, w, len(samp)) + b"".join(bytes([k + 1, (a << 4) | b, 0]) for k, (a, b) in enumerate(samp)))
+        sos = seg(0xda, bytes([len(samp)] + [x for k in range(len(samp)) for x in (k + 1, 0)] + ([0, 0, 0] if prog else [0, 63, 0])))
+        return soi + dqt + dht + sof + sos + b"\x00" * 400 + b"\xff\xd9"
+    fractional, integral = {}, {}
+    for prog in (False, True):
+        t = "p" if prog else "s"
+        fractional[f"frac33_{t}.jpg"] = frame(24, 24, [(3, 3), (2, 2), (2, 2)], prog)
+        fractional[f"frac31_{t}.jpg"] = frame(24, 8, [(3, 1), (2, 1), (2, 1)], prog)
+        fractional[f"frac13_{t}.jpg"] = frame(8, 24, [(1, 3), (1, 2), (1, 2)], prog)
+        fractional[f"frac44_{t}.jpg"] = frame(32, 32, [(4, 4), (3, 3), (1, 1)], prog)
+        fractional[f"frac_mixed_{t}.jpg"] = frame(29, 31, [(2, 3), (2, 2), (1, 1)], prog)
+        integral[f"int44_{t}.jpg"] = frame(33, 35, [(4, 4), (1, 1), (2, 2)], prog)      # 4:1 replication beside a 2:1 triangle filter
+        integral[f"int31_{t}.jpg"] = frame(25, 9, [(3, 1), (1, 1), (1, 1)], prog)
+        integral[f"int14_{t}.jpg"] = frame(7, 37, [(1, 4), (1, 2), (1, 1)], prog)
+        integral[f"int42_{t}.jpg"] = frame(17, 17, [(4, 2), (2, 2), (2, 1)], prog)
+        integral[f"int_cmax_{t}.jpg"] = frame(19, 21, [(1, 1), (2, 2), (1, 2)], prog)   # luma is NOT the largest component
+    adversarial.update(fractional)
+    # scans are cheap to write and expensive to walk: 200 DC-refinement scans of 14 bytes each, and a scan with no entropy-coded byte at all
+    adversarial["many_scans.jpg"] = (soi + dqt + dht + seg(0xc2, struct.pack(">BHHB", 8, 16, 16, 1) + bytes([1, 0x11, 0])) + seg(0xda, bytes([1, 1, 0, 0, 0, 0x01])) + b"\x00" * 8
+                                     + (seg(0xda, bytes([1, 1, 0, 0, 0, 0x10])) + b"\x00") * 200 + b"\xff\xd9")
+    adversarial["empty_scan.jpg"] = soi + dqt + dht + seg(0xc2, struct.pack(">BHHB", 8, 16, 16, 1) + bytes([1, 0x11, 0])) + seg(0xda, bytes([1, 1, 0, 0, 0, 0])) + b"\xff\xd9"
+    for name, data in list(adversarial.items()) + list(integral.items()):
         q = tmp_path / name; q.write_bytes(data); files.append(q)
+    # the mutation fuzzer aims at the frame header's sampling bytes too (random flips almost never hit those three bytes)
+    for j, gp in enumerate(good[:n_flip]):
+        gb = open(gp, "rb").read()
+        at = max(gb.find(b"\xff\xc0"), gb.find(b"\xff\xc2"))
+        ncomp = gb[at + 9]
+        for k in range(40):
+            b = bytearray(gb)
+            for c in range(ncomp):
+                if rng.random() < 0.7:
+                    b[at + 11 + 3 * c] = (int(rng.integers(1, 5)) << 4) | int(rng.integers(1, 5))
+            q = tmp_path / f"samp{j}_{k}.jpg"; q.write_bytes(bytes(b)); files.append(q)
     rc = run(parsers, files)
     assert all(rc[gp] == 0 for gp in good), {gp: rc[gp] for gp in good}
     for name in adversarial:
         if name != "prog_refine_first.jpg":               # (DC refinement bits without a first scan decode to something; it must only be memory-safe)
             assert rc[str(tmp_path / name)] < 0, name
+    assert all(rc[str(tmp_path / name)] == 0 for name in integral), {n: rc[str(tmp_path / n)] for n in integral}
     assert rc[str(tmp_path / "trunc0.jpg")] < 0 and rc[str(tmp_path / f"trunc{len(base) // 2}.jpg")] < 0
