@@ -23,11 +23,25 @@ using namespace vfhip;
 
 namespace vfhip {
 
+// The uniforms of the colour stages folded on the host (vf_fold) for the fast path, see color_fast ().
+enum { VF_ON_HUE = 1, VF_ON_GAMMA = 2, VF_ON_B = 4, VF_ON_KEY = 8, VF_ON_KEY_STEP = 16, VF_ON_VIG = 32, VF_ON_NOISE = 64 };
+struct VfFast {
+  float a[3][3], ao[3];            // brightness, contrast, saturation: one affine map
+  float b[3][3], bo[3];            // sepia mix, invert: one affine map
+  float hue_shift, inv_gamma;      // hue / 2 pi; 1 / gamma
+  float key_r, key_g, key_b, key_e0, key_scale, key_bias;     // smoothstep argument t = clamp (dist * scale + bias); step: dist < e0 ? 0 : 1
+  float vig, noise_gain;           // vignette amount; noise * .5
+  float fw, fh, lut_nm1, lut_n;    // frame size, LUT size - 1, LUT size, as floats
+  uint32_t on;                     // VF_ON_*
+};
+
 struct VfParams {
   metal::Img in;
   metal::OutImg out;
   VfHipVideoFilterParams u;
-  const float4 *lut;
+  VfFast f;
+  const float4 *lut;               // fp32 cells (96 bytes), the exact path's table
+  const uint4 *lut16;              // fp16 cells (64 bytes), the fast path's table; null when the table does not fit fp16
   int lut_size;
   int quad_in;                     // k_vf_sharp: a 4:2:0 input that meets metal::fetch420_quad's contract (the region fill takes 4 x 2 pixels at a time)
   size_t in_pitch, out_pitch;      // batch: frame blockIdx.z at base + z * pitch, frame_index + z
@@ -192,18 +206,161 @@ __device__ __forceinline__ void lut_sample (const float4 *cells, int N, F4 &c)
   c.r = o[0]; c.g = o[1]; c.b = o[2];
 }
 
-// pass 1 of the reference for one pixel: sample (exact texel, linear chroma) -> adjustments -> LUT -> 8-bit target
-__device__ __forceinline__ uint32_t vf_pass1 (const VfParams &p, int x, int y)
+
+// ---- the fast colour path (round 3; default) -----------------------------------------------------------------------
+// The reference compiles its MSL with default options (common/vfmetaldevice.m:87-93: options nil, i.e. fast-math on), so pow, /, sqrt,
+// length and distance of applyColorAdjustments (videofilter/metalvideofilter_shaders.h:92-155) ARE hardware approximations there.  This path
+// does the same with CDNA's: v_log_f32 / v_exp_f32 for the gamma pow, v_rcp_f32 for the divisions, v_sqrt_f32 for the distances (1 ulp each,
+// 6 issue cycles per wave against ~75 for vf_powf), and folds what is affine in the uniforms on the host (vf_fold): brightness, contrast and
+// saturation are ONE 3 x 3 map + offset, the sepia mix and the inversion another.  Same stages, same order, same clamps; every intermediate
+// differs from the exact sequence by a few ulp (1e-6), which moves an 8-bit result only where it sits within that of a rounding
+// boundary: tests compare this path with oracle/metalref.c at +-1 LSB and bound the fraction of bytes that differ.  color_adjust () above
+// — the oracle's sequence operation for operation — stays as the exact path (VFHIP_VF_EXACT=1), which the tests hold to the oracle too.
+// Issue-rate facts used (tools/ubench/valu_rate3.hip, profiles/r03a_valu_rate3.txt): add / mul / fma with or without the clamp modifier 2 cycles
+// per wave64; min / max / med3 / cndmask / compare / fract / floor / every cvt 3.1; log / exp / rcp / sqrt 6.
+__device__ __forceinline__ float fast_fract (float x) { return __builtin_amdgcn_fractf (x); }
+__device__ __forceinline__ F4 color_fast (F4 c, const VfFast &f, float tu, float tv, uint32_t frame)
 {
-  x = metal::iclamp (x, 0, p.out.w - 1); y = metal::iclamp (y, 0, p.out.h - 1);
-  const float tu = ((float) x + 0.5f) * (1.0f / (float) p.out.w), tv = ((float) y + 0.5f) * (1.0f / (float) p.out.h);      // wave-uniform reciprocals (oracle: inv_w, inv_h)
-  F4 c = metal::fetch_1to1 (p.in, x, y, true);
-  c = color_adjust (c, p.u, tu, tv, p.out.w, p.out.h);
+  // brightness, contrast, saturation (affine), then the clamp every later stage starts with (folds into the last fma)
+  float r = clamp01 (fmaf (f.a[0][0], c.r, fmaf (f.a[0][1], c.g, fmaf (f.a[0][2], c.b, f.ao[0]))));
+  float g = clamp01 (fmaf (f.a[1][0], c.r, fmaf (f.a[1][1], c.g, fmaf (f.a[1][2], c.b, f.ao[1]))));
+  float b = clamp01 (fmaf (f.a[2][0], c.r, fmaf (f.a[2][1], c.g, fmaf (f.a[2][2], c.b, f.ao[2]))));
+  float a = c.a;
+  if (f.on & VF_ON_HUE) {
+    // rgbToHsv: the step / mix selections of the shader are max / min of the sorted channels plus two selected constants
+    const float px = fmaxf (g, b), py = fminf (g, b);
+    const bool gb = !(g < b), rp = !(r < px);
+    const float pz = gb ? 0.0f : -1.0f, pw = gb ? -1.0f / 3.0f : 2.0f / 3.0f;
+    const float qx = fmaxf (r, px), qw = fminf (r, px), qz = rp ? pz : pw;
+    const float d = qx - fminf (qw, py);
+    const float h0 = fabsf (fmaf (qw - py, __builtin_amdgcn_rcpf (fmaf (6.0f, d, 1.0e-10f)), qz));
+    const float vs = d * __builtin_amdgcn_rcpf (qx + 1.0e-10f) * qx;             // v * s
+    // hsvToRgb on the rotated hue: v * mix (1, clamp (p - 1), s) = (v - v s) + v s * clamp (p - 1)
+    const float h = fast_fract (h0 + f.hue_shift);
+    const float base = qx - vs;
+    const float pr = fabsf (fmaf (h, 6.0f, -3.0f));                                // fract (h + 1) == h
+    const float pg = fabsf (fmaf (fast_fract (h + 2.0f / 3.0f), 6.0f, -3.0f));
+    const float pb = fabsf (fmaf (fast_fract (h + 1.0f / 3.0f), 6.0f, -3.0f));
+    r = fmaf (vs, clamp01 (pr - 1.0f), base); g = fmaf (vs, clamp01 (pg - 1.0f), base); b = fmaf (vs, clamp01 (pb - 1.0f), base);
+  }
+  r = fmaxf (r, 0.0001f); g = fmaxf (g, 0.0001f); b = fmaxf (b, 0.0001f);         // (<= 1 already: clamped above / v, s <= 1)
+  if (f.on & VF_ON_GAMMA) {
+    r = __builtin_amdgcn_exp2f (f.inv_gamma * __builtin_amdgcn_logf (r));
+    g = __builtin_amdgcn_exp2f (f.inv_gamma * __builtin_amdgcn_logf (g));
+    b = __builtin_amdgcn_exp2f (f.inv_gamma * __builtin_amdgcn_logf (b));
+  }
+  if (f.on & VF_ON_B) {
+    const float r1 = fmaf (f.b[0][0], r, fmaf (f.b[0][1], g, fmaf (f.b[0][2], b, f.bo[0])));
+    const float g1 = fmaf (f.b[1][0], r, fmaf (f.b[1][1], g, fmaf (f.b[1][2], b, f.bo[1])));
+    const float b1 = fmaf (f.b[2][0], r, fmaf (f.b[2][1], g, fmaf (f.b[2][2], b, f.bo[2])));
+    r = r1; g = g1; b = b1;
+  }
+  if (f.on & VF_ON_KEY) {
+    const float dr = r - f.key_r, dg = g - f.key_g, db = b - f.key_b;
+    const float dist = __builtin_amdgcn_sqrtf (fmaf (db, db, fmaf (dg, dg, dr * dr)));
+    if (f.on & VF_ON_KEY_STEP) a = dist < f.key_e0 ? 0.0f : a;
+    else {
+      const float t = clamp01 (fmaf (dist, f.key_scale, f.key_bias));
+      a *= (t * t) * fmaf (-2.0f, t, 3.0f);
+    }
+  }
+  if (f.on & VF_ON_VIG) {
+    const float cx = tu - 0.5f, cy = tv - 0.5f;
+    const float q = __builtin_amdgcn_sqrtf (fmaf (cx, cx, cy * cy));
+    const float t = clamp01 (fmaf (q, 2.0f * 1.414f, -1.0f));                       // smoothstep (.5, 1, q * 1.414)
+    const float vig = fmaf ((t * t) * fmaf (-2.0f, t, 3.0f), -f.vig, 1.0f);
+    r *= vig; g *= vig; b *= vig;
+  }
+  if (f.on & VF_ON_NOISE) {
+    // the hash amplifies ulp differences of its coordinates a hundredfold: its operations stay the oracle's, in its order (only fract is the instruction)
+    const float fo = (float) frame * 0.00137f;
+    const float hx = tu * f.fw, hy = tv * f.fh;
+    float x = fast_fract (hx * 0.1031f + fo), y = fast_fract (hy * 0.1031f + fo);
+    const float d = x * (y + 33.33f) + y * (x + 33.33f) + x * (x + 33.33f);     // (z == x: the shader's p3.z is p.x again)
+    x += d; y += d;
+    const float n = (fast_fract ((x + y) * x) - 0.5f) * f.noise_gain;
+    r += n; g += n; b += n;
+  }
+  F4 o; o.r = clamp01 (r); o.g = clamp01 (g); o.b = clamp01 (b); o.a = a;
+  return o;
+}
+
+// The fast path's LUT: 64-byte cells (one L2 line per pixel; 3 x 16 bytes read), fp16, per channel the eight coefficients of the cell's
+// trilinear polynomial  k0 + fx kx + fy (ky + fx kxy) + fz (kz + fx kxz + fy (kyz + fx kxyz))  of the table's RESIDUAL against the identity
+// (entry - lattice coordinate), times 255: trilinear interpolation reproduces the identity exactly, so  out * 255 = 255 c + poly (f),
+// and what fp16 rounds (2^-12 relative) is the residual — small for grading LUTs, zero for an identity table — not the value.  A gather of
+// random cells is bound by L2 requests, not by arithmetic (tools/ubench/lut_gather.hip, profiles/r03a_lut_gather.txt: 96-byte fp32 cells
+// 15.0 us per 1080p frame, 48-byte cells 11.3 — they straddle lines —, 64-byte aligned cells with three parts read 8.9); v_fma_mix_f32 feeds
+// the halves to an fp32 fma without a conversion.  Returns r, g, b TIMES 255 (the quantiser's multiply is folded in).
+typedef _Float16 h8 __attribute__ ((ext_vector_type (8)));
+__device__ __forceinline__ void lut_sample16 (const uint4 *cells, float nm1, float fn, F4 &c)
+{
+  const float x = c.r * nm1, y = c.g * nm1, z = c.b * nm1;               // lattice coordinate: c * (N-1)/N + .5/N, times N, minus .5
+  const float fx = fast_fract (x), fy = fast_fract (y), fz = fast_fract (z);
+  const float idx = fmaf (fmaf (z - fz, fn, y - fy), fn, x - fx);       // exact in fp32: < 2^24 (c == 1: cell N - 1, whose +1 corners are itself)
+  const uint4 *cell = cells + (uint32_t) idx * 4u;
+  const float in[3] = { c.r, c.g, c.b };
+  float o[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const uint4 raw = cell[k];
+    h8 q;
+    __builtin_memcpy (&q, &raw, 16);
+    const float A = fmaf (fx, (float) q[1], (float) q[0]), B = fmaf (fx, (float) q[3], (float) q[2]);
+    const float C = fmaf (fx, (float) q[5], (float) q[4]), D = fmaf (fx, (float) q[7], (float) q[6]);
+    o[k] = fmaf (in[k], 255.0f, fmaf (fz, fmaf (fy, D, C), fmaf (fy, B, A)));
+  }
+  c.r = o[0]; c.g = o[1]; c.b = o[2];
+}
+
+// pass 1 of the reference for one texel value: adjustments -> LUT -> 8-bit target.  FAST: color_fast + the fp16 table; otherwise the oracle's sequence.
+template <bool FAST> __device__ __forceinline__ uint32_t vf_shade (const VfParams &p, F4 c, float tu, float tv)
+{
+  if (FAST) {
+    c = color_fast (c, p.f, tu, tv, p.u.frame_index);
+    if (p.lut16) {
+      lut_sample16 (p.lut16, p.f.lut_nm1, p.f.lut_n, c);                 // r, g, b come back times 255
+      uint32_t q = __builtin_amdgcn_cvt_pk_u8_f32 (c.r, 0u, 0u);
+      q = __builtin_amdgcn_cvt_pk_u8_f32 (c.g, 1u, q);
+      q = __builtin_amdgcn_cvt_pk_u8_f32 (c.b, 2u, q);
+      return __builtin_amdgcn_cvt_pk_u8_f32 (c.a * 255.0f, 3u, q);
+    }
+  } else c = color_adjust (c, p.u, tu, tv, p.out.w, p.out.h);
   if (p.lut) lut_sample (p.lut, p.lut_size, c);
   return metal::quant_rgba8 (c);
 }
+// ... for one pixel: sample (exact texel, linear chroma) first
+template <bool FAST> __device__ __forceinline__ uint32_t vf_pass1 (const VfParams &p, int x, int y)
+{
+  x = metal::iclamp (x, 0, p.out.w - 1); y = metal::iclamp (y, 0, p.out.h - 1);
+  const float tu = ((float) x + 0.5f) * (1.0f / (float) p.out.w), tv = ((float) y + 0.5f) * (1.0f / (float) p.out.h);      // wave-uniform reciprocals (oracle: inv_w, inv_h)
+  return vf_shade<FAST> (p, metal::fetch_1to1 (p.in, x, y, true), tu, tv);
+}
+// an RGBA / BGRA texel as the sampler returns it
+__device__ __forceinline__ F4 vf_texel_rgb (uint32_t t, bool rgba)
+{
+  F4 c;
+  c.g = metal::un8 ((t >> 8) & 0xff); c.a = metal::un8 (t >> 24);
+  if (rgba) { c.r = metal::un8 (t & 0xff); c.b = metal::un8 ((t >> 16) & 0xff); }
+  else { c.b = metal::un8 (t & 0xff); c.r = metal::un8 ((t >> 16) & 0xff); }
+  return c;
+}
 
-__global__ __launch_bounds__ (256) void k_vf_point (const VfParams pp)
+// ... for an RGBA / BGRA texel in its 32 bits.  FAST: the launch has folded the texel's 1 / 255 into the first affine map (vf_launch_kernels: bytes
+// kernels), so the channels enter as byte values; without a chroma key the alpha byte passes through untouched (rint (a / 255 * 255) == a).
+template <bool FAST> __device__ __forceinline__ uint32_t vf_shade_texel (const VfParams &p, uint32_t t, bool rgba, float tu, float tv)
+{
+  if (!FAST) return vf_shade<false> (p, vf_texel_rgb (t, rgba), tu, tv);
+  F4 c;
+  c.g = (float) ((t >> 8) & 0xff);
+  if (rgba) { c.r = (float) (t & 0xff); c.b = (float) ((t >> 16) & 0xff); }
+  else { c.b = (float) (t & 0xff); c.r = (float) ((t >> 16) & 0xff); }
+  if (p.f.on & VF_ON_KEY) { c.a = metal::un8 (t >> 24); return vf_shade<true> (p, c, tu, tv); }
+  c.a = 0.0f;
+  return (vf_shade<true> (p, c, tu, tv) & 0x00ffffffu) | (t & 0xff000000u);
+}
+
+template <bool FAST> __global__ __launch_bounds__ (256) void k_vf_point (const VfParams pp)
 {
   const VfParams p = vf_frame (pp);
   const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
@@ -212,15 +369,17 @@ __global__ __launch_bounds__ (256) void k_vf_point (const VfParams pp)
 #pragma unroll
   for (int dy = 0; dy < 2; dy++)
 #pragma unroll
-    for (int dx = 0; dx < 2; dx++) q[dy][dx] = vf_pass1 (p, 2 * bx + dx, 2 * by + dy);
+    for (int dx = 0; dx < 2; dx++) q[dy][dx] = vf_pass1<FAST> (p, 2 * bx + dx, 2 * by + dy);
   metal::store_block (p.out, bx, by, q);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // k_vf_sharp: sharpness != 0.  One workgroup (512 lanes) per 128 x 56 output tile:
-//   1. pass 1 (colour adjustments + LUT — by far the most expensive part) for the tile and its 4-pixel halo,
-//      136 x 64 pixels = 1.21x redundancy (the first version's 64x16 tile: 1.69x, 128x32: 1.33x), quantised to 8 bits
-//      into LDS exactly where the reference wrote its render target;
+//   0. RGBA / BGRA inputs: the raw texels of the tile and its 4-pixel halo (136 x 64, clamped to the image like the blur's reads) go to LDS
+//      first, the seventeen loads of a lane all in flight — pass 1 then reads LDS, and no lane ever waits for HBM between two pixels (round 2
+//      loaded a texel, shaded it, loaded the next: with sharpening only, the kernel spent half its time in those seventeen latencies);
+//   1. pass 1 (colour adjustments + LUT — by far the most expensive part) for the region, 1.21x redundancy (the first version's 64x16
+//      tile: 1.69x, 128x32: 1.33x), quantised to 8 bits into LDS exactly where the reference wrote its render target;
 //   2. horizontal 9-tap Gaussian, LDS -> LDS: a lane owns one ROW of the region (64 rows = one wave) and a run of 16
 //      columns; it slides along the row, so every texel is unpacked once per run (24 unpacks for 16 outputs instead of
 //      144) and a wave reads one column at a time — conflict-free with the odd row stride;
@@ -235,10 +394,27 @@ constexpr int VF_TW = 128, VF_TH = 56, VF_THREADS = 512;
 constexpr int VF_RW = VF_TW + 2 * VF_HALO, VF_RH = VF_TH + 2 * VF_HALO;      // 136 x 64
 constexpr int VF_RS = VF_RW + 1, VF_HS = VF_TW + 1;                          // odd LDS row strides (dwords)
 constexpr int VF_HRUN = 16, VF_VRUN = 14;
-static_assert (VF_RH == 64 && VF_THREADS == VF_RH * (VF_TW / VF_HRUN) && VF_THREADS == VF_TW * (VF_TH / VF_VRUN), "tile / lane mapping");
+constexpr int VF_PER = VF_RW * VF_RH / VF_THREADS;                           // region pixels per lane: 17
+static_assert (VF_RH == 64 && VF_THREADS == VF_RH * (VF_TW / VF_HRUN) && VF_THREADS == VF_TW * (VF_TH / VF_VRUN) && VF_PER * VF_THREADS == VF_RW * VF_RH, "tile / lane mapping");
 __constant__ float kBlurW[9] = { 0.028532f, 0.067234f, 0.124009f, 0.179044f, 0.20236f, 0.179044f, 0.124009f, 0.067234f, 0.028532f };
 
 struct F3 { float r, g, b; };
+// FAST: the blur and the unsharp mask work on the byte VALUES (0 .. 255 as floats) instead of value / 255: the same weighted sums up to the last ulp, and
+// every unpack loses its multiply by 1 / 255, every quantisation its multiply by 255 (v_cvt_pk_u8_f32 rounds to nearest even and saturates either way)
+template <bool FAST> __device__ __forceinline__ F3 unpack_rgb (uint32_t q)
+{
+  F3 o;
+  if (FAST) { o.r = (float) (q & 0xff); o.g = (float) ((q >> 8) & 0xff); o.b = (float) ((q >> 16) & 0xff); }
+  else { o.r = metal::un8 (q & 0xff); o.g = metal::un8 ((q >> 8) & 0xff); o.b = metal::un8 ((q >> 16) & 0xff); }
+  return o;
+}
+template <bool FAST> __device__ __forceinline__ uint32_t quant_rgb (float r, float g, float b)
+{
+  const float k = FAST ? 1.0f : 255.0f;
+  uint32_t q = __builtin_amdgcn_cvt_pk_u8_f32 (FAST ? r : r * k, 0u, 0u);
+  q = __builtin_amdgcn_cvt_pk_u8_f32 (FAST ? g : g * k, 1u, q);
+  return __builtin_amdgcn_cvt_pk_u8_f32 (FAST ? b : b * k, 2u, q);
+}
 __device__ __forceinline__ F3 unpack_rgb8 (uint32_t q) { F3 o; o.r = metal::un8 (q & 0xff); o.g = metal::un8 ((q >> 8) & 0xff); o.b = metal::un8 ((q >> 16) & 0xff); return o; }
 __device__ __forceinline__ uint32_t quant_rgb8 (float r, float g, float b)
 {
@@ -250,7 +426,7 @@ __device__ __forceinline__ uint32_t quant_rgb8 (float r, float g, float b)
 // k_vf_point_rgba4: sharpness == 0, RGBA / BGRA in and out, 16-byte aligned rows (the filter on a decoded-to-RGB or rendered stream: by far the
 // most common way the element is used).  No 4:2:0 output means no 2 x 2 blocks: a lane takes four adjacent pixels of one row as ONE 16-byte
 // load and one 16-byte non-temporal store (k_vf_point moves 8 bytes per access); per pixel exactly vf_pass1's operations.
-__global__ __launch_bounds__ (256) void k_vf_point_rgba4 (const VfParams pp)
+template <bool FAST> __global__ __launch_bounds__ (256) void k_vf_point_rgba4 (const VfParams pp)
 {
   const VfParams p = vf_frame (pp);
   const int x4 = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
@@ -264,13 +440,7 @@ __global__ __launch_bounds__ (256) void k_vf_point_rgba4 (const VfParams pp)
   for (int i = 0; i < 4; i++) {
     const int x = 4 * x4 + i;
     const float tu = ((float) x + 0.5f) * (1.0f / (float) p.out.w);
-    F4 c;                                                             // metal::fetch_1to1's RGBA / BGRA texel
-    c.g = metal::un8 ((t[i] >> 8) & 0xff); c.a = metal::un8 (t[i] >> 24);
-    if (rgba_in) { c.r = metal::un8 (t[i] & 0xff); c.b = metal::un8 ((t[i] >> 16) & 0xff); }
-    else { c.b = metal::un8 (t[i] & 0xff); c.r = metal::un8 ((t[i] >> 16) & 0xff); }
-    c = color_adjust (c, p.u, tu, tv, p.out.w, p.out.h);
-    if (p.lut) lut_sample (p.lut, p.lut_size, c);
-    const uint32_t q = metal::quant_rgba8 (c);
+    const uint32_t q = vf_shade_texel<FAST> (p, t[i], rgba_in, tu, tv);               // metal::fetch_1to1's RGBA / BGRA texel
     o[i] = bgra_out ? __builtin_amdgcn_perm (0u, q, 0x03000102u) : q;
   }
   __builtin_nontemporal_store (o, reinterpret_cast<v4u *> (p.out.p[0] + (size_t) y * p.out.s[0]) + x4);
@@ -281,7 +451,7 @@ __global__ __launch_bounds__ (256) void k_vf_point_rgba4 (const VfParams pp)
 // the reference: four taps per pixel) and two-byte stores; here the block's chroma neighbourhood is three window loads, the luma two dwords
 // (metal::fetch_quad), and the output goes out as dwords / 16-byte rows (metal::store_quad).  Per pixel exactly vf_pass1's operations on exactly
 // its inputs: NV12 -> NV12 1080p 7.5 -> 5.05 us, NV12 -> BGRA 6.9 -> 4.3.
-__global__ __launch_bounds__ (256) void k_vf_point_quad (const VfParams pp)
+template <bool FAST> __global__ __launch_bounds__ (256) void k_vf_point_quad (const VfParams pp)
 {
   const VfParams p = vf_frame (pp);
   const int xq = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
@@ -294,17 +464,12 @@ __global__ __launch_bounds__ (256) void k_vf_point_quad (const VfParams pp)
   for (int dy = 0; dy < 2; dy++) {
     const float tv = ((float) (2 * by + dy) + 0.5f) * inv_h;
 #pragma unroll
-    for (int dx = 0; dx < 4; dx++) {
-      const float tu = ((float) (4 * xq + dx) + 0.5f) * inv_w;
-      F4 v = color_adjust (c[dy][dx], p.u, tu, tv, p.out.w, p.out.h);
-      if (p.lut) lut_sample (p.lut, p.lut_size, v);
-      q[dy][dx] = metal::quant_rgba8 (v);
-    }
+    for (int dx = 0; dx < 4; dx++) q[dy][dx] = vf_shade<FAST> (p, c[dy][dx], ((float) (4 * xq + dx) + 0.5f) * inv_w, tv);
   }
   metal::store_quad (p.out, xq, by, q);
 }
 
-__global__ __launch_bounds__ (VF_THREADS, 2) void k_vf_sharp (const VfParams pp)
+template <bool FAST> __global__ __launch_bounds__ (VF_THREADS, 2) void k_vf_sharp (const VfParams pp)
 {
   const VfParams p = vf_frame (pp);
   __shared__ uint32_t rt[VF_RH * VF_RS];       // pass-1 render target, tile + halo (clamped to the image like the blur's reads)
@@ -312,10 +477,10 @@ __global__ __launch_bounds__ (VF_THREADS, 2) void k_vf_sharp (const VfParams pp)
   const int x0 = blockIdx.x * VF_TW, y0 = blockIdx.y * VF_TH;
   const int tid = threadIdx.x;
   const int w = p.out.w, h = p.out.h;
+  const float inv_w = 1.0f / (float) p.out.w, inv_h = 1.0f / (float) p.out.h;
   if (p.quad_in) {
     // 4:2:0 input: the region (its corner sits on the 4 x 2 grid) in quads — the chroma neighbourhood of eight pixels as three window loads instead
     // of 32 taps; quads off the frame's edge (the halo of an edge tile) are clamped duplicates and go pixel by pixel
-    const float inv_w = 1.0f / (float) p.out.w, inv_h = 1.0f / (float) p.out.h;
     for (int i = tid; i < (VF_RW / 4) * (VF_RH / 2); i += VF_THREADS) {
       const int qx = i % (VF_RW / 4), qy = i / (VF_RW / 4);
       const int gx = x0 - VF_HALO + 4 * qx, gy = y0 - VF_HALO + 2 * qy;
@@ -327,21 +492,44 @@ __global__ __launch_bounds__ (VF_THREADS, 2) void k_vf_sharp (const VfParams pp)
         for (int dy = 0; dy < 2; dy++) {
           const float tv = ((float) (gy + dy) + 0.5f) * inv_h;
 #pragma unroll
-          for (int dx = 0; dx < 4; dx++) {
-            F4 v = color_adjust (c[dy][dx], p.u, ((float) (gx + dx) + 0.5f) * inv_w, tv, p.out.w, p.out.h);
-            if (p.lut) lut_sample (p.lut, p.lut_size, v);
-            d[dy * VF_RS + dx] = metal::quant_rgba8 (v);
-          }
+          for (int dx = 0; dx < 4; dx++) d[dy * VF_RS + dx] = vf_shade<FAST> (p, c[dy][dx], ((float) (gx + dx) + 0.5f) * inv_w, tv);
         }
       } else {
 #pragma unroll 1
-        for (int k = 0; k < 8; k++) d[(k >> 2) * VF_RS + (k & 3)] = vf_pass1 (p, gx + (k & 3), gy + (k >> 2));
+        for (int k = 0; k < 8; k++) d[(k >> 2) * VF_RS + (k & 3)] = vf_pass1<FAST> (p, gx + (k & 3), gy + (k >> 2));
       }
+    }
+  } else if (p.in.fmt == VFHIP_FORMAT_RGBA || p.in.fmt == VFHIP_FORMAT_BGRA) {
+    // step 0: raw texels -> LDS, every load of the lane issued before the first is used (consecutive lanes = consecutive pixels of a region row)
+    {
+      uint32_t raw[VF_PER];
+#pragma unroll
+      for (int k = 0; k < VF_PER; k++) {
+        const int i = tid + k * VF_THREADS, rx = i % VF_RW, ry = i / VF_RW;
+        const int gx = metal::iclamp (x0 - VF_HALO + rx, 0, w - 1), gy = metal::iclamp (y0 - VF_HALO + ry, 0, h - 1);
+        raw[k] = *reinterpret_cast<const uint32_t *> (p.in.p[0] + (size_t) gy * p.in.s[0] + 4 * (size_t) gx);
+      }
+#pragma unroll
+      for (int k = 0; k < VF_PER; k++) { const int i = tid + k * VF_THREADS; rt[(i / VF_RW) * VF_RS + i % VF_RW] = raw[k]; }
+    }
+    // step 1: pass 1 in place, each lane on the texels it staged itself (no barrier needed in between); (rx, ry) advance incrementally
+    const bool rgba_in = p.in.fmt == VFHIP_FORMAT_RGBA;
+    int rx = tid % VF_RW, ry = tid / VF_RW;
+#ifndef VF_P1_UNROLL
+#define VF_P1_UNROLL 2
+#endif
+#pragma unroll VF_P1_UNROLL
+    for (int k = 0; k < VF_PER; k++) {
+      uint32_t *d = rt + ry * VF_RS + rx;
+      const int gx = metal::iclamp (x0 - VF_HALO + rx, 0, w - 1), gy = metal::iclamp (y0 - VF_HALO + ry, 0, h - 1);
+      *d = vf_shade_texel<FAST> (p, *d, rgba_in, ((float) gx + 0.5f) * inv_w, ((float) gy + 0.5f) * inv_h);
+      rx += VF_THREADS % VF_RW; ry += VF_THREADS / VF_RW;
+      if (rx >= VF_RW) { rx -= VF_RW; ry++; }
     }
   } else
   for (int i = tid; i < VF_RW * VF_RH; i += VF_THREADS) {
     const int rx = i % VF_RW, ry = i / VF_RW;
-    rt[ry * VF_RS + rx] = vf_pass1 (p, x0 - VF_HALO + rx, y0 - VF_HALO + ry);
+    rt[ry * VF_RS + rx] = vf_pass1<FAST> (p, x0 - VF_HALO + rx, y0 - VF_HALO + ry);
   }
   __syncthreads ();
   // horizontal pass.  Reads clamp to the IMAGE (not the region): region column rx holds image column clamp(x0-4+rx)
@@ -351,13 +539,13 @@ __global__ __launch_bounds__ (VF_THREADS, 2) void k_vf_sharp (const VfParams pp)
     const uint32_t *src = rt + row * VF_RS + c0;
     F3 px[VF_HRUN + 8];
 #pragma unroll
-    for (int k = 0; k < VF_HRUN + 8; k++) px[k] = unpack_rgb8 (src[k]);
+    for (int k = 0; k < VF_HRUN + 8; k++) px[k] = unpack_rgb<FAST> (src[k]);
 #pragma unroll
     for (int j = 0; j < VF_HRUN; j++) {
       float sr = 0.0f, sg = 0.0f, sb = 0.0f;
 #pragma unroll
       for (int k = 0; k < 9; k++) { sr = fmaf (px[j + k].r, kBlurW[k], sr); sg = fmaf (px[j + k].g, kBlurW[k], sg); sb = fmaf (px[j + k].b, kBlurW[k], sb); }
-      hb[row * VF_HS + c0 + j] = quant_rgb8 (sr, sg, sb);
+      hb[row * VF_HS + c0 + j] = quant_rgb<FAST> (sr, sg, sb);
     }
   }
   __syncthreads ();
@@ -368,13 +556,19 @@ __global__ __launch_bounds__ (VF_THREADS, 2) void k_vf_sharp (const VfParams pp)
     const uint32_t *src = hb + r0 * VF_HS + col;
     F3 px[VF_VRUN + 8];
 #pragma unroll
-    for (int k = 0; k < VF_VRUN + 8; k++) px[k] = unpack_rgb8 (src[k * VF_HS]);
+    for (int k = 0; k < VF_VRUN + 8; k++) px[k] = unpack_rgb<FAST> (src[k * VF_HS]);
 #pragma unroll
     for (int j = 0; j < VF_VRUN; j++) {
       float sr = 0.0f, sg = 0.0f, sb = 0.0f;
 #pragma unroll
       for (int k = 0; k < 9; k++) { sr = fmaf (px[j + k].r, kBlurW[k], sr); sg = fmaf (px[j + k].g, kBlurW[k], sg); sb = fmaf (px[j + k].b, kBlurW[k], sb); }
-      const F3 b = unpack_rgb8 (quant_rgb8 (sr, sg, sb));               // _blurResult is 8-bit as well
+      // _blurResult is 8-bit as well.  The unsharp mask itself stays in the oracle's normalised arithmetic in both paths: with both operands 8-bit
+      // values and amount = .5 every other result is an exact tie in byte units, and the tie must fall the way value / 255 arithmetic makes it fall
+      // (the byte-domain version of this step differed from the oracle in 10 % of the bytes, all of them such ties)
+      F3 b;
+      if (FAST) {                                                       // (the weights sum to < 1: rint of the byte-domain sum needs no clamp)
+        b.r = __builtin_rintf (sr) * (1.0f / 255.0f); b.g = __builtin_rintf (sg) * (1.0f / 255.0f); b.b = __builtin_rintf (sb) * (1.0f / 255.0f);
+      } else b = unpack_rgb8 (quant_rgb8 (sr, sg, sb));
       const uint32_t oq = rt[(r0 + j + VF_HALO) * VF_RS + col + VF_HALO];
       const F3 o = unpack_rgb8 (oq);
       float rr, rg, rb;
@@ -431,10 +625,74 @@ struct VfHipVideoFilter {
   Staging st;
   bool configured = false;
   VfHipVideoInfo in {}, out {};
-  float4 *d_lut = nullptr;
+  float4 *d_lut = nullptr;          // fp32 cells (exact path; the fast path's fallback for tables fp16 cannot hold)
+  uint4 *d_lut16 = nullptr;         // fp16 residual cells (fast path)
   int lut_size = 0;
   Flights fl;                       // pipelined host path (submit / wait)
 };
+
+// the fast path's folded uniforms (VfFast), in double, rounded once
+static VfFast vf_fold (const VfHipVideoFilterParams &u, int w, int hh, int lut_size)
+{
+  VfFast f {};
+  const double k = u.contrast, b0 = u.brightness, s = u.saturation, t = k * b0 - 0.5 * k + 0.5;
+  const double wl[3] = { 0.2126, 0.7152, 0.0722 }, sw = wl[0] + wl[1] + wl[2];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) f.a[i][j] = (float) ((1.0 - s) * wl[j] * k + (i == j ? s * k : 0.0));
+    f.ao[i] = (float) (s * t + (1.0 - s) * t * sw);
+  }
+  if (fabsf (u.hue) > 0.001f) { f.on |= VF_ON_HUE; f.hue_shift = (float) ((double) u.hue / (2.0 * 3.14159265358979323846)); }
+  f.inv_gamma = 1.0f / u.gamma;
+  if (f.inv_gamma != 1.0f) f.on |= VF_ON_GAMMA;
+  const double sep[3][3] = { { 0.393, 0.769, 0.189 }, { 0.349, 0.686, 0.168 }, { 0.272, 0.534, 0.131 } };
+  const double ps = u.sepia > 0.001f ? (double) u.sepia : 0.0, sign = u.invert ? -1.0 : 1.0;
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) f.b[i][j] = (float) (sign * ((i == j ? 1.0 - ps : 0.0) + ps * sep[i][j]));
+    f.bo[i] = u.invert ? 1.0f : 0.0f;
+  }
+  if (ps > 0.0 || u.invert) f.on |= VF_ON_B;
+  if (u.chroma_key_enabled) {
+    f.on |= VF_ON_KEY;
+    f.key_r = u.chroma_key_r; f.key_g = u.chroma_key_g; f.key_b = u.chroma_key_b;
+    const float e0 = u.chroma_key_tolerance, e1 = u.chroma_key_tolerance + u.chroma_key_smoothness;
+    f.key_e0 = e0;
+    if (!(e0 < e1)) f.on |= VF_ON_KEY_STEP;
+    else { const double inv = 1.0 / ((double) e1 - (double) e0); f.key_scale = (float) inv; f.key_bias = (float) (-(double) e0 * inv); }
+  }
+  if (u.vignette > 0.001f) { f.on |= VF_ON_VIG; f.vig = u.vignette; }
+  if (u.noise > 0.001f) { f.on |= VF_ON_NOISE; f.noise_gain = u.noise * 0.5f; }
+  f.fw = (float) w; f.fh = (float) hh;
+  f.lut_nm1 = (float) (lut_size - 1); f.lut_n = (float) lut_size;
+  return f;
+}
+
+template <bool FAST> static void vf_launch_kernels (VfParams p, const VfHipFrame *in, const VfHipFrame *out, int w, int hh, int n_frames, hipStream_t s)
+{
+  const VfHipVideoFilterParams *prm = &p.u;
+  const bool rgb_in = in->info.format == VFHIP_FORMAT_RGBA || in->info.format == VFHIP_FORMAT_BGRA;
+  // the kernels that shade RGBA / BGRA texels straight from their bytes (vf_shade_texel) get the texel's 1 / 255 folded into the first affine map
+  auto bytes_in = [&p] () { for (auto &row : p.f.a) for (float &v : row) v = (float) ((double) v / 255.0); };
+  if (prm->sharpness < -0.001f || prm->sharpness > 0.001f) {
+    if (FAST && rgb_in && !p.quad_in) bytes_in ();
+    dim3 grid ((unsigned) ((w + VF_TW - 1) / VF_TW), (unsigned) ((hh + VF_TH - 1) / VF_TH), (unsigned) n_frames);
+    hipLaunchKernelGGL (k_vf_sharp<FAST>, grid, dim3 (VF_THREADS), 0, s, p);
+  } else {
+    const bool rgb_io = rgb_in && (out->info.format == VFHIP_FORMAT_RGBA || out->info.format == VFHIP_FORMAT_BGRA);
+    const uintptr_t al = (uintptr_t) in->data[0] | (uintptr_t) in->stride[0] | (uintptr_t) p.in_pitch | (uintptr_t) out->data[0] | (uintptr_t) out->stride[0] | (uintptr_t) p.out_pitch;
+    if (rgb_io && !(w & 3) && !(al & 15) && getenv ("VFHIP_VF_BLOCKS") == nullptr) {
+      dim3 grid ((unsigned) ((w / 4 + 63) / 64), (unsigned) ((hh + 3) / 4), (unsigned) n_frames);
+      if (FAST) bytes_in ();
+      hipLaunchKernelGGL (k_vf_point_rgba4<FAST>, grid, dim3 (64, 4), 0, s, p);
+    } else if (getenv ("VFHIP_VF_BLOCKS") == nullptr && metal::quad_frame_ok (in, p.in_pitch, false) && metal::quad_frame_ok (out, p.out_pitch, true)) {
+      dim3 grid ((unsigned) ((w / 4 + 63) / 64), (unsigned) ((hh / 2 + 3) / 4), (unsigned) n_frames);
+      hipLaunchKernelGGL (k_vf_point_quad<FAST>, grid, dim3 (64, 4), 0, s, p);
+    } else {
+      const int bw = (w + 1) / 2, bh = (hh + 1) / 2;
+      dim3 grid ((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4), (unsigned) n_frames);
+      hipLaunchKernelGGL (k_vf_point<FAST>, grid, dim3 (64, 4), 0, s, p);
+    }
+  }
+}
 
 static int vf_launch (VfHipVideoFilter *h, const VfHipFrame *in, VfHipFrame *out, const VfHipVideoFilterParams *prm, hipStream_t s,
     int n_frames = 1, size_t in_pitch = 0, size_t out_pitch = 0)
@@ -445,25 +703,13 @@ static int vf_launch (VfHipVideoFilter *h, const VfHipFrame *in, VfHipFrame *out
   p.u = *prm; p.lut = h->d_lut; p.lut_size = h->lut_size;
   p.quad_in = (in->info.format == VFHIP_FORMAT_NV12 || in->info.format == VFHIP_FORMAT_I420) && metal::quad_frame_ok (in, in_pitch, false) && getenv ("VFHIP_VF_BLOCKS") == nullptr;
   const int w = h->out.width, hh = h->out.height;
-  if (prm->sharpness < -0.001f || prm->sharpness > 0.001f) {
-    dim3 grid ((unsigned) ((w + VF_TW - 1) / VF_TW), (unsigned) ((hh + VF_TH - 1) / VF_TH), (unsigned) n_frames);
-    hipLaunchKernelGGL (k_vf_sharp, grid, dim3 (VF_THREADS), 0, s, p);
-  } else {
-    const bool rgb_io = (in->info.format == VFHIP_FORMAT_RGBA || in->info.format == VFHIP_FORMAT_BGRA) &&
-                        (out->info.format == VFHIP_FORMAT_RGBA || out->info.format == VFHIP_FORMAT_BGRA);
-    const uintptr_t al = (uintptr_t) in->data[0] | (uintptr_t) in->stride[0] | (uintptr_t) in_pitch | (uintptr_t) out->data[0] | (uintptr_t) out->stride[0] | (uintptr_t) out_pitch;
-    if (rgb_io && !(w & 3) && !(al & 15) && getenv ("VFHIP_VF_BLOCKS") == nullptr) {
-      dim3 grid ((unsigned) ((w / 4 + 63) / 64), (unsigned) ((hh + 3) / 4), (unsigned) n_frames);
-      hipLaunchKernelGGL (k_vf_point_rgba4, grid, dim3 (64, 4), 0, s, p);
-    } else if (getenv ("VFHIP_VF_BLOCKS") == nullptr && metal::quad_frame_ok (in, in_pitch, false) && metal::quad_frame_ok (out, out_pitch, true)) {
-      dim3 grid ((unsigned) ((w / 4 + 63) / 64), (unsigned) ((hh / 2 + 3) / 4), (unsigned) n_frames);
-      hipLaunchKernelGGL (k_vf_point_quad, grid, dim3 (64, 4), 0, s, p);
-    } else {
-      const int bw = (w + 1) / 2, bh = (hh + 1) / 2;
-      dim3 grid ((unsigned) ((bw + 63) / 64), (unsigned) ((bh + 3) / 4), (unsigned) n_frames);
-      hipLaunchKernelGGL (k_vf_point, grid, dim3 (64, 4), 0, s, p);
-    }
-  }
+  // the fast path (hardware transcendentals, folded uniforms, fp16 table) unless VFHIP_VF_EXACT asks for the oracle's operation sequence;
+  // VFHIP_VF_LUT32 keeps the fast path on the fp32 table (A/B of the table alone)
+  if (getenv ("VFHIP_VF_EXACT") == nullptr) {
+    p.f = vf_fold (*prm, w, hh, h->lut_size);
+    p.lut16 = getenv ("VFHIP_VF_LUT32") == nullptr ? h->d_lut16 : nullptr;
+    vf_launch_kernels<true> (p, in, out, w, hh, n_frames, s);
+  } else vf_launch_kernels<false> (p, in, out, w, hh, n_frames, s);
   VFHIP_CHECK_HIP (hipGetLastError ());
   return VFHIP_OK;
 }
@@ -503,10 +749,50 @@ static int vf_upload_lut (VfHipVideoFilter *h, const float *rgba, int size)
   VFHIP_CHECK_HIP (dev_malloc (&d, bytes));
   hipError_t e = upload_in_stream (d, faces.data (), bytes, h->st.s_compute);
   if (e != hipSuccess) { (void) hipFree (d); return set_error (VFHIP_ERR_HIP, "LUT upload failed: %s", hipGetErrorString (e)); }
+  // the fast path's table (lut_sample16): per cell and channel the eight coefficients of the trilinear polynomial of 255 * (entry - lattice
+  // coordinate), fp16, 64-byte cells (the last 16 bytes unused: a cell never straddles an L2 line).  Computed in double.  A table with an entry
+  // fp16 cannot hold (non-finite, or a coefficient beyond its range) gets no such table and the fast path reads the fp32 cells instead.
+  std::vector<uint16_t> half (n * n * n * 32, 0);
+  bool fits = true;
+  auto to_half = [&fits] (double v) -> uint16_t {
+    if (!(fabs (v) <= 65504.0)) { fits = false; return 0; }
+    const _Float16 hv = (_Float16) v;                       // round to nearest even
+    uint16_t bits; memcpy (&bits, &hv, 2);
+    return bits;
+  };
+  for (size_t b = 0; b < n && fits; b++)
+    for (size_t g = 0; g < n; g++)
+      for (size_t r = 0; r < n; r++) {
+        const size_t i1[3] = { r + 1 < n ? r + 1 : r, g + 1 < n ? g + 1 : g, b + 1 < n ? b + 1 : b }, i0[3] = { r, g, b };
+        uint16_t *cell = &half[((b * n + g) * n + r) * 32];
+        for (size_t k = 0; k < 3; k++) {
+          double R[2][2][2];                                  // residual at the corners [dz][dy][dx]
+          for (int dz = 0; dz < 2; dz++)
+            for (int dy = 0; dy < 2; dy++)
+              for (int dx = 0; dx < 2; dx++) {
+                const size_t ix = dx ? i1[0] : i0[0], iy = dy ? i1[1] : i0[1], iz = dz ? i1[2] : i0[2];
+                const size_t lattice[3] = { ix, iy, iz };
+                R[dz][dy][dx] = 255.0 * ((double) rgba[((iz * n + iy) * n + ix) * 4 + k] - (double) lattice[k] / (double) (n - 1));
+              }
+          // (a clamped +1 corner repeats the cell's own lattice point: its residual difference is zero, and so is the weight it gets — f == 0 there)
+          const double k0 = R[0][0][0], kx = R[0][0][1] - k0, ky = R[0][1][0] - k0, kz = R[1][0][0] - k0;
+          const double kxy = R[0][1][1] - R[0][0][1] - R[0][1][0] + k0, kxz = R[1][0][1] - R[0][0][1] - R[1][0][0] + k0, kyz = R[1][1][0] - R[0][1][0] - R[1][0][0] + k0;
+          const double kxyz = R[1][1][1] - R[1][1][0] - R[1][0][1] - R[0][1][1] + R[1][0][0] + R[0][1][0] + R[0][0][1] - k0;
+          const double co[8] = { k0, kx, ky, kxy, kz, kxz, kyz, kxyz };
+          for (int q = 0; q < 8; q++) cell[8 * k + q] = to_half (co[q]);
+        }
+      }
+  uint4 *d16 = nullptr;
+  if (fits) {
+    e = dev_malloc (&d16, half.size () * sizeof (uint16_t));
+    if (e == hipSuccess) e = upload_in_stream (d16, half.data (), half.size () * sizeof (uint16_t), h->st.s_compute);
+    if (e != hipSuccess) { (void) hipFree (d); if (d16) (void) hipFree (d16); return set_error (VFHIP_ERR_HIP, "LUT upload failed: %s", hipGetErrorString (e)); }
+  }
   // swap after the device is idle for this handle's streams: a frame in flight may still read the old table
   (void) hipStreamSynchronize (h->st.s_compute);
   if (h->d_lut) (void) hipFree (h->d_lut);
-  h->d_lut = d; h->lut_size = size;
+  if (h->d_lut16) (void) hipFree (h->d_lut16);
+  h->d_lut = d; h->d_lut16 = d16; h->lut_size = size;
   return VFHIP_OK;
 }
 
@@ -631,7 +917,8 @@ void vfhip_videofilter_clear_lut (VfHipVideoFilter *h)
   (void) hipSetDevice (h->dev->ordinal);
   (void) hipStreamSynchronize (h->st.s_compute);
   if (h->d_lut) (void) hipFree (h->d_lut);
-  h->d_lut = nullptr; h->lut_size = 0;
+  if (h->d_lut16) (void) hipFree (h->d_lut16);
+  h->d_lut = nullptr; h->d_lut16 = nullptr; h->lut_size = 0;
 }
 
 int vfhip_videofilter_lut_size (VfHipVideoFilter *h) { return h ? h->lut_size : 0; }
@@ -653,6 +940,7 @@ void vfhip_videofilter_free (VfHipVideoFilter *h)
   vfhip_videofilter_cleanup (h);
   (void) hipSetDevice (h->dev->ordinal);
   if (h->d_lut) (void) hipFree (h->d_lut);
+  if (h->d_lut16) (void) hipFree (h->d_lut16);
   h->st.destroy ();
   delete h;
 }

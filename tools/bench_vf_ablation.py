@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Ablation of the C3 videofilter cost: which property groups cost what (kernel-only, BGRA 1080p, device-resident)."""
+"""Ablation of the C3 videofilter cost: which property groups cost what (kernel-only, BGRA 1080p, device-resident).
+[case ...] on the command line restricts the run to those cases (PMC passes of one case: tools/gpu_pmc_cmd.sh)."""
 import json
 import math
 import os
@@ -28,7 +29,10 @@ cases = [("identity", {}, False), ("gamma", dict(gamma=1.5), False), ("hue", dic
          ("noise+vignette+key", dict(noise=0.1, vignette=0.3, chroma_key=(0.0, 1.0, 0.0), tolerance=0.3, smoothness=0.1), False),
          ("colour-all", ALL, False), ("lut-only", {}, True), ("colour-all+lut", ALL, True),
          ("sharp-only", dict(sharpness=0.5), False), ("sharp+lut", dict(sharpness=0.5), True), ("all-15+lut", dict(ALL, sharpness=0.5), True)]
+want = sys.argv[1:]
 for name, kw, use_lut in cases:
+    if want and name not in want:
+        continue
     if use_lut:
         vf.set_lut(lut)
     else:
