@@ -20,6 +20,9 @@ anything touches a GPU; under an external launcher WORLD_SIZE must equal --gpus.
 `--workload c5` = BASELINE configs[4] per GPU: `vfhipdeinterlace method=greedyh` (NV12 2160p) -> `vfhipconvertscale`
 (BGRA 1080p), intermediate frames device-resident, both legs batched.
 
+At one GPU the line also carries `others`: BASELINE configs[0], [2], [3] and [4] (C1, C3, C4, the C5 chain) measured right after the headline's
+timed region with the same protocol (bench_configs.py) — frames/s, kernel, ms per launch, algorithmic bytes, fraction of 8 TB/s, ring size.
+
 Prints ONE JSON line on rank 0 (fields: README.md / DESIGN.md §6).
 """
 import argparse
@@ -220,6 +223,7 @@ def main():
     ap.add_argument("--workload", choices=("c2", "c5"), default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ceilings", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="skip the other BASELINE configs (C1, C3, C4, C5) measured after the headline's timed region")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="rank plumbing only (spawn, gloo rendezvous, barrier, max over ranks, aggregation) with a sleep in place of the GPU step; prints a line marked as such, never a measurement")
     args = ap.parse_args()
@@ -379,6 +383,12 @@ def main():
             "clocks": clocks,
             "roofline": roof,
         }
+        if world == 1 and not args.no_others and not c5:
+            # the other BASELINE configs, kernel-only like the headline, AFTER its timed region and with its rings released (bench_configs.py)
+            import bench_configs
+            del ring_in, ring_out
+            torch.cuda.empty_cache()
+            out["others"] = bench_configs.others(torch, vfhip, stream, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)

@@ -24,7 +24,7 @@ using namespace vfhip;
 namespace vfhip {
 
 // The uniforms of the colour stages folded on the host (vf_fold) for the fast path, see color_fast ().
-enum { VF_ON_HUE = 1, VF_ON_GAMMA = 2, VF_ON_B = 4, VF_ON_KEY = 8, VF_ON_KEY_STEP = 16, VF_ON_VIG = 32, VF_ON_NOISE = 64 };
+enum { VF_ON_HUE = 1, VF_ON_GAMMA = 2, VF_ON_B = 4, VF_ON_KEY = 8, VF_ON_KEY_STEP = 16, VF_ON_VIG = 32, VF_ON_NOISE = 64, VF_ON_LUT16 = 128 };
 struct VfFast {
   float a[3][3], ao[3];            // brightness, contrast, saturation: one affine map
   float b[3][3], bo[3];            // sepia mix, invert: one affine map
@@ -219,6 +219,12 @@ __device__ __forceinline__ void lut_sample (const float4 *cells, int N, F4 &c)
 // Issue-rate facts used (tools/ubench/valu_rate3.hip, profiles/r03a_valu_rate3.txt): add / mul / fma with or without the clamp modifier 2 cycles
 // per wave64; min / max / med3 / cndmask / compare / fract / floor / every cvt 3.1; log / exp / rcp / sqrt 6.
 __device__ __forceinline__ float fast_fract (float x) { return __builtin_amdgcn_fractf (x); }
+// A VALU instruction with an SGPR operand issues in 3.9 cycles per wave64 on gfx950, the same instruction on VGPRs (or with an inline / literal constant) in
+// 2.2 (tools/ubench/valu_occ.hip, profiles/r03j_valu_occ.txt: v_add / v_mul / v_fmac / v_fma alike).  The compiler keeps every wave-uniform value — the
+// folded matrices, the blur weights — in SGPRs, so ~60 of a pixel's ~200 instructions and every one of the blur's 54 multiply-adds paid that.  in_vgpr ()
+// hands the value over in a VGPR (one v_mov per lane, hoisted out of the pixel loops); `on`, which only steers branches, stays scalar.
+__device__ __forceinline__ float in_vgpr (float x) { float v; asm ("v_mov_b32 %0, %1" : "=v"(v) : "s"(x)); return v; }
+
 __device__ __forceinline__ F4 color_fast (F4 c, const VfFast &f, float tu, float tv, uint32_t frame)
 {
   // brightness, contrast, saturation (affine), then the clamp every later stage starts with (folds into the last fma)
@@ -285,6 +291,37 @@ __device__ __forceinline__ F4 color_fast (F4 c, const VfFast &f, float tu, float
   return o;
 }
 
+__device__ __forceinline__ VfFast fast_in_vgprs (const VfFast &f)
+{
+  VfFast v = f;                                  // (a disabled stage's uniforms are never read: they stay where they are, no v_mov spent on them)
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) v.a[i][j] = in_vgpr (f.a[i][j]);
+    v.ao[i] = in_vgpr (f.ao[i]);
+  }
+  if (f.on & VF_ON_HUE) v.hue_shift = in_vgpr (f.hue_shift);
+  if (f.on & VF_ON_GAMMA) v.inv_gamma = in_vgpr (f.inv_gamma);
+  if (f.on & VF_ON_B)
+    for (int i = 0; i < 3; i++) {
+      for (int j = 0; j < 3; j++) v.b[i][j] = in_vgpr (f.b[i][j]);
+      v.bo[i] = in_vgpr (f.bo[i]);
+    }
+  if (f.on & VF_ON_KEY) {
+    v.key_r = in_vgpr (f.key_r); v.key_g = in_vgpr (f.key_g); v.key_b = in_vgpr (f.key_b);
+    v.key_e0 = in_vgpr (f.key_e0); v.key_scale = in_vgpr (f.key_scale); v.key_bias = in_vgpr (f.key_bias);
+  }
+  if (f.on & VF_ON_VIG) v.vig = in_vgpr (f.vig);
+  if (f.on & VF_ON_NOISE) { v.noise_gain = in_vgpr (f.noise_gain); v.fw = in_vgpr (f.fw); v.fh = in_vgpr (f.fh); }
+  if (f.on & VF_ON_LUT16) { v.lut_nm1 = in_vgpr (f.lut_nm1); v.lut_n = in_vgpr (f.lut_n); }
+  return v;
+}
+
+template <bool FAST> __device__ __forceinline__ VfParams vf_frame_t (const VfParams &p)
+{
+  VfParams q = vf_frame (p);
+  if (FAST) q.f = fast_in_vgprs (p.f);
+  return q;
+}
+
 // The fast path's LUT: 64-byte cells (one L2 line per pixel; 3 x 16 bytes read), fp16, per channel the eight coefficients of the cell's
 // trilinear polynomial  k0 + fx kx + fy (ky + fx kxy) + fz (kz + fx kxz + fy (kyz + fx kxyz))  of the table's RESIDUAL against the identity
 // (entry - lattice coordinate), times 255: trilinear interpolation reproduces the identity exactly, so  out * 255 = 255 c + poly (f),
@@ -301,9 +338,13 @@ __device__ __forceinline__ void lut_sample16 (const uint4 *cells, float nm1, flo
   const uint4 *cell = cells + (uint32_t) idx * 4u;
   const float in[3] = { c.r, c.g, c.b };
   float o[3];
+  // the three parts of the cell go out together, whatever the register pressure says: the scheduler otherwise serialises them under pressure
+  // (load, wait, use, load ...: three L2 latencies per pixel instead of one — the sharpening kernel ran 1.6x slower that way)
+  const uint4 part[3] = { cell[0], cell[1], cell[2] };
+  __builtin_amdgcn_sched_barrier (0);
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    const uint4 raw = cell[k];
+    const uint4 raw = part[k];
     h8 q;
     __builtin_memcpy (&q, &raw, 16);
     const float A = fmaf (fx, (float) q[1], (float) q[0]), B = fmaf (fx, (float) q[3], (float) q[2]);
@@ -355,14 +396,15 @@ template <bool FAST> __device__ __forceinline__ uint32_t vf_shade_texel (const V
   c.g = (float) ((t >> 8) & 0xff);
   if (rgba) { c.r = (float) (t & 0xff); c.b = (float) ((t >> 16) & 0xff); }
   else { c.b = (float) (t & 0xff); c.r = (float) ((t >> 16) & 0xff); }
-  if (p.f.on & VF_ON_KEY) { c.a = metal::un8 (t >> 24); return vf_shade<true> (p, c, tu, tv); }
-  c.a = 0.0f;
-  return (vf_shade<true> (p, c, tu, tv) & 0x00ffffffu) | (t & 0xff000000u);
+  const bool key = p.f.on & VF_ON_KEY;
+  c.a = key ? metal::un8 (t >> 24) : 0.0f;
+  const uint32_t q = vf_shade<true> (p, c, tu, tv);
+  return key ? q : (q & 0x00ffffffu) | (t & 0xff000000u);
 }
 
 template <bool FAST> __global__ __launch_bounds__ (256) void k_vf_point (const VfParams pp)
 {
-  const VfParams p = vf_frame (pp);
+  const VfParams p = vf_frame_t<FAST> (pp);
   const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
   if (2 * bx >= p.out.w || 2 * by >= p.out.h) return;
   uint32_t q[2][2];
@@ -395,7 +437,8 @@ constexpr int VF_RW = VF_TW + 2 * VF_HALO, VF_RH = VF_TH + 2 * VF_HALO;      // 
 constexpr int VF_RS = VF_RW + 1, VF_HS = VF_TW + 1;                          // odd LDS row strides (dwords)
 constexpr int VF_HRUN = 16, VF_VRUN = 14;
 constexpr int VF_PER = VF_RW * VF_RH / VF_THREADS;                           // region pixels per lane: 17
-static_assert (VF_RH == 64 && VF_THREADS == VF_RH * (VF_TW / VF_HRUN) && VF_THREADS == VF_TW * (VF_TH / VF_VRUN) && VF_PER * VF_THREADS == VF_RW * VF_RH, "tile / lane mapping");
+static_assert (VF_RH == 64 && VF_THREADS == VF_RH * (VF_TW / VF_HRUN) && VF_THREADS == VF_TW * (VF_TH / VF_VRUN) && VF_PER * VF_THREADS == VF_RW * VF_RH &&
+               VF_THREADS == 4 * 128 && VF_RW == 128 + 8 && VF_THREADS == 8 * VF_RH && VF_PER == 17, "tile / lane mapping");
 __constant__ float kBlurW[9] = { 0.028532f, 0.067234f, 0.124009f, 0.179044f, 0.20236f, 0.179044f, 0.124009f, 0.067234f, 0.028532f };
 
 struct F3 { float r, g, b; };
@@ -428,7 +471,7 @@ __device__ __forceinline__ uint32_t quant_rgb8 (float r, float g, float b)
 // load and one 16-byte non-temporal store (k_vf_point moves 8 bytes per access); per pixel exactly vf_pass1's operations.
 template <bool FAST> __global__ __launch_bounds__ (256) void k_vf_point_rgba4 (const VfParams pp)
 {
-  const VfParams p = vf_frame (pp);
+  const VfParams p = vf_frame_t<FAST> (pp);
   const int x4 = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
   if (4 * x4 >= p.out.w || y >= p.out.h) return;                     // out.w is a multiple of 4
   typedef uint32_t v4u __attribute__ ((ext_vector_type (4)));
@@ -453,7 +496,7 @@ template <bool FAST> __global__ __launch_bounds__ (256) void k_vf_point_rgba4 (c
 // its inputs: NV12 -> NV12 1080p 7.5 -> 5.05 us, NV12 -> BGRA 6.9 -> 4.3.
 template <bool FAST> __global__ __launch_bounds__ (256) void k_vf_point_quad (const VfParams pp)
 {
-  const VfParams p = vf_frame (pp);
+  const VfParams p = vf_frame_t<FAST> (pp);
   const int xq = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
   if (4 * xq >= p.out.w || 2 * by >= p.out.h) return;                 // W % 4 == 0, even H
   F4 c[2][4];
@@ -469,16 +512,39 @@ template <bool FAST> __global__ __launch_bounds__ (256) void k_vf_point_quad (co
   metal::store_quad (p.out, xq, by, q);
 }
 
-template <bool FAST> __global__ __launch_bounds__ (VF_THREADS, 2) void k_vf_sharp (const VfParams pp)
+// One workgroup per tile, tiles numbered x fastest, then y, then frame.  (Round 3 also tried PERSISTENT workgroups — two per CU walking the tiles,
+// each loading its next tile's raw texels into registers during the vertical pass — and the kernel without its barriers: both within 1 % of this
+// version, profiles/r03j_sharp_experiments.txt; the time is not in load latency or barrier skew.)
+struct VfTile { int x0, y0; uint32_t frame; };
+__device__ __forceinline__ VfTile vf_tile (int t, int tiles_x, int tiles_y)
 {
-  const VfParams p = vf_frame (pp);
+  const int per = tiles_x * tiles_y, f = t / per, r = t - f * per, ty = r / tiles_x;
+  VfTile o; o.frame = (uint32_t) f; o.y0 = ty * VF_TH; o.x0 = (r - ty * tiles_x) * VF_TW;
+  return o;
+}
+template <bool FAST, bool STAGED> __global__ __launch_bounds__ (VF_THREADS, 4) void k_vf_sharp (const VfParams pp, int tiles_x, int tiles_y)
+{
   __shared__ uint32_t rt[VF_RH * VF_RS];       // pass-1 render target, tile + halo (clamped to the image like the blur's reads)
   __shared__ uint32_t hb[VF_RH * VF_HS];       // horizontal blur (8-bit, like _blurTemp); reused for the result of YUV outputs
-  const int x0 = blockIdx.x * VF_TW, y0 = blockIdx.y * VF_TH;
   const int tid = threadIdx.x;
-  const int w = p.out.w, h = p.out.h;
-  const float inv_w = 1.0f / (float) p.out.w, inv_h = 1.0f / (float) p.out.h;
-  if (p.quad_in) {
+  const int w = pp.out.w, h = pp.out.h;
+  const float inv_w = 1.0f / (float) w, inv_h = 1.0f / (float) h;
+  // STAGED: an RGBA / BGRA input (the launch decides; the two kinds of input are two kernels so that neither carries the other's registers)
+  // staged inputs, lane mapping: the region's first 128 columns as a walk down ONE column (rows tid / 128, + 4, ...: 16 texels; a wave = 64 consecutive
+  // texels of a row), its last 8 columns one texel per lane (64 rows x 8).  So 16 of a lane's 17 pixels share their x: the texture coordinate, the
+  // vignette's cx^2 and the LDS column are loop invariants.
+  const int cx = tid & 127, cy = tid >> 7, ex = 128 + (tid & 7), ey = tid >> 3;
+  const VfTile T = vf_tile ((int) blockIdx.x, tiles_x, tiles_y);
+  const int x0 = T.x0, y0 = T.y0;
+  VfParams p = pp;
+  p.in = metal::img_at (pp.in, T.frame * pp.in_pitch);
+  p.out = metal::out_at (pp.out, T.frame * pp.out_pitch);
+  p.u.frame_index += T.frame;
+  if (FAST) p.f = fast_in_vgprs (pp.f);
+  float bw[9];                                  // the blur weights in VGPRs (in_vgpr: SGPR operands halve the multiply-adds' issue rate); symmetric
+#pragma unroll
+  for (int k = 0; k < 5; k++) bw[k] = bw[8 - k] = in_vgpr (kBlurW[k]);
+  if (!STAGED && p.quad_in) {
     // 4:2:0 input: the region (its corner sits on the 4 x 2 grid) in quads — the chroma neighbourhood of eight pixels as three window loads instead
     // of 32 taps; quads off the frame's edge (the halo of an edge tile) are clamped duplicates and go pixel by pixel
     for (int i = tid; i < (VF_RW / 4) * (VF_RH / 2); i += VF_THREADS) {
@@ -499,32 +565,31 @@ template <bool FAST> __global__ __launch_bounds__ (VF_THREADS, 2) void k_vf_shar
         for (int k = 0; k < 8; k++) d[(k >> 2) * VF_RS + (k & 3)] = vf_pass1<FAST> (p, gx + (k & 3), gy + (k >> 2));
       }
     }
-  } else if (p.in.fmt == VFHIP_FORMAT_RGBA || p.in.fmt == VFHIP_FORMAT_BGRA) {
-    // step 0: raw texels -> LDS, every load of the lane issued before the first is used (consecutive lanes = consecutive pixels of a region row)
+  } else if (STAGED) {
+    // step 0: the tile's raw texels -> LDS, every load of the lane issued before the first is used
     {
       uint32_t raw[VF_PER];
+      const int gx = metal::iclamp (x0 - VF_HALO + cx, 0, w - 1);
 #pragma unroll
-      for (int k = 0; k < VF_PER; k++) {
-        const int i = tid + k * VF_THREADS, rx = i % VF_RW, ry = i / VF_RW;
-        const int gx = metal::iclamp (x0 - VF_HALO + rx, 0, w - 1), gy = metal::iclamp (y0 - VF_HALO + ry, 0, h - 1);
-        raw[k] = *reinterpret_cast<const uint32_t *> (p.in.p[0] + (size_t) gy * p.in.s[0] + 4 * (size_t) gx);
-      }
+      for (int k = 0; k < VF_PER - 1; k++)
+        raw[k] = *reinterpret_cast<const uint32_t *> (p.in.p[0] + (size_t) metal::iclamp (y0 - VF_HALO + cy + 4 * k, 0, h - 1) * p.in.s[0] + 4 * (size_t) gx);
+      raw[VF_PER - 1] = *reinterpret_cast<const uint32_t *> (p.in.p[0] + (size_t) metal::iclamp (y0 - VF_HALO + ey, 0, h - 1) * p.in.s[0] + 4 * (size_t) metal::iclamp (x0 - VF_HALO + ex, 0, w - 1));
 #pragma unroll
-      for (int k = 0; k < VF_PER; k++) { const int i = tid + k * VF_THREADS; rt[(i / VF_RW) * VF_RS + i % VF_RW] = raw[k]; }
+      for (int k = 0; k < VF_PER - 1; k++) rt[(cy + 4 * k) * VF_RS + cx] = raw[k];
+      rt[ey * VF_RS + ex] = raw[VF_PER - 1];
     }
-    // step 1: pass 1 in place, each lane on the texels it staged itself (no barrier needed in between); (rx, ry) advance incrementally
+    // step 1: pass 1 in place, each lane on the texels it staged itself (no barrier needed in between)
     const bool rgba_in = p.in.fmt == VFHIP_FORMAT_RGBA;
-    int rx = tid % VF_RW, ry = tid / VF_RW;
-#ifndef VF_P1_UNROLL
-#define VF_P1_UNROLL 2
-#endif
-#pragma unroll VF_P1_UNROLL
+    const float wm1 = in_vgpr ((float) (w - 1)), hm1 = in_vgpr ((float) (h - 1)), inv_wv = in_vgpr (inv_w), inv_hv = in_vgpr (inv_h);
+    uint32_t *d = rt + cy * VF_RS + cx;
+    float fx = (float) (x0 - VF_HALO + cx), fy = (float) (y0 - VF_HALO + cy);
+#pragma unroll 1
     for (int k = 0; k < VF_PER; k++) {
-      uint32_t *d = rt + ry * VF_RS + rx;
-      const int gx = metal::iclamp (x0 - VF_HALO + rx, 0, w - 1), gy = metal::iclamp (y0 - VF_HALO + ry, 0, h - 1);
-      *d = vf_shade_texel<FAST> (p, *d, rgba_in, ((float) gx + 0.5f) * inv_w, ((float) gy + 0.5f) * inv_h);
-      rx += VF_THREADS % VF_RW; ry += VF_THREADS / VF_RW;
-      if (rx >= VF_RW) { rx -= VF_RW; ry++; }
+      if (k == VF_PER - 1) { d = rt + ey * VF_RS + ex; fx = (float) (x0 - VF_HALO + ex); fy = (float) (y0 - VF_HALO + ey); }
+      // (the oracle's texture coordinate, operation for operation: the noise hash amplifies an ulp of it a thousandfold)
+      const float tu = (__builtin_amdgcn_fmed3f (fx, 0.0f, wm1) + 0.5f) * inv_wv, tv = (__builtin_amdgcn_fmed3f (fy, 0.0f, hm1) + 0.5f) * inv_hv;
+      *d = vf_shade_texel<FAST> (p, *d, rgba_in, tu, tv);
+      d += 4 * VF_RS; fy += 4.0f;
     }
   } else
   for (int i = tid; i < VF_RW * VF_RH; i += VF_THREADS) {
@@ -544,15 +609,15 @@ template <bool FAST> __global__ __launch_bounds__ (VF_THREADS, 2) void k_vf_shar
     for (int j = 0; j < VF_HRUN; j++) {
       float sr = 0.0f, sg = 0.0f, sb = 0.0f;
 #pragma unroll
-      for (int k = 0; k < 9; k++) { sr = fmaf (px[j + k].r, kBlurW[k], sr); sg = fmaf (px[j + k].g, kBlurW[k], sg); sb = fmaf (px[j + k].b, kBlurW[k], sb); }
+      for (int k = 0; k < 9; k++) { sr = fmaf (px[j + k].r, bw[k], sr); sg = fmaf (px[j + k].g, bw[k], sg); sb = fmaf (px[j + k].b, bw[k], sb); }
       hb[row * VF_HS + c0 + j] = quant_rgb<FAST> (sr, sg, sb);
     }
   }
   __syncthreads ();
   const float amount = p.u.sharpness;
   const int col = tid & (VF_TW - 1), r0 = (tid >> 7) * VF_VRUN;
-  uint32_t res[VF_VRUN];
-  {
+  // the vertical pass + unsharp mask of this lane's column run; emit (j, rgba8) takes each result as it is finished
+  auto vertical = [&] (auto &&emit) {
     const uint32_t *src = hb + r0 * VF_HS + col;
     F3 px[VF_VRUN + 8];
 #pragma unroll
@@ -561,7 +626,7 @@ template <bool FAST> __global__ __launch_bounds__ (VF_THREADS, 2) void k_vf_shar
     for (int j = 0; j < VF_VRUN; j++) {
       float sr = 0.0f, sg = 0.0f, sb = 0.0f;
 #pragma unroll
-      for (int k = 0; k < 9; k++) { sr = fmaf (px[j + k].r, kBlurW[k], sr); sg = fmaf (px[j + k].g, kBlurW[k], sg); sb = fmaf (px[j + k].b, kBlurW[k], sb); }
+      for (int k = 0; k < 9; k++) { sr = fmaf (px[j + k].r, bw[k], sr); sg = fmaf (px[j + k].g, bw[k], sg); sb = fmaf (px[j + k].b, bw[k], sb); }
       // _blurResult is 8-bit as well.  The unsharp mask itself stays in the oracle's normalised arithmetic in both paths: with both operands 8-bit
       // values and amount = .5 every other result is an exact tie in byte units, and the tie must fall the way value / 255 arithmetic makes it fall
       // (the byte-domain version of this step differed from the oracle in 10 % of the bytes, all of them such ties)
@@ -578,42 +643,37 @@ template <bool FAST> __global__ __launch_bounds__ (VF_THREADS, 2) void k_vf_shar
         const float t = fabsf (amount);
         rr = mixf (o.r, b.r, t); rg = mixf (o.g, b.g, t); rb = mixf (o.b, b.b, t);
       }
-      res[j] = quant_rgb8 (rr, rg, rb) | (oq & 0xff000000u);            // alpha: the pass-1 value, untouched
+      emit (j, quant_rgb8 (rr, rg, rb) | (oq & 0xff000000u));           // alpha: the pass-1 value, untouched
     }
-  }
+  };
   if (p.out.fmt == VFHIP_FORMAT_BGRA || p.out.fmt == VFHIP_FORMAT_RGBA) {
-    // RGB outputs: a wave's 64 lanes are 64 consecutive pixels of one row -> 256-byte coalesced dword stores, straight from registers
+    // RGB outputs: a wave's 64 lanes are 64 consecutive pixels of one row -> 256-byte coalesced dword stores, each as soon as its value exists
     const int gx = x0 + col;
-    if (gx < w) {
+    const bool bgra = p.out.fmt == VFHIP_FORMAT_BGRA;
+    uint8_t *o0 = p.out.p[0] + (size_t) (y0 + r0) * p.out.s[0] + 4 * (size_t) gx;
+    vertical ([&] (int j, uint32_t v) {
+      if (gx < w && y0 + r0 + j < h)
+        __builtin_nontemporal_store (bgra ? __builtin_amdgcn_perm (0u, v, 0x03000102u) : v, reinterpret_cast<uint32_t *> (o0 + (size_t) j * p.out.s[0]));
+    });
+  } else {
+    // the unsharp result (8-bit) goes to the tile's own rows of rt: each lane overwrites exactly the pass-1 texels it has just read (oq), nobody else's
+    vertical ([&] (int j, uint32_t v) { rt[(r0 + j + VF_HALO) * VF_RS + col + VF_HALO] = v; });
+    __syncthreads ();
+    // store epilogue: 2x2 blocks of the tile
+    for (int i = tid; i < (VF_TW / 2) * (VF_TH / 2); i += VF_THREADS) {
+      const int lbx = i % (VF_TW / 2), lby = i / (VF_TW / 2);
+      const int gx = x0 + 2 * lbx, gy = y0 + 2 * lby;
+      if (gx >= w || gy >= h) continue;
+      uint32_t q[2][2];
 #pragma unroll
-      for (int j = 0; j < VF_VRUN; j++) {
-        const int gy = y0 + r0 + j;
-        if (gy >= h) break;
-        uint32_t v = res[j];
-        if (p.out.fmt == VFHIP_FORMAT_BGRA) v = __builtin_amdgcn_perm (0u, v, 0x03000102u);
-        __builtin_nontemporal_store (v, reinterpret_cast<uint32_t *> (p.out.p[0] + (size_t) gy * p.out.s[0]) + gx);
-      }
+      for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+        for (int dx = 0; dx < 2; dx++) {
+          const int lx = min (gx + dx, w - 1) - x0, ly = min (gy + dy, h - 1) - y0;      // edge-clamped duplicates
+          q[dy][dx] = rt[(ly + VF_HALO) * VF_RS + lx + VF_HALO];
+        }
+      metal::store_block (p.out, gx / 2, gy / 2, q);
     }
-    return;
-  }
-  __syncthreads ();                                                      // every lane is done reading hb
-#pragma unroll
-  for (int j = 0; j < VF_VRUN; j++) hb[(r0 + j) * VF_HS + col] = res[j];   // unsharp result (8-bit), tile rows only
-  __syncthreads ();
-  // store epilogue: 2x2 blocks of the tile
-  for (int i = tid; i < (VF_TW / 2) * (VF_TH / 2); i += VF_THREADS) {
-    const int lbx = i % (VF_TW / 2), lby = i / (VF_TW / 2);
-    const int gx = x0 + 2 * lbx, gy = y0 + 2 * lby;
-    if (gx >= w || gy >= h) continue;
-    uint32_t q[2][2];
-#pragma unroll
-    for (int dy = 0; dy < 2; dy++)
-#pragma unroll
-      for (int dx = 0; dx < 2; dx++) {
-        const int lx = min (gx + dx, w - 1) - x0, ly = min (gy + dy, h - 1) - y0;      // edge-clamped duplicates
-        q[dy][dx] = hb[ly * VF_HS + lx];
-      }
-    metal::store_block (p.out, gx / 2, gy / 2, q);
   }
 }
 
@@ -674,8 +734,11 @@ template <bool FAST> static void vf_launch_kernels (VfParams p, const VfHipFrame
   auto bytes_in = [&p] () { for (auto &row : p.f.a) for (float &v : row) v = (float) ((double) v / 255.0); };
   if (prm->sharpness < -0.001f || prm->sharpness > 0.001f) {
     if (FAST && rgb_in && !p.quad_in) bytes_in ();
-    dim3 grid ((unsigned) ((w + VF_TW - 1) / VF_TW), (unsigned) ((hh + VF_TH - 1) / VF_TH), (unsigned) n_frames);
-    hipLaunchKernelGGL (k_vf_sharp<FAST>, grid, dim3 (VF_THREADS), 0, s, p);
+    const int tiles_x = (w + VF_TW - 1) / VF_TW, tiles_y = (hh + VF_TH - 1) / VF_TH;
+    const long long n_tiles = (long long) tiles_x * tiles_y * n_frames;           // (< 2^31: 65535 frames of at most 256 x 586 tiles)
+    const dim3 grid ((unsigned) n_tiles);
+    if (rgb_in && !p.quad_in) hipLaunchKernelGGL ((k_vf_sharp<FAST, true>), grid, dim3 (VF_THREADS), 0, s, p, tiles_x, tiles_y);
+    else hipLaunchKernelGGL ((k_vf_sharp<FAST, false>), grid, dim3 (VF_THREADS), 0, s, p, tiles_x, tiles_y);
   } else {
     const bool rgb_io = rgb_in && (out->info.format == VFHIP_FORMAT_RGBA || out->info.format == VFHIP_FORMAT_BGRA);
     const uintptr_t al = (uintptr_t) in->data[0] | (uintptr_t) in->stride[0] | (uintptr_t) p.in_pitch | (uintptr_t) out->data[0] | (uintptr_t) out->stride[0] | (uintptr_t) p.out_pitch;
@@ -708,6 +771,7 @@ static int vf_launch (VfHipVideoFilter *h, const VfHipFrame *in, VfHipFrame *out
   if (getenv ("VFHIP_VF_EXACT") == nullptr) {
     p.f = vf_fold (*prm, w, hh, h->lut_size);
     p.lut16 = getenv ("VFHIP_VF_LUT32") == nullptr ? h->d_lut16 : nullptr;
+    if (p.lut16) p.f.on |= VF_ON_LUT16;
     vf_launch_kernels<true> (p, in, out, w, hh, n_frames, s);
   } else vf_launch_kernels<false> (p, in, out, w, hh, n_frames, s);
   VFHIP_CHECK_HIP (hipGetLastError ());
