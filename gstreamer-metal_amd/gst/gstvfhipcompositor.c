@@ -15,7 +15,12 @@
  * again, buffers that end before the output frame are dropped, a pad that reached EOS disappears once its last buffer
  * has run out (or stays with repeat-after-eos), EOS goes downstream when every pad is done.  Pads of different frame
  * rates therefore composite like in the reference.  Obscured-pad culling (gstvfmetalcompositorpad.m:180-255), pointer
- * navigation (:706-787), async-depth and memory:HIPMemory are part of the same code. */
+ * navigation (:706-787), async-depth and memory:HIPMemory are part of the same code.
+ *
+ * NOT carried over from GstVideoAggregator (the reference inherits them from its base class, this element has no such base class on 1.14):
+ * QoS-driven frame dropping (the QOS events of a late sink are accepted and ignored: every output frame is composited), the pad property
+ * max-last-buffer-repeat (a pad's last buffer is held for its own duration, or for ever with repeat-after-eos), and the GstVideoAggregatorPad
+ * C API on the request pads — an application that casts them to GstVideoAggregatorPad, rather than setting properties by name, does not drop in. */
 #ifdef HAVE_CONFIG_H
 #include "config.h"
 #endif

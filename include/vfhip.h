@@ -237,7 +237,7 @@ int vfhip_videofilter_process_device_batch (VfHipVideoFilter *h, const VfHipFram
 int vfhip_videofilter_submit (VfHipVideoFilter *h, const VfHipFrame *in, VfHipFrame *out, const VfHipVideoFilterParams *params);
 int vfhip_videofilter_wait (VfHipVideoFilter *h);
 int vfhip_videofilter_in_flight (VfHipVideoFilter *h);
-int vfhip_videofilter_load_lut (VfHipVideoFilter *h, const char *path);                       /* -loadLUTFromFile: (.cube only) */
+int vfhip_videofilter_load_lut (VfHipVideoFilter *h, const char *path);                       /* -loadLUTFromFile: (.cube, or a .png of size^2 x size slices) */
 int vfhip_videofilter_set_lut (VfHipVideoFilter *h, const float *rgba, int size);             /* size^3 RGBA32F, R fastest */
 void vfhip_videofilter_clear_lut (VfHipVideoFilter *h);
 int vfhip_videofilter_lut_size (VfHipVideoFilter *h);

@@ -125,10 +125,17 @@ int gst114_packed422_to_rgb (const uint8_t *in, int is, int yuy2, int w, int h, 
   if (w <= 0 || h <= 0 || matrix < 0 || matrix > 2) return -1;
   const int cw = (w + 1) / 2, yo = yuy2 ? 0 : 1, uo = yuy2 ? 1 : 0, vo = yuy2 ? 3 : 2;
   const int ro = out_format == GST114_RGBA ? 0 : 2, bo = 2 - ro;
+  int oom = 0;                                          /* a failed per-row scratch allocation: the row is skipped, the call fails (-2), nothing is dereferenced */
 #pragma omp parallel for schedule(static)
   for (int y = 0; y < h; y++) {
     const uint8_t *row = in + (size_t) y * is;
     uint8_t *hu = malloc ((size_t) w), *hv = malloc ((size_t) w);
+    if (!hu || !hv) {
+      free (hu); free (hv);
+#pragma omp atomic write
+      oom = 1;
+      continue;
+    }
     upsample_h (row + uo, 4, cw, w, cosited, hu);
     upsample_h (row + vo, 4, cw, w, cosited, hv);
     uint8_t *o = out + (size_t) y * os;
@@ -139,7 +146,7 @@ int gst114_packed422_to_rgb (const uint8_t *in, int is, int yuy2, int w, int h, 
     }
     free (hu); free (hv);
   }
-  return 0;
+  return oom ? -2 : 0;
 }
 
 int gst114_convertscale_packed422 (const uint8_t *in, int is, int yuy2, int w, int h, int matrix, int cosited, int out_format, int method,
@@ -668,10 +675,18 @@ int gst114_rgb_to_packed422 (const uint8_t *in, int is, int in_format, int w, in
   if (w <= 0 || h <= 0 || matrix < 0 || matrix > 2) return -1;
   const int *c = RGB2YUV[matrix];
   const int ro = in_format == GST114_RGBA ? 0 : 2, bo = 2 - ro, cw = (w + 1) / 2;
+  int oom = 0;
 #pragma omp parallel for schedule(static)
   for (int y = 0; y < h; y++) {
     uint8_t *Y = malloc ((size_t) w);
-    int *u = malloc (sizeof (int) * (size_t) (2 * w + 2 * cw)), *v = u + w, *du = v + w, *dv = du + cw;
+    int *u = malloc (sizeof (int) * (size_t) (2 * w + 2 * cw));
+    if (!Y || !u) {
+      free (Y); free (u);
+#pragma omp atomic write
+      oom = 1;
+      continue;
+    }
+    int *v = u + w, *du = v + w, *dv = du + cw;
     for (int x = 0; x < w; x++) {
       const uint8_t *px = in + (size_t) y * is + 4 * x;
       const int r = px[ro], g = px[1], b = px[bo];
@@ -683,7 +698,7 @@ int gst114_rgb_to_packed422 (const uint8_t *in, int is, int in_format, int w, in
     pk_store_row (out + (size_t) y * os, yuy2, w, Y, du, dv);
     free (Y); free (u);
   }
-  return 0;
+  return oom ? -2 : 0;
 }
 
 int gst114_yuv420_to_packed422 (const uint8_t *yp, int ys, const uint8_t *up, int us, const uint8_t *vp, int vs,
@@ -700,10 +715,17 @@ int gst114_yuv420_to_packed422 (const uint8_t *yp, int ys, const uint8_t *up, in
       upsample_h (up + (size_t) j * us + 1, 2, cw, w, cosited_in, hv + (size_t) j * w);
     }
   }
+  int oom = 0;
 #pragma omp parallel for schedule(static)
   for (int y = 0; y < h; y++) {
     const int j = y >> 1;
-    int *u = malloc (sizeof (int) * (size_t) (2 * w + 2 * cw)), *v = u + w, *du = v + w, *dv = du + cw;
+    int *u = malloc (sizeof (int) * (size_t) (2 * w + 2 * cw));
+    if (!u) {
+#pragma omp atomic write
+      oom = 1;
+      continue;
+    }
+    int *v = u + w, *du = v + w, *dv = du + cw;
     if (planar) {
       for (int k = 0; k < cw; k++) { du[k] = up[(size_t) j * us + k]; dv[k] = vp[(size_t) j * vs + k]; }
     } else {
@@ -718,7 +740,7 @@ int gst114_yuv420_to_packed422 (const uint8_t *yp, int ys, const uint8_t *up, in
     free (u);
   }
   free (hu); free (hv);
-  return 0;
+  return oom ? -2 : 0;
 }
 
 int gst114_packed422_swizzle (const uint8_t *in, int is, int in_yuy2, int w, int h, int out_yuy2, uint8_t *out, int os)
@@ -742,6 +764,7 @@ int gst114_packed422_to_yuv420 (const uint8_t *in, int is, int yuy2, int w, int 
   const int cw = (w + 1) / 2, ch = (h + 1) / 2;
   for (int y = 0; y < h; y++)
     for (int x = 0; x < w; x++) yp[(size_t) y * ys + x] = in[(size_t) y * is + 2 * x + yo];
+  int oom = 0;
 #pragma omp parallel for schedule(static)
   for (int j = 0; j < ch; j++) {
     const uint8_t *r0 = in + (size_t) (2 * j) * is, *r1 = in + (size_t) (2 * j + 1 < h ? 2 * j + 1 : h - 1) * is;
@@ -751,8 +774,16 @@ int gst114_packed422_to_yuv420 (const uint8_t *in, int is, int yuy2, int w, int 
         vp[(size_t) j * vs + k] = (uint8_t) ((r0[4 * k + vo] + r1[4 * k + vo] + 1) >> 1);
       }
     } else {
-      uint8_t *a = malloc ((size_t) 4 * w), *b = a + w, *c = b + w, *d = c + w;
-      int *u = malloc (sizeof (int) * (size_t) (2 * w + 2 * cw)), *v = u + w, *du = v + w, *dv = du + cw;
+      uint8_t *a = malloc ((size_t) 4 * w);
+      int *u = malloc (sizeof (int) * (size_t) (2 * w + 2 * cw));
+      if (!a || !u) {
+        free (a); free (u);
+#pragma omp atomic write
+      oom = 1;
+      continue;
+    }
+      uint8_t *b = a + w, *c = b + w, *d = c + w;
+      int *v = u + w, *du = v + w, *dv = du + cw;
       upsample_h (r0 + uo, 4, cw, w, cosited_in, a); upsample_h (r1 + uo, 4, cw, w, cosited_in, b);
       upsample_h (r0 + vo, 4, cw, w, cosited_in, c); upsample_h (r1 + vo, 4, cw, w, cosited_in, d);
       for (int x = 0; x < w; x++) { u[x] = (a[x] + b[x] + 1) >> 1; v[x] = (c[x] + d[x] + 1) >> 1; }
@@ -761,7 +792,7 @@ int gst114_packed422_to_yuv420 (const uint8_t *in, int is, int yuy2, int w, int 
       free (a); free (u);
     }
   }
-  return 0;
+  return oom ? -2 : 0;
 }
 
 /* videoscale method=bilinear on a packed 4:2:2 frame */

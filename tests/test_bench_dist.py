@@ -73,6 +73,22 @@ def test_bench_py_starts_its_own_ranks():
     assert d["ms_per_step"] >= 4.0 - 0.5                          # the slow rank (4 ms per step) sets the time
 
 
+def test_bench_py_eight_ranks_selftest():
+    """the real world size of the node the driver scales to: `python bench.py --gpus 8 --selftest-cpu` spawns 8 ranks on 127.0.0.1, they rendezvous on
+    gloo, pass the barriers, the device list is gathered from all eight in rank order, the step count is the MAX over ranks (8: rank 7's value) and
+    the slowest rank (16 ms per step) sets the reported time.  No GPU, not a measurement: it shows the N = 8 path cannot hang or mis-aggregate."""
+    import json
+    r = _run_bench(["--gpus", "8", "--steps", "4", "--warmup", "1", "--selftest-cpu"], timeout=420)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                               # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["value"] is None and d["scaling"] == "weak"
+    assert [x["rank"] for x in d["config"]["devices"]] == list(range(8)) and [x["ordinal"] for x in d["config"]["devices"]] == list(range(8))
+    assert d["config"]["launches_per_step"] == 8
+    assert d["ms_per_step"] >= 16.0 - 1.0
+
+
 def test_bench_py_refuses_a_world_size_mismatch():
     r = _run_bench(["--gpus", "4", "--selftest-cpu"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29745"})
     assert r.returncode != 0 and "must agree" in (r.stdout + r.stderr)

@@ -84,7 +84,15 @@ for case in range(N):
         got2 = cs2.process(raw); cs2.close()
         want2 = (oracle_lib.convertscale_with_borders(orc, ifmt, w, h, raw, col, site, method, ofmt, ow, oh, 0xC0123456) if borders
                  else orc.convertscale(ifmt, w, h, raw, col, site, method, ofmt, ow, oh))
-        print("MISMATCH", ifmt, (w, h), "->", ofmt, (ow, oh), method, col, site, k, d, "bytes", "borders" if borders else "",
+        # the whole record goes to a file: a one-off must be diagnosable from what this run saw, without trying to make it happen again
+        dump_dir = os.path.join(ROOT, "gpurun_out", "fuzz_dumps")
+        os.makedirs(dump_dir, exist_ok=True)
+        dump = os.path.join(dump_dir, f"gst_seed{sys.argv[2] if len(sys.argv) > 2 else 1}_case{case}.npz")
+        np.savez_compressed(dump, raw=raw, got=np.asarray(got).reshape(-1), want=np.asarray(want).reshape(-1), got2=np.asarray(got2).reshape(-1),
+                            want2=np.asarray(want2).reshape(-1),
+                            params=np.array([ifmt, str(w), str(h), ofmt, str(ow), str(oh), method, col, site, k, str(bool(borders)),
+                                             os.environ.get("VFHIP_DEBUG_POISON", ""), os.environ.get("VFHIP_ORACLE_THREADS", "1")]))
+        print("MISMATCH", ifmt, (w, h), "->", ofmt, (ow, oh), method, col, site, k, d, "bytes", "borders" if borders else "", "| record:", dump,
               "| library repeats itself:", bool(np.array_equal(np.asarray(got).reshape(-1), np.asarray(got2).reshape(-1))),
               "| oracle repeats itself:", bool(np.array_equal(np.asarray(want).reshape(-1), np.asarray(want2).reshape(-1))),
               "| second run equal:", bool(np.array_equal(np.asarray(got2).reshape(-1), np.asarray(want2).reshape(-1))), flush=True)

@@ -22,12 +22,18 @@ def frame(fmt, w, h):
     return rng.integers(0, 256, ol.raw_layout(fmt, w, h)[1], dtype=np.uint8)
 
 
-def check(what, got, want):
+def check(what, got, want, tol=1, rare=None, **record):
+    """tol: the largest byte difference allowed; rare: the share of bytes that may exceed +-1 when tol > 1.  A mismatch is written out whole
+    (inputs, both outputs) so that a one-off can be diagnosed from the record instead of being chased"""
     global bad
     d = np.abs(np.asarray(got).astype(int).reshape(-1) - np.asarray(want).astype(int).reshape(-1))
-    if d.max() > 1:
+    if d.max() > tol or (rare is not None and (d > 1).mean() > rare):
         bad += 1
-        print("MISMATCH", what, "max", int(d.max()), "count", int((d > 1).sum()), flush=True)
+        dump_dir = os.path.join(ROOT, "gpurun_out", "fuzz_dumps")
+        os.makedirs(dump_dir, exist_ok=True)
+        dump = os.path.join(dump_dir, f"metal_seed{sys.argv[2] if len(sys.argv) > 2 else 1}_case{case}.npz")
+        np.savez_compressed(dump, got=np.asarray(got).reshape(-1), want=np.asarray(want).reshape(-1), what=np.array([what]), **record)
+        print("MISMATCH", what, "max", int(d.max()), "count", int((d > 1).sum()), "| record:", dump, flush=True)
 
 
 ONLY = int(sys.argv[3]) if len(sys.argv) > 3 else -1                # restrict to one element (3 = compositor)
@@ -75,7 +81,10 @@ for case in range(N):
         vf = vfhip.VideoFilter(0)
         vf.configure(ifmt, w, h, ofmt, colorimetry=col)
         prm = vfhip.filter_params(**kw)
-        check(f"videofilter {ifmt}->{ofmt}{(w, h)} {sorted(kw)}", vf.process(raw, prm), mr.videofilter(ifmt, w, h, raw, ofmt, ol.mr_filter_params(prm), m709=m709))
+        # sharpened frames: an off-by-one byte of pass 1 (legitimate) leaves the unsharp mask times 1 + 2 |amount| (tests/test_metal_elements_gpu.py, vf_parity)
+        amount = abs(kw.get("sharpness", 0.0))
+        check(f"videofilter {ifmt}->{ofmt}{(w, h)} {sorted(kw.items())}", vf.process(raw, prm), mr.videofilter(ifmt, w, h, raw, ofmt, ol.mr_filter_params(prm), m709=m709),
+              tol=1 + int(np.ceil(2 * amount)) if amount > 0.001 else 1, rare=0.004 if amount > 0.001 else None, raw=raw)
         vf.close()
     elif kind == 3:
         ofmt = F4[rng.integers(4)]
