@@ -944,7 +944,11 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
       const uintptr_t a = (uintptr_t) t.cs.in[0] | (uintptr_t) t.cs.in[1] | (uintptr_t) t.cs.is[0] | (uintptr_t) t.cs.is[1] | (uintptr_t) in_pitch;
       t.fast_nv12 = h->in.format == VFHIP_FORMAT_NV12 && !(a & 7) && h->in.width >= 16 && getenv ("VFHIP_CUBIC_SCALAR") == nullptr;
     }
-    dim3 grid ((unsigned) ((t.ow + CT_TW - 1) / CT_TW), (unsigned) ((t.oh + CT_TH - 1) / CT_TH), (unsigned) n_frames);
+    t.tiles_x = (t.ow + CT_TW - 1) / CT_TW; t.tiles_y = (t.oh + CT_TH - 1) / CT_TH;
+    const long long nt = (long long) t.tiles_x * t.tiles_y * n_frames;
+    if (nt > 0x7fffff00ll) return set_error (VFHIP_ERR_INVALID, "bicubic: too many tiles in one batch");
+    t.n_tiles = (int) nt; t.n_chunk = (t.n_tiles + 7) / 8;
+    dim3 grid ((unsigned) (8 * t.n_chunk));
     // 512 lanes share one tile's 48 KB of LDS: 3 workgroups = 24 waves per CU (256 lanes: 12 waves, latency-bound)
     // (measured on C2 bicubic: 256 lanes 25.2 k frames/s, 512 lanes 28.6 k, 1024 lanes 19.6 k)
     // a source format without alpha converts to A = 255 everywhere: the tile kernel then filters three channels (ntap_accf)
@@ -1033,7 +1037,12 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
       if ((size_t) grid.x * ((p.out_h + rows - 1) / rows) * n_frames < (size_t) h->strip_fill * 4 * h->dev->n_cu) rows = 1;      // the launch must still give that many waves per SIMD
     }
     if (rows > 1) {
-      dim3 sg (grid.x, (unsigned) (((p.out_h + rows - 1) / rows + 3) / 4), (unsigned) n_frames);
+      // 1-D launch in XCD-aware block order (cs_xcd_block)
+      p.xg_x = (int) grid.x; p.xg_y = ((p.out_h + rows - 1) / rows + 3) / 4;
+      const long long nb = (long long) p.xg_x * p.xg_y * n_frames;
+      if (nb > 0x7fffff00ll) return set_error (VFHIP_ERR_INVALID, "convertscale: too many blocks in one batch");
+      p.xg_n = (int) nb; p.xg_chunk = (p.xg_n + 7) / 8;
+      dim3 sg ((unsigned) (8 * p.xg_chunk));
       const bool i420 = p.in_fmt == VFHIP_FORMAT_I420;
 #define VF_STRIP(I, C, V) hipLaunchKernelGGL ((k_cs_taps_strip<I, C, V, 4>), sg, dim3 (64, 4), 0, s, p)
       if (i420) { if (p.vfirst) VF_STRIP (true, false, true); else VF_STRIP (true, false, false); }

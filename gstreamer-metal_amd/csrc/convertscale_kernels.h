@@ -44,7 +44,23 @@ struct CsParams {
   const int *htab;                  // nearest: rw source columns
   uint32_t border;                  // border colour in output byte order
   int half_rows;                    // k_cs_nv12_half: output rows per lane (strip height)
+  int xg_x, xg_y, xg_n, xg_chunk;   // XCD-aware 1-D launches (cs_xcd_block): blocks per row / column of a frame, blocks in all, blocks per XCD
 };
+
+// XCD-aware block order for kernels whose neighbouring blocks share source lines (k_cs_taps_strip: a block's 64 columns x 16 rows lean on 1.5 luma
+// lines per row that its neighbours touch too).  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one and its L2), so a 1-D
+// launch of 8 * chunk blocks gives block b the work item (b % 8) * chunk + b / 8 — each XCD ONE contiguous run (x fastest, then y, then frame) —
+// and shared lines are fetched into one L2.  Returns false for the surplus blocks of the rounded-up grid.  Speed only: any mapping gives the same bytes.
+__device__ __forceinline__ bool cs_xcd_block (const CsParams &p, int &bx, int &by, int &bz)
+{
+  const int bt = (int) (blockIdx.x & 7u) * p.xg_chunk + (int) (blockIdx.x >> 3);
+  if (bt >= p.xg_n) return false;
+  const int per = p.xg_x * p.xg_y;
+  bz = bt / per;
+  const int r = bt - bz * per;
+  by = r / p.xg_x; bx = r - by * p.xg_x;
+  return true;
+}
 
 // ------------------------------------------------------------------------------------------------
 // packed-byte helpers
@@ -498,14 +514,16 @@ struct TapRow { uint2 a, b, c; uint32_t yw[2]; };      // NV12: chroma windows o
 template <bool I420, bool COSITED, bool VFIRST, int ROWS>
 __global__ __launch_bounds__ (256) void k_cs_taps_strip (const CsParams p)
 {
-  const int x = blockIdx.x * 64 + threadIdx.x;
-  const int strip = __builtin_amdgcn_readfirstlane ((int) (blockIdx.y * 4 + threadIdx.y));
+  int bx, by, bz;
+  if (!cs_xcd_block (p, bx, by, bz)) return;
+  const int x = bx * 64 + threadIdx.x;
+  const int strip = __builtin_amdgcn_readfirstlane ((int) (by * 4 + threadIdx.y));
   const int y0 = strip * ROWS, yend = min (y0 + ROWS, p.out_h);
   if (x >= p.out_w || y0 >= p.out_h) return;
-  const uint8_t *yp = p.in[0] + (size_t) blockIdx.z * p.in_pitch;
-  const uint8_t *up = p.in[1] + (size_t) blockIdx.z * p.in_pitch;
-  const uint8_t *vp = I420 ? p.in[2] + (size_t) blockIdx.z * p.in_pitch : nullptr;
-  uint8_t *op = p.out + (size_t) blockIdx.z * p.out_pitch + 4 * (size_t) x;
+  const uint8_t *yp = p.in[0] + (size_t) bz * p.in_pitch;
+  const uint8_t *up = p.in[1] + (size_t) bz * p.in_pitch;
+  const uint8_t *vp = I420 ? p.in[2] + (size_t) bz * p.in_pitch : nullptr;
+  uint8_t *op = p.out + (size_t) bz * p.out_pitch + 4 * (size_t) x;
   const int4 *vt = reinterpret_cast<const int4 *> (p.vtab);
   const uint32_t tt = (uint32_t) x * p.hinc;
   const int xa = min ((int) (tt >> 16), p.in_w - 1), f = (int) ((tt >> 8) & 0xff), xb = min (xa + 1, p.in_w - 1);

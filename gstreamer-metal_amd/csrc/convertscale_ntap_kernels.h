@@ -251,6 +251,7 @@ struct CubicTileParams {
   int ow, oh, nh, nv, vfirst;
   int fast_nv12;                     // NV12 input with 8-byte aligned planes / strides: convert in 8-column groups (cs_convert8_nv12)
   const int2 *tab_h, *tab_v;         // [ow][nh], [oh][nv] of {source index, 6-bit weight}; nh / nv == 0: no scaling on that axis
+  int tiles_x, tiles_y, n_tiles, n_chunk;   // the launch: tiles per row / column of a frame, tiles in all, tiles per XCD (ceil (n_tiles / 8))
 };
 
 template <int THREADS, bool OPAQUE>
@@ -260,12 +261,19 @@ __global__ __launch_bounds__ (THREADS) void k_cs_cubic_tile (const CubicTilePara
   __shared__ uint32_t tmp[CT_RH * CT_TW];                             // first-pass result: [CT_TH][rw] (V first) or [rh][CT_TW] (H first)
   __shared__ int2 lth[CT_TW * CT_MAXN], ltv[CT_TH * CT_MAXN];         // this tile's tap tables (LDS reads instead of per-lane global loads)
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * CT_TW, y0 = blockIdx.y * CT_TH;
+  // XCD-aware tile order (1-D grid of 8 * n_chunk blocks): blocks b and b + 8 share an XCD and its L2, so block b takes tile (b % 8) * n_chunk + b / 8
+  // — each XCD one contiguous run of tiles (x fastest, then y, then frame).  Neighbouring tiles share the source lines their regions overlap in and
+  // both halves of every 128-byte line a 64-pixel-wide tile covers half of; dealt out round-robin they sat in different L2s and the input was fetched
+  // 3.4 times (profiles/r03s_pmc_elements_summary.json).  Speed only: any mapping computes the same bytes.
+  const int bt = (int) (blockIdx.x & 7u) * p.n_chunk + (int) (blockIdx.x >> 3);
+  if (bt >= p.n_tiles) return;
+  const int per = p.tiles_x * p.tiles_y, bz = bt / per, brem = bt - bz * per, by = brem / p.tiles_x, bx = brem - by * p.tiles_x;
+  const int x0 = bx * CT_TW, y0 = by * CT_TH;
   const int tw = min (CT_TW, p.ow - x0), th = min (CT_TH, p.oh - y0);
-  const uint8_t *in[3] = { p.cs.in[0] + (size_t) blockIdx.z * p.cs.in_pitch,
-                           p.cs.in[1] ? p.cs.in[1] + (size_t) blockIdx.z * p.cs.in_pitch : nullptr,
-                           p.cs.in[2] ? p.cs.in[2] + (size_t) blockIdx.z * p.cs.in_pitch : nullptr };
-  uint8_t *out = p.out + (size_t) blockIdx.z * p.cs.out_pitch;
+  const uint8_t *in[3] = { p.cs.in[0] + (size_t) bz * p.cs.in_pitch,
+                           p.cs.in[1] ? p.cs.in[1] + (size_t) bz * p.cs.in_pitch : nullptr,
+                           p.cs.in[2] ? p.cs.in[2] + (size_t) bz * p.cs.in_pitch : nullptr };
+  uint8_t *out = p.out + (size_t) bz * p.cs.out_pitch;
   // source region of this tile (tables hold absolute, edge-clamped, non-decreasing indices)
   int cx0 = p.nh ? p.tab_h[(size_t) x0 * p.nh].x : x0;
   const int cx1 = p.nh ? p.tab_h[(size_t) (x0 + tw - 1) * p.nh + p.nh - 1].x : x0 + tw - 1;

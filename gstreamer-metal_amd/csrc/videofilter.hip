@@ -522,7 +522,7 @@ __device__ __forceinline__ VfTile vf_tile (int t, int tiles_x, int tiles_y)
   VfTile o; o.frame = (uint32_t) f; o.y0 = ty * VF_TH; o.x0 = (r - ty * tiles_x) * VF_TW;
   return o;
 }
-template <bool FAST, bool STAGED> __global__ __launch_bounds__ (VF_THREADS, 4) void k_vf_sharp (const VfParams pp, int tiles_x, int tiles_y)
+template <bool FAST, bool STAGED> __global__ __launch_bounds__ (VF_THREADS, 4) void k_vf_sharp (const VfParams pp, int tiles_x, int tiles_y, int n_tiles, int n_chunk)
 {
   __shared__ uint32_t rt[VF_RH * VF_RS];       // pass-1 render target, tile + halo (clamped to the image like the blur's reads)
   __shared__ uint32_t hb[VF_RH * VF_HS];       // horizontal blur (8-bit, like _blurTemp); reused for the result of YUV outputs
@@ -534,7 +534,13 @@ template <bool FAST, bool STAGED> __global__ __launch_bounds__ (VF_THREADS, 4) v
   // texels of a row), its last 8 columns one texel per lane (64 rows x 8).  So 16 of a lane's 17 pixels share their x: the texture coordinate, the
   // vignette's cx^2 and the LDS column are loop invariants.
   const int cx = tid & 127, cy = tid >> 7, ex = 128 + (tid & 7), ey = tid >> 3;
-  const VfTile T = vf_tile ((int) blockIdx.x, tiles_x, tiles_y);
+  // XCD-aware tile order: workgroups are dealt round-robin over the chip's 8 XCDs (blocks b and b + 8 share one, each XCD has its own L2), so block b
+  // takes tile (b % 8) * chunk + b / 8: every XCD works through ONE contiguous run of tiles — whole frames of a batch — and the halo rows and columns
+  // neighbouring tiles share are fetched into one L2 instead of up to four (PMC, 64-frame launches: input fetched 1.64x -> see DESIGN §5.3).
+  // The grid is rounded up to 8 * chunk blocks; the surplus ones have no tile.  Placement is a speed matter only: any mapping gives the same bytes.
+  const int bt = (int) (blockIdx.x & 7u) * n_chunk + (int) (blockIdx.x >> 3);
+  if (bt >= n_tiles) return;
+  const VfTile T = vf_tile (bt, tiles_x, tiles_y);
   const int x0 = T.x0, y0 = T.y0;
   VfParams p = pp;
   p.in = metal::img_at (pp.in, T.frame * pp.in_pitch);
@@ -736,9 +742,10 @@ template <bool FAST> static void vf_launch_kernels (VfParams p, const VfHipFrame
     if (FAST && rgb_in && !p.quad_in) bytes_in ();
     const int tiles_x = (w + VF_TW - 1) / VF_TW, tiles_y = (hh + VF_TH - 1) / VF_TH;
     const long long n_tiles = (long long) tiles_x * tiles_y * n_frames;           // (< 2^31: 65535 frames of at most 256 x 586 tiles)
-    const dim3 grid ((unsigned) n_tiles);
-    if (rgb_in && !p.quad_in) hipLaunchKernelGGL ((k_vf_sharp<FAST, true>), grid, dim3 (VF_THREADS), 0, s, p, tiles_x, tiles_y);
-    else hipLaunchKernelGGL ((k_vf_sharp<FAST, false>), grid, dim3 (VF_THREADS), 0, s, p, tiles_x, tiles_y);
+    const int n_chunk = (int) ((n_tiles + 7) / 8);                               // tiles per XCD (k_vf_sharp's tile order)
+    const dim3 grid ((unsigned) (8 * n_chunk));
+    if (rgb_in && !p.quad_in) hipLaunchKernelGGL ((k_vf_sharp<FAST, true>), grid, dim3 (VF_THREADS), 0, s, p, tiles_x, tiles_y, (int) n_tiles, n_chunk);
+    else hipLaunchKernelGGL ((k_vf_sharp<FAST, false>), grid, dim3 (VF_THREADS), 0, s, p, tiles_x, tiles_y, (int) n_tiles, n_chunk);
   } else {
     const bool rgb_io = rgb_in && (out->info.format == VFHIP_FORMAT_RGBA || out->info.format == VFHIP_FORMAT_BGRA);
     const uintptr_t al = (uintptr_t) in->data[0] | (uintptr_t) in->stride[0] | (uintptr_t) p.in_pitch | (uintptr_t) out->data[0] | (uintptr_t) out->stride[0] | (uintptr_t) p.out_pitch;
