@@ -76,6 +76,8 @@ struct VfHipConvertScale {
   int2 *d_nt_h = nullptr, *d_nt_v = nullptr; int nt_h = 0, nt_v = 0;
   void *nt_mid0 = nullptr, *nt_mid1 = nullptr;
   bool nt_tile = false;             // every tile's source region fits k_cs_cubic_tile's LDS arrays
+  bool nt_dot = false;              // ... and k_cs_cubic_dot's planes, with every merged weight an int8: the dot-product tile kernel runs
+  uint32_t *d_win_h = nullptr, *d_win_v = nullptr; int win_wh = 4, win_wv = 4;   // its window tables ([out][CD_WT]) and window widths
   Flights fl;                       // pipelined host path (submit / wait)
 };
 
@@ -97,6 +99,9 @@ static void free_tables (VfHipConvertScale *h)
   h->nt_tmp = nullptr; h->nt_tmp_bytes = 0;
   if (h->d_nt_h) (void) hipFree (h->d_nt_h);
   if (h->d_nt_v) (void) hipFree (h->d_nt_v);
+  if (h->d_win_h) (void) hipFree (h->d_win_h);
+  if (h->d_win_v) (void) hipFree (h->d_win_v);
+  h->d_win_h = h->d_win_v = nullptr; h->nt_dot = false;
   if (h->nt_mid0) (void) hipFree (h->nt_mid0);
   if (h->nt_mid1) (void) hipFree (h->nt_mid1);
   h->d_nt_h = h->d_nt_v = nullptr; h->nt_mid0 = h->nt_mid1 = nullptr; h->nt_h = h->nt_v = 0;
@@ -451,6 +456,57 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
     const int rwa = rw + 14;                          // 8-column alignment slack of the NV12 fast conversion on both sides
     h->nt_tile = h->nt_h <= CT_MAXN && h->nt_v <= CT_MAXN && rwa <= CT_RW && rh <= CT_RH && (h->vfirst ? CT_TH * rwa : rh * CT_TW) <= CT_RH * CT_TW;
     if (const char *e = getenv ("VFHIP_CUBIC_TILE")) h->nt_tile = h->nt_tile && atoi (e) != 0;        // tuning / test knob
+    // k_cs_cubic_dot's window tables: per output { start, tap sum, W int8 weights (taps the edge clamp put on one sample merged), alpha of an opaque
+    // source after this pass }; an unscaled axis is the identity window { o, 64, [64, 0, 0, 0] }.  The kernel runs when every tile's windows fit its
+    // planes and every merged weight is an int8
+    {
+      auto windows = [] (const std::vector<int2> &tb, int n, int out, std::vector<uint32_t> &w, int &W) {
+        W = n ? 4 * ((n + 3) / 4) : 4;
+        w.assign ((size_t) out * CD_WT, 0u);
+        bool ok = W <= 12;
+        for (int o = 0; o < out && ok; o++) {
+          int wt[12] = { 0 }, sum = 0, s0 = o;
+          if (n) {
+            s0 = tb[(size_t) o * n].x;
+            for (int l = 0; l < n; l++) {
+              const int k = tb[(size_t) o * n + l].x - s0;
+              if (k < 0 || k >= W) { ok = false; break; }
+              wt[k] += tb[(size_t) o * n + l].y; sum += tb[(size_t) o * n + l].y;
+            }
+          } else { wt[0] = 64; sum = 64; }
+          uint32_t *e = &w[(size_t) o * CD_WT];
+          e[0] = (uint32_t) s0; e[1] = (uint32_t) sum;
+          for (int k = 0; k < 12; k++) {
+            if (wt[k] < -128 || wt[k] > 127) ok = false;
+            e[2 + k / 4] |= (uint32_t) (wt[k] & 0xff) << (8 * (k & 3));
+          }
+          const int a = (255 * sum + 32) >> 6;
+          e[5] = (uint32_t) (a < 0 ? 0 : (a > 255 ? 255 : a));
+          if (sum < -255 || sum > 255) ok = false;                      // (the kernel's 128 * sum + 32 and alpha * sum stay far inside 32 bits; sanity only)
+        }
+        return ok;
+      };
+      std::vector<uint32_t> wh_, wv_;
+      bool ok = windows (th_, h->nt_h, ow, wh_, h->win_wh) && windows (tv_, h->nt_v, oh, wv_, h->win_wv);
+      // every tile's region: columns [first start & ~7, last start + W), rows [first start, last start + W)
+      for (int x0 = 0; x0 < ow && ok; x0 += CD_TW) {
+        const int x1 = std::min (x0 + CD_TW, ow) - 1;
+        const int cols = (int) wh_[(size_t) x1 * CD_WT] + h->win_wh - ((int) wh_[(size_t) x0 * CD_WT] & ~7);
+        if (((cols + 7) & ~7) > CD_RW - 8) ok = false;
+      }
+      for (int y0 = 0; y0 < oh && ok; y0 += CD_TH) {
+        const int y1 = std::min (y0 + CD_TH, oh) - 1;
+        if ((int) wv_[(size_t) y1 * CD_WT] + h->win_wv - (int) wv_[(size_t) y0 * CD_WT] > CD_RH) ok = false;
+      }
+      if (const char *e = getenv ("VFHIP_CUBIC_DOT")) ok = ok && atoi (e) != 0;                     // test / A-B knob: 0 = k_cs_cubic_tile
+      h->nt_dot = ok && h->nt_tile;
+      if (h->nt_dot) {
+        VFHIP_CHECK_HIP (dev_malloc (&h->d_win_h, wh_.size () * sizeof (uint32_t)));
+        VFHIP_CHECK_HIP (upload_in_stream (h->d_win_h, wh_.data (), wh_.size () * sizeof (uint32_t), t_upload_stream));
+        VFHIP_CHECK_HIP (dev_malloc (&h->d_win_v, wv_.size () * sizeof (uint32_t)));
+        VFHIP_CHECK_HIP (upload_in_stream (h->d_win_v, wv_.data (), wv_.size () * sizeof (uint32_t), t_upload_stream));
+      }
+    }
     if (!h->nt_tile) {                                // three-pass fallback: conversion at the input size by a child handle, then the passes
       if (in->format != out->format) {
         h->conv = vfhip_convertscale_new (h->dev->ordinal);
@@ -463,7 +519,7 @@ int vfhip_convertscale_configure (VfHipConvertScale *h, const VfHipVideoInfo *in
       }
       if (h->nt_h && h->nt_v) VFHIP_CHECK_HIP (dev_malloc (&h->nt_mid1, (h->vfirst ? (size_t) iw * oh : (size_t) ow * ih) * 4 + 256));
     }
-    h->kernel = VfHipConvertScale::K_NTAP; h->kernel_name = h->nt_tile ? "k_cs_cubic_tile" : "k_cs_ntap";
+    h->kernel = VfHipConvertScale::K_NTAP; h->kernel_name = h->nt_dot ? "k_cs_cubic_dot" : (h->nt_tile ? "k_cs_cubic_tile" : "k_cs_ntap");
     h->configured = true;
     return VFHIP_OK;
   }
@@ -929,6 +985,30 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
     rect_view = *out;
     rect_view.data[0] = (uint8_t *) out->data[0] + (size_t) h->ry * out->stride[0] + 4 * (size_t) h->rx;
     out = &rect_view;
+  }
+  if (h->kernel == VfHipConvertScale::K_NTAP && h->nt_dot) {
+    CubicDotParams t {};
+    for (int k = 0; k < 3; k++) { t.cs.in[k] = (const uint8_t *) in->data[k]; t.cs.is[k] = in->stride[k]; }
+    t.cs.in_pitch = in_pitch; t.cs.out_pitch = out_pitch;
+    t.cs.in_w = h->in.width; t.cs.in_h = h->in.height; t.cs.in_fmt = h->in.format; t.cs.out_rgba = h->out.format == VFHIP_FORMAT_RGBA;
+    for (int k = 0; k < 5; k++) t.cs.c[k] = kOrcCoef[h->in.color_matrix][k];
+    t.cs.cosited = h->in.chroma_site == VFHIP_CHROMA_SITE_H_COSITED;
+    t.out = (uint8_t *) out->data[0]; t.os = out->stride[0];
+    t.ow = h->rw; t.oh = h->rh; t.vfirst = h->vfirst;
+    t.win_h = h->d_win_h; t.win_v = h->d_win_v; t.wh = h->win_wh; t.wv = h->win_wv;
+    {
+      const uintptr_t a = (uintptr_t) t.cs.in[0] | (uintptr_t) t.cs.in[1] | (uintptr_t) t.cs.is[0] | (uintptr_t) t.cs.is[1] | (uintptr_t) in_pitch;
+      t.fast_nv12 = h->in.format == VFHIP_FORMAT_NV12 && !(a & 7) && h->in.width >= 16 && getenv ("VFHIP_CUBIC_SCALAR") == nullptr;
+    }
+    t.tiles_x = (t.ow + CD_TW - 1) / CD_TW; t.tiles_y = (t.oh + CD_TH - 1) / CD_TH;
+    const long long nt = (long long) t.tiles_x * t.tiles_y * n_frames;
+    if (nt > 0x7fffff00ll) return set_error (VFHIP_ERR_INVALID, "bicubic: too many tiles in one batch");
+    t.n_tiles = (int) nt; t.n_chunk = (t.n_tiles + 7) / 8;
+    const bool opaque = h->in.format != VFHIP_FORMAT_BGRA && h->in.format != VFHIP_FORMAT_RGBA;
+    if (opaque) hipLaunchKernelGGL ((k_cs_cubic_dot<3>), dim3 ((unsigned) (8 * t.n_chunk)), dim3 (512), 0, s, t);
+    else hipLaunchKernelGGL ((k_cs_cubic_dot<4>), dim3 ((unsigned) (8 * t.n_chunk)), dim3 (512), 0, s, t);
+    VFHIP_CHECK_HIP (hipGetLastError ());
+    return VFHIP_OK;
   }
   if (h->kernel == VfHipConvertScale::K_NTAP && h->nt_tile) {
     CubicTileParams t {};

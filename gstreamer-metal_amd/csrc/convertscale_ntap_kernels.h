@@ -8,6 +8,7 @@
 //   k_ntap_h : one lane = one output pixel; its n taps (source column, weight) come from the per-column table
 // Correct-first kernels (three passes over HBM for a converting scale); the fused 2-tap kernels stay the headline path.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -135,6 +136,43 @@ __device__ __forceinline__ void cs_convert8_nv12 (const CsParams &p, const uint8
     out[2 * n] = perm_b32 (za, xg, 0x05040100u);                                // [x_e, g_e, z_e, ff]
     out[2 * n + 1] = perm_b32 (za, xg, 0x07060302u);                            // [x_o, g_o, z_o, ff]
   }
+}
+
+// cs_convert8_nv12 for k_cs_cubic_dot (load and arithmetic apart, so that the next item's loads can be in flight): the same eight pixels as three CHANNEL dwords per four pixels (lo: pixels 0-3, hi: 4-7; channel index = byte
+// position in the output pixel) straight from orc_pair's planar [even, odd] byte pairs — the RGBA interleave above and the de-interleave the planes
+// would need cancel (32 v_perm per eight pixels); alpha is not produced (a source without alpha: the kernel derives A from the tap sums)
+struct Cv8Raw { CRaw a, b; uint2 y; };           // the raw bytes behind eight NV12 pixels: chroma rows j and its vertical neighbour, the luma
+template <bool COSITED>
+__device__ __forceinline__ Cv8Raw cs_load8_nv12 (const CsParams &p, const uint8_t *const in[3], int gx, int cy)
+{
+  const int cw = (p.in_w + 1) >> 1, chh = (p.in_h + 1) >> 1;
+  const int j = cy >> 1, jn = (cy & 1) ? min (j + 1, chh - 1) : max (j - 1, 0);
+  const uint32_t roff = (gx / 2 + 4 < cw) ? 8u : 6u, loff = gx > 0 ? 2u : 0u;
+  Cv8Raw r;
+  r.a = load_craw<COSITED> (in[1], (uint32_t) j * (uint32_t) p.is[1] + (uint32_t) gx, roff, loff);
+  r.b = load_craw<COSITED> (in[1], (uint32_t) jn * (uint32_t) p.is[1] + (uint32_t) gx, roff, loff);
+  r.y = *reinterpret_cast<const uint2 *> (in[0] + (size_t) cy * p.is[0] + gx);
+  return r;
+}
+template <bool COSITED>
+__device__ __forceinline__ void cs_convert8_nv12_planar (const CsParams &p, const Cv8Raw &raw, uint32_t lo[3], uint32_t hi[3])
+{
+  const CRow a = hfilter<COSITED> (raw.a), b = hfilter<COSITED> (raw.b);
+  const uint32_t X = 0x80808080u;
+  const uint32_t e01 = filt31_u8 (a.e01, b.e01) ^ X, e23 = filt31_u8 (a.e23, b.e23) ^ X, o01 = filt31_u8 (a.o01, b.o01) ^ X, o23 = filt31_u8 (a.o23, b.o23) ^ X;
+  const uint32_t y0 = raw.y.x ^ X, y1 = raw.y.y ^ X;
+  const int bias = 128 << 16;
+  uint32_t bb[4], gg[4], rr[4];
+#pragma unroll
+  for (int n = 0; n < 4; n++) {
+    const uint32_t sel = (n & 1) ? 0x03030202u : 0x01010000u;
+    const uint32_t yn = n < 2 ? y0 : y1, en = n < 2 ? e01 : e23, on = n < 2 ? o01 : o23;
+    orc_pair (perm_b32 (0u, yn, sel), perm_b32 (0u, en, sel), perm_b32 (0u, on, sel), p.c, bias, bb[n], gg[n], rr[n]);
+  }
+  const uint32_t *x = p.out_rgba ? rr : bb, *z = p.out_rgba ? bb : rr;          // byte 0 / byte 2 channel
+  lo[0] = perm_b32 (x[1], x[0], 0x05040100u); hi[0] = perm_b32 (x[3], x[2], 0x05040100u);
+  lo[1] = perm_b32 (gg[1], gg[0], 0x05040100u); hi[1] = perm_b32 (gg[3], gg[2], 0x05040100u);
+  lo[2] = perm_b32 (z[1], z[0], 0x05040100u); hi[2] = perm_b32 (z[3], z[2], 0x05040100u);
 }
 
 // the same for I420: GStreamer's I420 fast path replicates the chroma sample of row cy >> 1 to its two columns and two rows (nearest:
@@ -366,6 +404,229 @@ __global__ __launch_bounds__ (THREADS) void k_cs_cubic_tile (const CubicTilePara
       q = ntap_finishf<OPAQUE> (a, 255.0f);
     } else q = reg[ty][tx];
     *reinterpret_cast<uint32_t *> (out + (size_t) (y0 + ty) * p.os + 4 * (x0 + tx)) = q;
+  }
+}
+
+// ---- k_cs_cubic_dot: the tile kernel with the passes as int8 dot products (round 3) ---------------------------------------------------------
+// k_cs_cubic_tile evaluates a tap as three v_cvt_f32_ubyte + three v_fma (21 issue cycles per tap and pixel) and reads its sample AND its table
+// entry from LDS for every tap: ~210 of its ~520 instructions per output pixel.  A pass is sum (sample * 6-bit tap) over a WINDOW of adjacent
+// samples of one channel, so here the converted region lives in LDS as byte PLANES (one per channel, row-major, samples biased by -128 to int8)
+// and a pass is v_dot4c_i32_i8 on four samples at a time:
+//   * the host turns each output's tap list {index, weight} into a window: start s (the first tap's index), W = 4, 8 or 12 weights as int8 (taps
+//     that the edge clamp put on the same sample merged, the rest 0), and the tap sum; with acc0 = 128 * sum + 32 the dot products give
+//     sum (sample * tap) + 32 exactly, then >> 6 and saturate to a byte — GstVideoScaler's clamp ((sum + 32) >> 6), bit for bit;
+//   * horizontal pass: a window starts at any byte: W / 4 + 1 dwords, v_alignbyte_b32 by s & 3, W / 4 dot products (16 cycles per channel at W = 8);
+//   * vertical pass: four adjacent columns at once — one dword per window row, a 4 x 4 byte transpose (8 v_perm) per four rows turns them into
+//     four column dwords, four dot products (24 cycles per channel and pixel at W = 8);
+//   * the conversion (cs_convert8_nv12's eight pixels of a row, or cs_tap) is de-interleaved with the same 4 x 4 transpose and written as one
+//     8-byte store per channel; the first pass writes the planes the second reads (four results per dword store), the second pass writes pixels.
+// A source without alpha converts to A = 255 everywhere: three planes, and A of the output from the two tap sums (the rule of k_cs_cubic_tile:
+// GStreamer's taps do not always sum to 64).  Same results as k_cs_cubic_tile and the three-pass path (tests compare all three with the real
+// element's vectors); used when every tile's windows fit the planes and every merged weight fits int8 (else k_cs_cubic_tile).
+constexpr int CD_TW = 64, CD_TH = 16;
+constexpr int CD_RW = 176, CD_RH = 52;            // plane row stride in bytes (a multiple of 8) / plane rows: the region of a tile incl. alignment and window slack
+constexpr int CD_P2 = CD_RH * CD_TW;              // first-pass result per channel: [CD_TH][CD_RW] (V first) or [CD_RH][CD_TW] (H first), whichever is larger
+constexpr int CD_WT = 6;                          // dwords per output in a window table: start, tap sum, three dwords of int8 weights, alpha of an opaque source after this pass
+static_assert (CD_TH * CD_RW <= CD_P2 && CD_RW % 8 == 0, "plane geometry");
+
+struct CubicDotParams {
+  CsParams cs;                       // input planes / strides / matrix / formats for the conversion; in_pitch, out_pitch for batches
+  uint8_t *out; int os;
+  int ow, oh, vfirst, fast_nv12;
+  const uint32_t *win_h, *win_v;     // [ow][CD_WT], [oh][CD_WT]
+  int wh, wv;                        // window widths: 4, 8 or 12
+  int tiles_x, tiles_y, n_tiles, n_chunk;
+};
+
+// 4 x 4 byte transpose: (a, b, c, d) = four dwords of four bytes -> o[j] = { a.byte j, b.byte j, c.byte j, d.byte j }.  Pixels -> channel dwords,
+// window rows -> column dwords, channel dwords -> pixels: the same eight v_perm
+__device__ __forceinline__ void cd_transpose4 (uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t o[4])
+{
+  const uint32_t t0 = perm_b32 (b, a, 0x05010400u), t1 = perm_b32 (b, a, 0x07030602u), t2 = perm_b32 (d, c, 0x05010400u), t3 = perm_b32 (d, c, 0x07030602u);
+  o[0] = perm_b32 (t2, t0, 0x05040100u); o[1] = perm_b32 (t2, t0, 0x07060302u); o[2] = perm_b32 (t3, t1, 0x05040100u); o[3] = perm_b32 (t3, t1, 0x07060302u);
+}
+// four sums -> four bytes clamp (sum >> 6): 16-bit pairs through v_sat_pk_u8_i16 (|sum >> 6| < 2^15 by far: |sum| < 2^15 already)
+__device__ __forceinline__ uint32_t cd_pack4 (int a0, int a1, int a2, int a3)
+{
+  const uint32_t p01 = sat_pk_u8_i16 (perm_b32 ((uint32_t) (a1 >> 6), (uint32_t) (a0 >> 6), 0x05040100u));
+  const uint32_t p23 = sat_pk_u8_i16 (perm_b32 ((uint32_t) (a3 >> 6), (uint32_t) (a2 >> 6), 0x05040100u));
+  return perm_b32 (p23, p01, 0x05040100u);
+}
+// window along a row: `row` = the plane row, wt = the output's table entry (start relative to the row's first byte); NG = W / 4 dwords of weights
+template <int NG>
+__device__ __forceinline__ int cd_hwin_n (const uint8_t *row, const uint32_t *wt)
+{
+  const uint32_t s = wt[0];
+  const uint32_t *d = reinterpret_cast<const uint32_t *> (row + (s & ~3u));
+  int acc = (int) wt[1] * 128 + 32;
+  uint32_t lo = d[0];
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+    const uint32_t hi = d[g + 1];
+    acc = __builtin_amdgcn_sdot4 ((int) alignbyte (hi, lo, s & 3u), (int) wt[2 + g], acc, false);
+    lo = hi;
+  }
+  return acc;
+}
+__device__ __forceinline__ int cd_hwin (const uint8_t *row, const uint32_t *wt, int W)        // W is wave-uniform: one scalar branch
+{
+  return W == 8 ? cd_hwin_n<2> (row, wt) : (W == 4 ? cd_hwin_n<1> (row, wt) : cd_hwin_n<3> (row, wt));
+}
+// window down four adjacent columns (byte offset col4, a multiple of 4) of a plane with `stride` bytes per row
+template <int NG>
+__device__ __forceinline__ void cd_vwin4_n (const uint8_t *plane, int stride, int col4, const uint32_t *wt, int acc[4])
+{
+  const uint8_t *r = plane + (int) wt[0] * stride + col4;
+  acc[0] = acc[1] = acc[2] = acc[3] = (int) wt[1] * 128 + 32;
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+    uint32_t col[4];
+    cd_transpose4 (*reinterpret_cast<const uint32_t *> (r), *reinterpret_cast<const uint32_t *> (r + stride),
+                   *reinterpret_cast<const uint32_t *> (r + 2 * stride), *reinterpret_cast<const uint32_t *> (r + 3 * stride), col);
+    const int w = (int) wt[2 + g];
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_sdot4 ((int) col[j], w, acc[j], false);
+    r += 4 * stride;
+  }
+}
+__device__ __forceinline__ void cd_vwin4 (const uint8_t *plane, int stride, int col4, const uint32_t *wt, int W, int acc[4])
+{
+  if (W == 8) cd_vwin4_n<2> (plane, stride, col4, wt, acc);
+  else if (W == 4) cd_vwin4_n<1> (plane, stride, col4, wt, acc);
+  else cd_vwin4_n<3> (plane, stride, col4, wt, acc);
+}
+
+// i / d for the kernel's item indices without an integer division (~20 instructions): exact for d <= 64-ish divisors and quotients < 1000 —
+// (i + .5) * fl (1 / d) is off by < 1e-4 there and (i + .5) / d is at least .5 / d away from every integer
+__device__ __forceinline__ int cd_div (int i, float inv) { return (int) (((float) i + 0.5f) * inv); }
+
+template <int NCH>
+__global__ __launch_bounds__ (512, NCH == 3 ? 8 : 6) void k_cs_cubic_dot (const CubicDotParams p)
+{
+  __shared__ __attribute__ ((aligned (16))) uint8_t P1[NCH][CD_RH * CD_RW + 16];    // converted region, one plane per channel (byte order of the output pixel)
+  __shared__ __attribute__ ((aligned (16))) uint8_t P2[NCH][CD_P2 + 16];            // first-pass result
+  __shared__ uint32_t lwh[CD_TW][CD_WT], lwv[CD_TH][CD_WT];
+  const int tid = threadIdx.x;
+  const int bt = (int) (blockIdx.x & 7u) * p.n_chunk + (int) (blockIdx.x >> 3);       // XCD-aware tile order (k_cs_cubic_tile)
+  if (bt >= p.n_tiles) return;
+  const int per = p.tiles_x * p.tiles_y, bz = bt / per, brem = bt - bz * per, by = brem / p.tiles_x, bx = brem - by * p.tiles_x;
+  const int x0 = bx * CD_TW, y0 = by * CD_TH;
+  const int tw = min (CD_TW, p.ow - x0), th = min (CD_TH, p.oh - y0);
+  const uint8_t *in[3] = { p.cs.in[0] + (size_t) bz * p.cs.in_pitch,
+                           p.cs.in[1] ? p.cs.in[1] + (size_t) bz * p.cs.in_pitch : nullptr,
+                           p.cs.in[2] ? p.cs.in[2] + (size_t) bz * p.cs.in_pitch : nullptr };
+  uint8_t *out = p.out + (size_t) bz * p.cs.out_pitch;
+  // the region: columns from the first window's start (down to a multiple of 8: whole conversion groups, dword-aligned windows) to the last window's
+  // end, rows likewise; the tables staged with starts relative to it (entries beyond a partial tile repeat the last one: harmless work)
+  const int ga = (int) p.win_h[(size_t) x0 * CD_WT] & ~7, ry0 = (int) p.win_v[(size_t) y0 * CD_WT];
+  const int cols = (int) p.win_h[(size_t) (x0 + tw - 1) * CD_WT] + p.wh - ga, rows = (int) p.win_v[(size_t) (y0 + th - 1) * CD_WT] + p.wv - ry0;
+  const int groups = (cols + 7) >> 3;
+  for (int i = tid; i < CD_TW * CD_WT; i += 512) {
+    const int tx = i / CD_WT, k = i - tx * CD_WT;
+    const uint32_t v = p.win_h[(size_t) (x0 + min (tx, tw - 1)) * CD_WT + k];
+    lwh[tx][k] = k ? v : v - (uint32_t) ga;
+  }
+  for (int i = tid; i < CD_TH * CD_WT; i += 512) {
+    const int ty = i / CD_WT, k = i - ty * CD_WT;
+    const uint32_t v = p.win_v[(size_t) (y0 + min (ty, th - 1)) * CD_WT + k];
+    lwv[ty][k] = k ? v : v - (uint32_t) ry0;
+  }
+  // conversion: eight pixels of a row per item -> NCH x 8 bytes.  Rows / groups beyond the frame are not converted: their weights are 0.
+  // NV12 through the packed ORC pipeline with the NEXT item's seven loads issued before this item's arithmetic (a lane has one or two items:
+  // without this the second one's HBM latency was the phase's tail); everything else pixel by pixel (cs_tap)
+  const float inv_groups = 1.0f / (float) groups;
+  const int n_items = groups * rows;
+  auto convert = [&] (auto cosited_tag) {
+    constexpr bool COS = decltype (cosited_tag)::value;
+    auto where = [&] (int i, int &ry, int &g, int &gx, int &cy) { ry = cd_div (i, inv_groups); g = i - ry * groups; gx = ga + 8 * g; cy = ry0 + ry; };
+    auto is_fast = [&] (int gx, int cy) { return NCH == 3 && p.fast_nv12 && cy < p.cs.in_h && gx + 8 <= p.cs.in_w; };
+    int i = tid, ry = 0, g = 0, gx = 0, cy = 0;
+    Cv8Raw cur {};
+    if (i < n_items) { where (i, ry, g, gx, cy); if (is_fast (gx, cy)) cur = cs_load8_nv12<COS> (p.cs, in, gx, cy); }
+    while (i < n_items) {
+      const int in_ = i + 512;
+      int nry = 0, ng = 0, ngx = 0, ncy = 0;
+      Cv8Raw nxt {};
+      if (in_ < n_items) { where (in_, nry, ng, ngx, ncy); if (is_fast (ngx, ncy)) nxt = cs_load8_nv12<COS> (p.cs, in, ngx, ncy); }
+      if (cy < p.cs.in_h && gx < p.cs.in_w) {
+        uint32_t lo[4], hi[4];
+        if (is_fast (gx, cy)) cs_convert8_nv12_planar<COS> (p.cs, cur, lo, hi);
+        else {
+          uint32_t px8[8];
+#pragma unroll 1
+          for (int k = 0; k < 8; k++) {
+            int px[4];
+            cs_tap (p.cs, in, min (gx + k, p.cs.in_w - 1), cy, px);
+            px8[k] = (uint32_t) px[0] | ((uint32_t) px[1] << 8) | ((uint32_t) px[2] << 16) | ((uint32_t) px[3] << 24);
+          }
+          cd_transpose4 (px8[0], px8[1], px8[2], px8[3], lo);
+          cd_transpose4 (px8[4], px8[5], px8[6], px8[7], hi);
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; c++)
+          *reinterpret_cast<uint2 *> (&P1[c][ry * CD_RW + 8 * g]) = make_uint2 (lo[c] ^ 0x80808080u, hi[c] ^ 0x80808080u);
+      }
+      cur = nxt; i = in_; ry = nry; g = ng; gx = ngx; cy = ncy;
+    }
+  };
+  if (p.cs.cosited) convert (std::true_type ()); else convert (std::false_type ());
+  __syncthreads ();
+  const uint32_t X = 0x80808080u;
+  if (p.vfirst) {
+    // pass 1, vertical: (channel, output row, four region columns) -> P2[c][ty][rx]
+    const int q = groups * 2;                                         // dwords per region row
+    const float inv_q = 1.0f / (float) q;
+    for (int i = tid; i < NCH * th * q; i += 512) {
+      const int cty = cd_div (i, inv_q), rx4 = i - cty * q;         // (channel, row) pairs: c * th + ty
+      const int c = cty >= 2 * th ? (cty >= 3 * th ? 3 : 2) : (cty >= th ? 1 : 0), ty = cty - c * th;
+      int acc[4];
+      cd_vwin4 (P1[c], CD_RW, 4 * rx4, lwv[ty], p.wv, acc);
+      *reinterpret_cast<uint32_t *> (&P2[c][ty * CD_RW + 4 * rx4]) = cd_pack4 (acc[0], acc[1], acc[2], acc[3]) ^ X;
+    }
+    __syncthreads ();
+    // pass 2, horizontal: one output pixel per item
+    const float inv_tw = 1.0f / (float) tw;
+    for (int i = tid; i < th * tw; i += 512) {
+      const int ty = cd_div (i, inv_tw), tx = i - ty * tw;
+      int a[4];
+#pragma unroll
+      for (int c = 0; c < NCH; c++) a[c] = cd_hwin (&P2[c][ty * CD_RW], lwh[tx], p.wh);
+      if (NCH == 3) a[3] = (int) lwv[ty][5] * (int) lwh[tx][1] + 32;                       // alpha after the vertical pass x the horizontal tap sum
+      *reinterpret_cast<uint32_t *> (out + (size_t) (y0 + ty) * p.os + 4 * (x0 + tx)) = cd_pack4 (a[0], a[1], a[2], a[3]);
+    }
+  } else {
+    // pass 1, horizontal: (channel, region row, four output columns) -> P2[c][ry][tx]
+    for (int i = tid; i < NCH * rows * (CD_TW / 4); i += 512) {
+      const int cry = i / (CD_TW / 4), tx4 = i - cry * (CD_TW / 4);       // (channel, region row) pairs: c * rows + ry
+      const int c = cry >= 2 * rows ? (cry >= 3 * rows ? 3 : 2) : (cry >= rows ? 1 : 0), ry = cry - c * rows;
+      const uint8_t *row = &P1[c][ry * CD_RW];
+      int a[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) a[k] = cd_hwin (row, lwh[4 * tx4 + k], p.wh);
+      *reinterpret_cast<uint32_t *> (&P2[c][ry * CD_TW + 4 * tx4]) = cd_pack4 (a[0], a[1], a[2], a[3]) ^ X;
+    }
+    __syncthreads ();
+    // pass 2, vertical: four output pixels of a row per item
+    for (int i = tid; i < th * (CD_TW / 4); i += 512) {
+      const int ty = i / (CD_TW / 4), tx4 = i - ty * (CD_TW / 4);
+      if (4 * tx4 >= tw) continue;
+      uint32_t ch[4];
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        int acc[4];
+        cd_vwin4 (P2[c], CD_TW, 4 * tx4, lwv[ty], p.wv, acc);
+        ch[c] = cd_pack4 (acc[0], acc[1], acc[2], acc[3]);
+      }
+      if (NCH == 3) {
+        const int sv = (int) lwv[ty][1];
+        ch[3] = cd_pack4 ((int) lwh[4 * tx4][5] * sv + 32, (int) lwh[4 * tx4 + 1][5] * sv + 32, (int) lwh[4 * tx4 + 2][5] * sv + 32, (int) lwh[4 * tx4 + 3][5] * sv + 32);
+      }
+      uint32_t px[4];
+      cd_transpose4 (ch[0], ch[1], ch[2], ch[3], px);
+      uint32_t *o = reinterpret_cast<uint32_t *> (out + (size_t) (y0 + ty) * p.os + 4 * (x0 + 4 * tx4));
+#pragma unroll
+      for (int k = 0; k < 4; k++) if (4 * tx4 + k < tw) o[k] = px[k];
+    }
   }
 }
 

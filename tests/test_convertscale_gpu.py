@@ -223,17 +223,19 @@ def test_yuv_outputs_1080p_vs_oracle(vfhip, oracle, ifmt, ofmt):
 from test_oracle_golden import MANIFEST_B, ZB, cubic_in_domain  # noqa: E402
 
 
-@pytest.mark.parametrize("tile", [1, 0], ids=["fused-tile", "three-pass"])
+@pytest.mark.parametrize("tile", [2, 1, 0], ids=["dot-tile", "float-tile", "three-pass"])
 @pytest.mark.parametrize("case", [c for c in MANIFEST_B if cubic_in_domain(c)], ids=[c["name"] for c in MANIFEST_B if cubic_in_domain(c)])
 def test_golden_gstreamer_vectors_bicubic(vfhip, case, tile, monkeypatch):
-    """both device paths: the fused tile kernel (when a tile's source region fits LDS) and the three-pass fallback"""
-    monkeypatch.setenv("VFHIP_CUBIC_TILE", str(tile))
+    """all three device paths: the tile kernel with int8 dot products (k_cs_cubic_dot, the default when a tile's windows fit its LDS planes), the
+    float tile kernel (k_cs_cubic_tile) and the three-pass fallback"""
+    monkeypatch.setenv("VFHIP_CUBIC_TILE", str(min(tile, 1)))
+    monkeypatch.setenv("VFHIP_CUBIC_DOT", "1" if tile == 2 else "0")
     raw, want = ZB[case["name"] + "_in"], ZB[case["name"] + "_out"]
     col, site = case["colorimetry"], case["chroma_site"]
     if col is None:
         col, site = oracle_lib.default_colorimetry(case["h"])
     got, kname = run(vfhip, case["in_format"], case["w"], case["h"], raw, col, site, "bicubic", case["out_format"], case["ow"], case["oh"])
-    assert kname in ("k_cs_cubic_tile", "k_cs_ntap") and (tile or kname == "k_cs_ntap")
+    assert kname in ("k_cs_cubic_dot", "k_cs_cubic_tile", "k_cs_ntap") and (tile or kname == "k_cs_ntap") and (tile == 2 or kname != "k_cs_cubic_dot")
     assert np.array_equal(got.reshape(-1), want), f"{kname}: {(got.reshape(-1) != want).sum()} bytes differ"
 
 
@@ -251,10 +253,12 @@ def test_bicubic_outside_the_pinned_domain_is_refused(vfhip):
 @pytest.mark.gpu
 @pytest.mark.parametrize("ifmt,w,h,ow,oh", [("I420", 54, 67, 18, 74), ("I420", 93, 32, 33, 101), ("NV12", 54, 67, 18, 74), ("NV12", 54, 67, 18, 67),
                                             ("UYVY", 60, 40, 20, 13), ("BGRA", 54, 67, 18, 74), ("NV12", 300, 200, 100, 67)])
-def test_bicubic_alpha_where_the_taps_do_not_sum_to_64(vfhip, oracle, ifmt, w, h, ow, oh):
+@pytest.mark.parametrize("dot", ["1", "0"], ids=["dot-tile", "float-tile"])
+def test_bicubic_alpha_where_the_taps_do_not_sum_to_64(vfhip, oracle, ifmt, w, h, ow, oh, dot, monkeypatch):
     """GStreamer's 6-bit catrom taps sum to 63 in some columns / rows at 3:1, and videoscale then outputs A = 251 for an opaque
     source (pinned: the oracle equals the real element on such vectors).  The tile kernel, which does not filter the alpha of a
     source without alpha tap by tap, has to reproduce that from the tap sums."""
+    monkeypatch.setenv("VFHIP_CUBIC_DOT", dot)
     rng = np.random.default_rng(w * 1000 + h)
     raw = rng.integers(0, 256, vfhip.plane_layout(ifmt, w, h)[1], dtype=np.uint8)
     got, kname = run(vfhip, ifmt, w, h, raw, "bt601", "jpeg", "bicubic", "RGBA", ow, oh)
@@ -273,7 +277,7 @@ def test_bicubic_1080p_to_540p_vs_oracle_and_batch(vfhip, oracle):
     frames = [rng.integers(0, 256, size, dtype=np.uint8) for _ in range(3)]
     cs = vfhip.ConvertScale(0)
     cs.configure("NV12", w, h, "BGRA", ow, oh, method="bicubic", colorimetry="bt709", chroma_site="mpeg2")
-    assert cs.kernel_name == "k_cs_cubic_tile"              # 2:1 fits the tile kernel's LDS region
+    assert cs.kernel_name == "k_cs_cubic_dot"               # 2:1 fits the tile kernel's LDS planes
     want = [oracle.convertscale("NV12", w, h, f, "bt709", "mpeg2", "bicubic", "BGRA", ow, oh) for f in frames]
     assert np.array_equal(cs.process(frames[0]).reshape(oh, ow, 4), want[0])
     pitch = (size + 255) // 256 * 256
@@ -300,7 +304,7 @@ def test_golden_gstreamer_vectors_packed_inputs(vfhip, case):
     raw, want = ZP[case["name"] + "_in"], ZP[case["name"] + "_out"]
     got, kname = run(vfhip, case["in_format"], case["w"], case["h"], raw, case["colorimetry"], case["chroma_site"], case["method"],
                      case["out_format"], case["ow"], case["oh"])
-    assert kname in ("k_cs_generic", "k_cs_bilinear_tile", "k_cs_cubic_tile", "k_cs_ntap", "k_cs_uyvy_same", "k_cs_yuy2_same")            # never the metal arithmetic
+    assert kname in ("k_cs_generic", "k_cs_bilinear_tile", "k_cs_cubic_dot", "k_cs_cubic_tile", "k_cs_ntap", "k_cs_uyvy_same", "k_cs_yuy2_same")            # never the metal arithmetic
     assert np.array_equal(got.reshape(-1), want), f"{kname}: {(got.reshape(-1) != want).sum()} bytes differ"
 
 

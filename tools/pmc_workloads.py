@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/pmc_workloads.py — the element kernels of the BASELINE configs (and two neighbours) launched a few times each, as the command for the PMC passes
 of tools/gpu_pmc_cmd.sh: C1 k_cs_taps_strip, C3 k_vf_sharp, the filter without sharpening (k_vf_point_rgba4), C4 k_compositor_quads + _420,
-C5 k_deinterlace_420q (+ the headline kernel as its second leg), bicubic C2 k_cs_cubic_tile.  Rings as in bench_configs.py (beyond the Infinity Cache);
+C5 k_deinterlace_420q (+ the headline kernel as its second leg), bicubic C2 k_cs_cubic_dot.  Rings as in bench_configs.py (beyond the Infinity Cache);
 prints the algorithmic bytes per LAUNCH of every workload so that FETCH x 2 + WRITE per dispatch can be set against them."""
 import json
 import os
