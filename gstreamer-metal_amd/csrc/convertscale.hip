@@ -1122,6 +1122,13 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
       const long long nb = (long long) p.xg_x * p.xg_y * n_frames;
       if (nb > 0x7fffff00ll) return set_error (VFHIP_ERR_INVALID, "convertscale: too many blocks in one batch");
       p.xg_n = (int) nb; p.xg_chunk = (p.xg_n + 7) / 8;
+      // n / d for n < 2^31 as (umulhi (m, n) + n) >> l with l = ceil (log2 d), m = floor (2^32 (2^l - d) / d) + 1 (Granlund & Montgomery)
+      auto fastdiv = [] (uint32_t d, uint32_t &m, uint32_t &l) {
+        l = 0; while ((1ull << l) < d) l++;
+        m = (uint32_t) ((((1ull << l) - d) << 32) / d + 1);
+      };
+      fastdiv ((uint32_t) (p.xg_x * p.xg_y), p.xg_m_per, p.xg_l_per);
+      fastdiv ((uint32_t) p.xg_x, p.xg_m_x, p.xg_l_x);
       dim3 sg ((unsigned) (8 * p.xg_chunk));
       const bool i420 = p.in_fmt == VFHIP_FORMAT_I420;
 #define VF_STRIP(I, C, V) hipLaunchKernelGGL ((k_cs_taps_strip<I, C, V, 4>), sg, dim3 (64, 4), 0, s, p)

@@ -45,6 +45,7 @@ struct CsParams {
   uint32_t border;                  // border colour in output byte order
   int half_rows;                    // k_cs_nv12_half: output rows per lane (strip height)
   int xg_x, xg_y, xg_n, xg_chunk;   // XCD-aware 1-D launches (cs_xcd_block): blocks per row / column of a frame, blocks in all, blocks per XCD
+  uint32_t xg_m_per, xg_l_per, xg_m_x, xg_l_x;   // n / (xg_x * xg_y) and n / xg_x as (umulhi (m, n) + n) >> l (cs_fastdiv, host)
 };
 
 // XCD-aware block order for kernels whose neighbouring blocks share source lines (k_cs_taps_strip: a block's 64 columns x 16 rows lean on 1.5 luma
@@ -53,12 +54,13 @@ struct CsParams {
 // and shared lines are fetched into one L2.  Returns false for the surplus blocks of the rounded-up grid.  Speed only: any mapping gives the same bytes.
 __device__ __forceinline__ bool cs_xcd_block (const CsParams &p, int &bx, int &by, int &bz)
 {
-  const int bt = (int) (blockIdx.x & 7u) * p.xg_chunk + (int) (blockIdx.x >> 3);
-  if (bt >= p.xg_n) return false;
-  const int per = p.xg_x * p.xg_y;
-  bz = bt / per;
-  const int r = bt - bz * per;
-  by = r / p.xg_x; bx = r - by * p.xg_x;
+  const uint32_t bt = (blockIdx.x & 7u) * (uint32_t) p.xg_chunk + (blockIdx.x >> 3);
+  if (bt >= (uint32_t) p.xg_n) return false;
+  // two divisions by launch constants as multiply-high + shift (scalar: s_mul_hi_u32): the generic integer division is ~30 instructions, and a
+  // block of this kernel is one strip of four rows per wave — the two divisions made every 2-tap down-scale 8-10 % slower when this went in
+  const uint32_t z = (__umulhi (p.xg_m_per, bt) + bt) >> p.xg_l_per, r = bt - z * (uint32_t) (p.xg_x * p.xg_y);
+  const uint32_t y = (__umulhi (p.xg_m_x, r) + r) >> p.xg_l_x;
+  bz = (int) z; by = (int) y; bx = (int) (r - y * (uint32_t) p.xg_x);
   return true;
 }
 

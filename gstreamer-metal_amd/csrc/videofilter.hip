@@ -404,7 +404,7 @@ template <bool FAST> __device__ __forceinline__ uint32_t vf_shade_texel (const V
 
 template <bool FAST> __global__ __launch_bounds__ (256) void k_vf_point (const VfParams pp)
 {
-  const VfParams p = vf_frame_t<FAST> (pp);
+  const VfParams p = vf_frame (pp);          // (uniforms stay in SGPRs here: with the 4:2:0 sampler's registers the VGPR copies cost more occupancy than the operands cost issue cycles)
   const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
   if (2 * bx >= p.out.w || 2 * by >= p.out.h) return;
   uint32_t q[2][2];
@@ -496,7 +496,7 @@ template <bool FAST> __global__ __launch_bounds__ (256) void k_vf_point_rgba4 (c
 // its inputs: NV12 -> NV12 1080p 7.5 -> 5.05 us, NV12 -> BGRA 6.9 -> 4.3.
 template <bool FAST> __global__ __launch_bounds__ (256) void k_vf_point_quad (const VfParams pp)
 {
-  const VfParams p = vf_frame_t<FAST> (pp);
+  const VfParams p = vf_frame (pp);          // (uniforms stay in SGPRs here: with the 4:2:0 sampler's registers the VGPR copies cost more occupancy than the operands cost issue cycles)
   const int xq = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
   if (4 * xq >= p.out.w || 2 * by >= p.out.h) return;                 // W % 4 == 0, even H
   F4 c[2][4];
