@@ -58,6 +58,31 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
+def csrc_sha16():
+    """identity of ALL kernel sources (the VALU figures of profiles/valu_latest.json cover every element kernel)"""
+    h = hashlib.sha256()
+    d = os.path.join(PKG, "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_valu():
+    """per-kernel VALU roofline figures (tools/valu_roofline.py on committed PMC passes): kernel -> {valu_issue_share, avg_issue_cycles}, only when they
+    were measured on exactly these sources; else {} — a VALU-bound kernel's HBM fraction says how far it is from the wrong roof, this says how near the right one"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "valu_latest.json")) as f:
+            v = json.load(f)
+    except Exception:
+        return {}
+    if v.get("source_sha16") != csrc_sha16():
+        return {}
+    return {k: {"valu_issue_share": d["valu_issue_share"], "avg_issue_cycles": d["avg_issue_cycles"], "source": "profiles/valu_latest.json (PMC SQ_INSTS_VALU x opcode-mix issue cost / SIMD cycles; lower bound)"}
+            for k, d in v.get("kernels", {}).items()}
+
+
 def load_traffic(frames):
     """HBM bytes per launch from the committed PMC summary (separate rocprofv3 --pmc passes, FETCH_SIZE x2 per the gfx950
     correction + WRITE_SIZE: MI355X_MICROARCH.md §HBM), rescaled to this run's frames per launch.  The summary names the
@@ -362,6 +387,9 @@ def main():
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": traffic_note, "kernel": dom, "kernel_ms": round(dom_ms, 4),
                 "algorithmic_bytes_per_launch": dom_bytes, "kernel_source_sha16": kernel_source_sha16()}
+        valu = load_valu()
+        if dom in valu:
+            roof["valu"] = valu[dom]
         if c5:
             roof["legs_ms_per_launch"] = {"k_deinterlace_420q": round(de_ms, 4), kernel: round(cs_ms, 4)}
         if not args.no_ceilings:
@@ -389,6 +417,10 @@ def main():
             del ring_in, ring_out
             torch.cuda.empty_cache()
             out["others"] = bench_configs.others(torch, vfhip, stream, local_rank)
+            for o in out["others"].values():               # the VALU figure of the config's dominant kernel, when one is committed for these sources
+                k0 = str(o.get("kernel", "")).split(" + ")[0]
+                if k0 in valu:
+                    o["valu"] = valu[k0]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
