@@ -732,7 +732,7 @@ static VfFast vf_fold (const VfHipVideoFilterParams &u, int w, int hh, int lut_s
   return f;
 }
 
-template <bool FAST> static void vf_launch_kernels (VfParams p, const VfHipFrame *in, const VfHipFrame *out, int w, int hh, int n_frames, hipStream_t s)
+template <bool FAST> static int vf_launch_kernels (VfParams p, const VfHipFrame *in, const VfHipFrame *out, int w, int hh, int n_frames, hipStream_t s)
 {
   const VfHipVideoFilterParams *prm = &p.u;
   const bool rgb_in = in->info.format == VFHIP_FORMAT_RGBA || in->info.format == VFHIP_FORMAT_BGRA;
@@ -741,7 +741,8 @@ template <bool FAST> static void vf_launch_kernels (VfParams p, const VfHipFrame
   if (prm->sharpness < -0.001f || prm->sharpness > 0.001f) {
     if (FAST && rgb_in && !p.quad_in) bytes_in ();
     const int tiles_x = (w + VF_TW - 1) / VF_TW, tiles_y = (hh + VF_TH - 1) / VF_TH;
-    const long long n_tiles = (long long) tiles_x * tiles_y * n_frames;           // (< 2^31: 65535 frames of at most 256 x 586 tiles)
+    const long long n_tiles = (long long) tiles_x * tiles_y * n_frames;
+    if (n_tiles > 0x7fffff00ll) return set_error (VFHIP_ERR_INVALID, "videofilter: %lld tiles in one batch (at most 2^31): split the batch", n_tiles);
     const int n_chunk = (int) ((n_tiles + 7) / 8);                               // tiles per XCD (k_vf_sharp's tile order)
     const dim3 grid ((unsigned) (8 * n_chunk));
     if (rgb_in && !p.quad_in) hipLaunchKernelGGL ((k_vf_sharp<FAST, true>), grid, dim3 (VF_THREADS), 0, s, p, tiles_x, tiles_y, (int) n_tiles, n_chunk);
@@ -762,6 +763,7 @@ template <bool FAST> static void vf_launch_kernels (VfParams p, const VfHipFrame
       hipLaunchKernelGGL (k_vf_point<FAST>, grid, dim3 (64, 4), 0, s, p);
     }
   }
+  return VFHIP_OK;
 }
 
 static int vf_launch (VfHipVideoFilter *h, const VfHipFrame *in, VfHipFrame *out, const VfHipVideoFilterParams *prm, hipStream_t s,
@@ -779,8 +781,8 @@ static int vf_launch (VfHipVideoFilter *h, const VfHipFrame *in, VfHipFrame *out
     p.f = vf_fold (*prm, w, hh, h->lut_size);
     p.lut16 = getenv ("VFHIP_VF_LUT32") == nullptr ? h->d_lut16 : nullptr;
     if (p.lut16) p.f.on |= VF_ON_LUT16;
-    vf_launch_kernels<true> (p, in, out, w, hh, n_frames, s);
-  } else vf_launch_kernels<false> (p, in, out, w, hh, n_frames, s);
+    if (int rc = vf_launch_kernels<true> (p, in, out, w, hh, n_frames, s)) return rc;
+  } else if (int rc = vf_launch_kernels<false> (p, in, out, w, hh, n_frames, s)) return rc;
   VFHIP_CHECK_HIP (hipGetLastError ());
   return VFHIP_OK;
 }
