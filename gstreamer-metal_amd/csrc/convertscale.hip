@@ -1005,8 +1005,9 @@ static int launch_device (VfHipConvertScale *h, const VfHipFrame *in, VfHipFrame
     if (nt > 0x7fffff00ll) return set_error (VFHIP_ERR_INVALID, "bicubic: too many tiles in one batch");
     t.n_tiles = (int) nt; t.n_chunk = (t.n_tiles + 7) / 8;
     const bool opaque = h->in.format != VFHIP_FORMAT_BGRA && h->in.format != VFHIP_FORMAT_RGBA;
-    if (opaque) hipLaunchKernelGGL ((k_cs_cubic_dot<3>), dim3 ((unsigned) (8 * t.n_chunk)), dim3 (512), 0, s, t);
-    else hipLaunchKernelGGL ((k_cs_cubic_dot<4>), dim3 ((unsigned) (8 * t.n_chunk)), dim3 (512), 0, s, t);
+    if (opaque && t.fast_nv12 && !(t.cs.in_w & 7)) hipLaunchKernelGGL ((k_cs_cubic_dot<3, true>), dim3 ((unsigned) (8 * t.n_chunk)), dim3 (512), 0, s, t);
+    else if (opaque) hipLaunchKernelGGL ((k_cs_cubic_dot<3, false>), dim3 ((unsigned) (8 * t.n_chunk)), dim3 (512), 0, s, t);
+    else hipLaunchKernelGGL ((k_cs_cubic_dot<4, false>), dim3 ((unsigned) (8 * t.n_chunk)), dim3 (512), 0, s, t);
     VFHIP_CHECK_HIP (hipGetLastError ());
     return VFHIP_OK;
   }

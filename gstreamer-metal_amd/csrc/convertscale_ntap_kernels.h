@@ -500,8 +500,10 @@ __device__ __forceinline__ void cd_vwin4 (const uint8_t *plane, int stride, int 
 // (i + .5) * fl (1 / d) is off by < 1e-4 there and (i + .5) / d is at least .5 / d away from every integer
 __device__ __forceinline__ int cd_div (int i, float inv) { return (int) (((float) i + 0.5f) * inv); }
 
-template <int NCH>
-__global__ __launch_bounds__ (512, NCH == 3 ? 8 : 6) void k_cs_cubic_dot (const CubicDotParams p)
+// ONLY_FAST (host: NV12 through the packed pipeline and in_w % 8 == 0, so that every 8-pixel group is inside the frame or outside it): the instantiation
+// without cs_tap's general conversion — with both in one kernel the lane index spilled to scratch at 64 VGPRs (four workgroups per CU)
+template <int NCH, bool ONLY_FAST>
+__global__ __launch_bounds__ (512, ONLY_FAST ? 8 : 6) void k_cs_cubic_dot (const CubicDotParams p)
 {
   __shared__ __attribute__ ((aligned (16))) uint8_t P1[NCH][CD_RH * CD_RW + 16];    // converted region, one plane per channel (byte order of the output pixel)
   __shared__ __attribute__ ((aligned (16))) uint8_t P2[NCH][CD_P2 + 16];            // first-pass result
@@ -539,7 +541,7 @@ __global__ __launch_bounds__ (512, NCH == 3 ? 8 : 6) void k_cs_cubic_dot (const 
   auto convert = [&] (auto cosited_tag) {
     constexpr bool COS = decltype (cosited_tag)::value;
     auto where = [&] (int i, int &ry, int &g, int &gx, int &cy) { ry = cd_div (i, inv_groups); g = i - ry * groups; gx = ga + 8 * g; cy = ry0 + ry; };
-    auto is_fast = [&] (int gx, int cy) { return NCH == 3 && p.fast_nv12 && cy < p.cs.in_h && gx + 8 <= p.cs.in_w; };
+    auto is_fast = [&] (int gx, int cy) { return NCH == 3 && (ONLY_FAST || p.fast_nv12) && cy < p.cs.in_h && gx + 8 <= p.cs.in_w; };
     int i = tid, ry = 0, g = 0, gx = 0, cy = 0;
     Cv8Raw cur {};
     if (i < n_items) { where (i, ry, g, gx, cy); if (is_fast (gx, cy)) cur = cs_load8_nv12<COS> (p.cs, in, gx, cy); }
@@ -550,7 +552,7 @@ __global__ __launch_bounds__ (512, NCH == 3 ? 8 : 6) void k_cs_cubic_dot (const 
       if (in_ < n_items) { where (in_, nry, ng, ngx, ncy); if (is_fast (ngx, ncy)) nxt = cs_load8_nv12<COS> (p.cs, in, ngx, ncy); }
       if (cy < p.cs.in_h && gx < p.cs.in_w) {
         uint32_t lo[4], hi[4];
-        if (is_fast (gx, cy)) cs_convert8_nv12_planar<COS> (p.cs, cur, lo, hi);
+        if (ONLY_FAST || is_fast (gx, cy)) cs_convert8_nv12_planar<COS> (p.cs, cur, lo, hi);
         else {
           uint32_t px8[8];
 #pragma unroll 1

@@ -15,6 +15,8 @@ using namespace vfhip;
 
 namespace vfhip {
 
+typedef float f2 __attribute__ ((ext_vector_type (2)));
+
 struct DeintParams {
   metal::Img cur, prev;      // prev.p[0] == nullptr: no history
   metal::OutImg out;
@@ -174,66 +176,96 @@ __global__ __launch_bounds__ (256) void k_deinterlace_420 (const DeintParams pp)
 // k_deinterlace_420q.  Same values as the kernels above (and as the reference's three passes), organised for the
 // machine: a lane owns FOUR adjacent pixels (one dword of luma, two chroma columns) and walks a strip of rows in pairs.
 //   * The reference's 8-bit RGBA intermediate lives in registers as the float an 8-bit texel reads back as — byte / 255
-//     with the byte obtained by x255, round-to-nearest-even (`quantf`) — so nothing is packed to bytes and unpacked again
+//     with the byte obtained by x255, round-to-nearest-even (`quant2`) — so nothing is packed to bytes and unpacked again
 //     between the input pass, the method pass and the RGB -> YUV pass (each row used to be unpacked up to three times).
-//   * Every source row is converted once per strip and carried as the above / below tap of its neighbours.
+//   * Every source row is converted once per strip and carried as the above / below tap of its neighbours; the chroma of a
+//     row pair is converted once (the two rows of a 4:2:0 pair read the same chroma row).
+//   * The arithmetic is PACKED f32 (v_pk_mul / add / fma_f32: two lanes' worth in ~3.9 issue cycles against 2 x 2.2, and a third
+//     fewer instructions to fetch and schedule; the kernel sits at 0.96 VALU issue share, profiles/r03ad_deint_pmc.txt): the
+//     four pixels are held as the pairs (0, 2) and (1, 3), so that both pairs take the lane's two chroma samples (u0, u1) as
+//     they are, and the 2x2 chroma means of the output come out of the same packed adds in the reference's summation order.
+//     Each float operation is the one the scalar code made, on the same operands: the results are bit-identical.  Three
+//     products by powers of two are folded where that is exact: (a + b) * 0.5 * 255 == (a + b) * 127.5 and
+//     (k * (s * 0.25)) + c == fma (k * s, 0.25, c) (scaling by 2^-n commutes with rounding away from the denormals).
 //   * greedy-H compares the squared distance with the smallest float whose correctly rounded square root reaches the
 //     threshold (computed on the host: `motion2_limit`), which decides exactly like sqrt (d2) < threshold without the
 //     square root.
 //   * Dword loads / stores on luma and on NV12 chroma, 32-bit offsets from wave-uniform plane bases.
-struct Rgb4 { float r[4], g[4], b[4]; };
-// the two matrices of metal_common.h as wave-uniform coefficient sets (selected once per kernel: no per-pixel branch on m709)
-struct YuvCoef { float rv, gu, gv, bu; };
-struct RgbCoef { float yr, yg, yb, ur, ug, ub, vr, vg, vb; };
-__device__ __forceinline__ YuvCoef yuv_coef (int m709)
+struct Rgb4 { f2 r[2], g[2], b[2]; };                    // [0]: pixels 0 and 2 of the lane's four, [1]: pixels 1 and 3
+struct Chroma2 { f2 u, v; };                             // cb - 128/255, cr - 128/255 of the lane's two chroma columns
+// the two matrices of metal_common.h as wave-uniform coefficient sets, filled in by the host and passed as kernel arguments: they
+// arrive in SGPRs (the coefficients of the clamped fmas as aligned pairs { k, k }, which v_pk_fma_f32 takes as its one scalar operand;
+// coefficients selected inside the kernel ended up as splat VGPR pairs: 30 VGPRs of loop invariants)
+struct YuvCoef { f2 rv, gv, bu; float gu, pad; };
+struct RgbCoef { float yr, yg, yb, ur, ug, ub, vr, vg, vb, pad; };
+struct DeintCoefs { YuvCoef cur, prev; RgbCoef out; };
+static YuvCoef yuv_coef (int m709)
 {
-  YuvCoef k;
-  k.rv = m709 ? 1.792741f : 1.596027f; k.gu = m709 ? -0.213249f : -0.391762f; k.gv = m709 ? -0.532909f : -0.812968f; k.bu = m709 ? 2.112402f : 2.017232f;
+  YuvCoef k {};
+  const float rv = m709 ? 1.792741f : 1.596027f, gv = m709 ? -0.532909f : -0.812968f, bu = m709 ? 2.112402f : 2.017232f;
+  k.rv = f2 { rv, rv }; k.gv = f2 { gv, gv }; k.bu = f2 { bu, bu }; k.gu = m709 ? -0.213249f : -0.391762f;
   return k;
 }
-__device__ __forceinline__ RgbCoef rgb_coef (int m709)
+static RgbCoef rgb_coef (int m709)
 {
-  RgbCoef k;
+  RgbCoef k {};
   k.yr = m709 ? 0.182586f : 0.256788f; k.yg = m709 ? 0.614231f : 0.504129f; k.yb = m709 ? 0.062007f : 0.097906f;
   k.ur = m709 ? -0.100644f : -0.148223f; k.ug = m709 ? -0.338572f : -0.290993f; k.ub = 0.439216f;
   k.vr = 0.439216f; k.vg = m709 ? -0.398942f : -0.367788f; k.vb = m709 ? -0.040274f : -0.071427f;
   return k;
 }
 
-__device__ __forceinline__ float quantf01 (float x)      // what an 8-bit unorm texel written with x in [0, 1] reads back as
+__device__ __forceinline__ f2 splat2 (float x) { return f2 { x, x }; }
+__device__ __forceinline__ f2 rint2 (f2 x) { return f2 { __builtin_rintf (x.x), __builtin_rintf (x.y) }; }
+__device__ __forceinline__ f2 fma2 (f2 a, f2 b, f2 c) { return __builtin_elementwise_fma (a, b, c); }
+// what an 8-bit unorm texel written with x in [0, 1] reads back as
+__device__ __forceinline__ f2 quant2 (f2 x) { return rint2 (x * 255.0f) * (1.0f / 255.0f); }
+// clamp01 (fmaf (a, b, c)) in ONE instruction: the clamp output modifier saturates the correctly rounded fma result to [0, 1]
+// (the compiler emits fma + v_max ... clamp: a fifth of the scalar kernel's instructions were such clamps)
+__device__ __forceinline__ f2 fma_sat2 (f2 a, f2 b, f2 c)      // a: wave-uniform coefficient { k, k } in an SGPR pair
 {
-  return __builtin_rintf (x * 255.0f) * (1.0f / 255.0f);
-}
-// clamp01 (fmaf (a, b, c)) in ONE instruction: the clamp output modifier of v_fma_f32 saturates the correctly rounded fma result
-// to [0, 1] (the compiler emits fma + v_max ... clamp: a fifth of this kernel's instructions were such clamps)
-__device__ __forceinline__ float fma_sat (float a, float b, float c)
-{
-  float d;
-  asm ("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  f2 d;
+  asm ("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "s"(a), "v"(b), "v"(c));
   return d;
 }
 
-template <bool PLANAR>
-__device__ __forceinline__ Rgb4 deint_row4 (const uint8_t *yp, const uint8_t *up, const uint8_t *vp, uint32_t ys, uint32_t cs, const YuvCoef &k, uint32_t q, int y)
+// raw loads: one dword of luma (four pixels), the lane's two chroma columns of row y >> 1 as one dword
+// (NV12: U0 V0 U1 V1; planar: U0 U1 V0 V1)
+__device__ __forceinline__ uint32_t deint_luma4 (const uint8_t *yp, uint32_t ys, uint32_t q, int y)
 {
-  const uint32_t Y4 = *reinterpret_cast<const uint32_t *> (yp + (__umul24 ((uint32_t) y, ys) + 4u * q));
-  uint32_t U0, V0, U1, V1;
+  return *reinterpret_cast<const uint32_t *> (yp + (__umul24 ((uint32_t) y, ys) + 4u * q));
+}
+template <bool PLANAR>
+__device__ __forceinline__ uint32_t deint_chroma4 (const uint8_t *up, const uint8_t *vp, uint32_t cs, uint32_t q, int y)
+{
   if (PLANAR) {
     const uint32_t co = __umul24 ((uint32_t) (y >> 1), cs) + 2u * q;
-    const uint32_t u2 = *reinterpret_cast<const uint16_t *> (up + co), v2 = *reinterpret_cast<const uint16_t *> (vp + co);
-    U0 = u2 & 0xffu; U1 = u2 >> 8; V0 = v2 & 0xffu; V1 = v2 >> 8;
-  } else {
-    const uint32_t c4 = *reinterpret_cast<const uint32_t *> (up + (__umul24 ((uint32_t) (y >> 1), cs) + 4u * q));
-    U0 = c4 & 0xffu; V0 = (c4 >> 8) & 0xffu; U1 = (c4 >> 16) & 0xffu; V1 = c4 >> 24;
+    return (uint32_t) *reinterpret_cast<const uint16_t *> (up + co) | ((uint32_t) *reinterpret_cast<const uint16_t *> (vp + co) << 16);
   }
-  const float cb[2] = { metal::un8 (U0), metal::un8 (U1) }, cr[2] = { metal::un8 (V0), metal::un8 (V1) };
+  return *reinterpret_cast<const uint32_t *> (up + (__umul24 ((uint32_t) (y >> 1), cs) + 4u * q));
+}
+template <bool PLANAR>
+__device__ __forceinline__ Chroma2 deint_chroma2 (uint32_t c4)
+{
+  f2 cb, cr;
+  if (PLANAR) { cb = f2 { (float) (c4 & 0xffu), (float) ((c4 >> 8) & 0xffu) }; cr = f2 { (float) ((c4 >> 16) & 0xffu), (float) (c4 >> 24) }; }
+  else { cb = f2 { (float) (c4 & 0xffu), (float) ((c4 >> 16) & 0xffu) }; cr = f2 { (float) ((c4 >> 8) & 0xffu), (float) (c4 >> 24) }; }
+  Chroma2 c;
+  c.u = cb * (1.0f / 255.0f) - 128.0f / 255.0f; c.v = cr * (1.0f / 255.0f) - 128.0f / 255.0f;      // metal::un8, then yuv_to_rgb's offsets
+  return c;
+}
+
+__device__ __forceinline__ Rgb4 deint_row4 (uint32_t Y4, const Chroma2 &c, const YuvCoef &k)
+{
+  const f2 yb[2] = { f2 { (float) (Y4 & 0xffu), (float) ((Y4 >> 16) & 0xffu) }, f2 { (float) ((Y4 >> 8) & 0xffu), (float) (Y4 >> 24) } };
   Rgb4 o;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < 2; i++) {
     // metal::yuv_to_rgb with the coefficients in registers (same operations, same order)
-    const float ly = 1.164383f * (metal::un8 ((Y4 >> (8 * i)) & 0xffu) - 16.0f / 255.0f);
-    const float u = cb[i >> 1] - 128.0f / 255.0f, v = cr[i >> 1] - 128.0f / 255.0f;
-    o.r[i] = quantf01 (fma_sat (k.rv, v, ly)); o.g[i] = quantf01 (fma_sat (k.gv, v, fmaf (k.gu, u, ly))); o.b[i] = quantf01 (fma_sat (k.bu, u, ly));
+    const f2 ly = 1.164383f * (yb[i] * (1.0f / 255.0f) - 16.0f / 255.0f);
+    o.r[i] = quant2 (fma_sat2 (k.rv, c.v, ly));
+    o.g[i] = quant2 (fma_sat2 (k.gv, c.v, fma2 (splat2 (k.gu), c.u, ly)));
+    o.b[i] = quant2 (fma_sat2 (k.bu, c.u, ly));
   }
   return o;
 }
@@ -245,106 +277,154 @@ __device__ __forceinline__ void deint_store4 (const metal::OutImg &o, const RgbC
 {
   uint32_t l0 = 0, l1 = 0;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    // metal::rgb_to_yuv (luma row), coefficients in registers
-    const float Y0 = fmaf (k.yb, o0.b[i], fmaf (k.yg, o0.g[i], k.yr * o0.r[i])) + 16.0f / 255.0f;
-    const float Y1 = fmaf (k.yb, o1.b[i], fmaf (k.yg, o1.g[i], k.yr * o1.r[i])) + 16.0f / 255.0f;
-    l0 = __builtin_amdgcn_cvt_pk_u8_f32 (Y0 * 255.0f, (uint32_t) i, l0);
-    l1 = __builtin_amdgcn_cvt_pk_u8_f32 (Y1 * 255.0f, (uint32_t) i, l1);
+  for (int i = 0; i < 2; i++) {
+    // metal::rgb_to_yuv (luma row), coefficients in registers; pair i holds the bytes i and i + 2 of the dword
+    const f2 Y0 = (fma2 (splat2 (k.yb), o0.b[i], fma2 (splat2 (k.yg), o0.g[i], k.yr * o0.r[i])) + 16.0f / 255.0f) * 255.0f;
+    const f2 Y1 = (fma2 (splat2 (k.yb), o1.b[i], fma2 (splat2 (k.yg), o1.g[i], k.yr * o1.r[i])) + 16.0f / 255.0f) * 255.0f;
+    l0 = __builtin_amdgcn_cvt_pk_u8_f32 (Y0.x, (uint32_t) i, l0); l0 = __builtin_amdgcn_cvt_pk_u8_f32 (Y0.y, (uint32_t) i + 2u, l0);
+    l1 = __builtin_amdgcn_cvt_pk_u8_f32 (Y1.x, (uint32_t) i, l1); l1 = __builtin_amdgcn_cvt_pk_u8_f32 (Y1.y, (uint32_t) i + 2u, l1);
   }
   const uint32_t lo = __umul24 ((uint32_t) y, (uint32_t) o.s[0]) + 4u * q;
   __builtin_nontemporal_store (l0, reinterpret_cast<uint32_t *> (o.p[0] + lo));
   __builtin_nontemporal_store (l1, reinterpret_cast<uint32_t *> (o.p[0] + (lo + (uint32_t) o.s[0])));
-  uint32_t uu[2], vv[2];
-#pragma unroll
-  for (int c = 0; c < 2; c++) {
-    float sr = 0.0f, sg = 0.0f, sb = 0.0f;
-    sr += o0.r[2 * c]; sg += o0.g[2 * c]; sb += o0.b[2 * c];
-    sr += o0.r[2 * c + 1]; sg += o0.g[2 * c + 1]; sb += o0.b[2 * c + 1];
-    sr += o1.r[2 * c]; sg += o1.g[2 * c]; sb += o1.b[2 * c];
-    sr += o1.r[2 * c + 1]; sg += o1.g[2 * c + 1]; sb += o1.b[2 * c + 1];
-    sr *= 0.25f; sg *= 0.25f; sb *= 0.25f;
-    const float U = fmaf (k.ub, sb, fmaf (k.ug, sg, k.ur * sr)) + 128.0f / 255.0f;
-    const float V = fmaf (k.vb, sb, fmaf (k.vg, sg, k.vr * sr)) + 128.0f / 255.0f;
-    uu[c] = metal::quant8 (U); vv[c] = metal::quant8 (V);
-  }
+  // the two 2x2 blocks at once: ((row0 left + row0 right) + row1 left) + row1 right, x 0.25 folded into the last fma
+  const f2 sr = ((o0.r[0] + o0.r[1]) + o1.r[0]) + o1.r[1], sg = ((o0.g[0] + o0.g[1]) + o1.g[0]) + o1.g[1], sb = ((o0.b[0] + o0.b[1]) + o1.b[0]) + o1.b[1];
+  const f2 U = fma2 (fma2 (splat2 (k.ub), sb, fma2 (splat2 (k.ug), sg, k.ur * sr)), splat2 (0.25f), splat2 (128.0f / 255.0f)) * 255.0f;
+  const f2 V = fma2 (fma2 (splat2 (k.vb), sb, fma2 (splat2 (k.vg), sg, k.vr * sr)), splat2 (0.25f), splat2 (128.0f / 255.0f)) * 255.0f;
   if (PLANAR) {
+    uint32_t uu = __builtin_amdgcn_cvt_pk_u8_f32 (U.x, 0u, 0u), vv = __builtin_amdgcn_cvt_pk_u8_f32 (V.x, 0u, 0u);
+    uu = __builtin_amdgcn_cvt_pk_u8_f32 (U.y, 1u, uu); vv = __builtin_amdgcn_cvt_pk_u8_f32 (V.y, 1u, vv);
     const uint32_t co = __umul24 ((uint32_t) (y >> 1), (uint32_t) o.s[1]) + 2u * q;
-    *reinterpret_cast<uint16_t *> (o.p[1] + co) = (uint16_t) (uu[0] | (uu[1] << 8));
-    *reinterpret_cast<uint16_t *> (o.p[2] + (__umul24 ((uint32_t) (y >> 1), (uint32_t) o.s[2]) + 2u * q)) = (uint16_t) (vv[0] | (vv[1] << 8));
+    *reinterpret_cast<uint16_t *> (o.p[1] + co) = (uint16_t) uu;
+    *reinterpret_cast<uint16_t *> (o.p[2] + (__umul24 ((uint32_t) (y >> 1), (uint32_t) o.s[2]) + 2u * q)) = (uint16_t) vv;
   } else {
+    uint32_t c4 = __builtin_amdgcn_cvt_pk_u8_f32 (U.x, 0u, 0u);
+    c4 = __builtin_amdgcn_cvt_pk_u8_f32 (V.x, 1u, c4); c4 = __builtin_amdgcn_cvt_pk_u8_f32 (U.y, 2u, c4); c4 = __builtin_amdgcn_cvt_pk_u8_f32 (V.y, 3u, c4);
     const uint32_t co = __umul24 ((uint32_t) (y >> 1), (uint32_t) o.s[1]) + 4u * q;
-    __builtin_nontemporal_store (uu[0] | (vv[0] << 8) | (uu[1] << 16) | (vv[1] << 24), reinterpret_cast<uint32_t *> (o.p[1] + co));
+    __builtin_nontemporal_store (c4, reinterpret_cast<uint32_t *> (o.p[1] + co));
   }
 }
 
-// the reconstructed line: own pixel `cur`, its neighbours in the kept field, the previous frame's pixel
+// greedy-H's motion test of the lane's four pixels (bit k: pixel k of the pairs' order 0, 2, 1, 3 has NOT moved against the
+// previous frame: weave it)
+struct Still4 { bool s[2][2]; };
+__device__ __forceinline__ Still4 deint_still4 (const Rgb4 &cur, const Rgb4 &prev, float m2_limit)
+{
+  Still4 st;
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const f2 dr = cur.r[i] - prev.r[i], dg = cur.g[i] - prev.g[i], db = cur.b[i] - prev.b[i];
+    const f2 d2 = (dr * dr + dg * dg) + db * db;
+    st.s[i][0] = d2.x < m2_limit; st.s[i][1] = d2.y < m2_limit;
+  }
+  return st;
+}
+// the reconstructed line from its neighbours in the kept field (bob) and the previous frame's pixel (weave / still pixels of greedy-H)
 template <int METHOD>
-__device__ __forceinline__ Rgb4 deint_recon4 (const Rgb4 &cur, const Rgb4 &above, const Rgb4 &below, const Rgb4 &prev, float m2_limit)
+__device__ __forceinline__ Rgb4 deint_recon4 (const Still4 &st, const Rgb4 &above, const Rgb4 &below, const Rgb4 &prev)
 {
   if (METHOD == VFHIP_DEINTERLACE_WEAVE) return prev;
   Rgb4 o;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    // the mean of two texel values is inside [0, 1]: no clamp
-    const float br = quantf01 ((above.r[i] + below.r[i]) * 0.5f), bg = quantf01 ((above.g[i] + below.g[i]) * 0.5f), bb = quantf01 ((above.b[i] + below.b[i]) * 0.5f);
-    bool still = false;                                   // greedy-H: no motion against the previous frame -> weave (selects, no divergent branch)
-    if (METHOD == VFHIP_DEINTERLACE_GREEDYH) {
-      const float dr = cur.r[i] - prev.r[i], dg = cur.g[i] - prev.g[i], db = cur.b[i] - prev.b[i];
-      still = dr * dr + dg * dg + db * db < m2_limit;
+  for (int i = 0; i < 2; i++) {
+    // the mean of two texel values is inside [0, 1]: no clamp.  (a + b) * 0.5 * 255 == (a + b) * 127.5 exactly.
+    const f2 br = rint2 ((above.r[i] + below.r[i]) * 127.5f) * (1.0f / 255.0f), bg = rint2 ((above.g[i] + below.g[i]) * 127.5f) * (1.0f / 255.0f),
+             bb = rint2 ((above.b[i] + below.b[i]) * 127.5f) * (1.0f / 255.0f);
+    if (METHOD == VFHIP_DEINTERLACE_GREEDYH) {      // selects, no divergent branch
+      const bool s0 = st.s[i][0], s1 = st.s[i][1];
+      o.r[i] = f2 { s0 ? prev.r[i].x : br.x, s1 ? prev.r[i].y : br.y };
+      o.g[i] = f2 { s0 ? prev.g[i].x : bg.x, s1 ? prev.g[i].y : bg.y };
+      o.b[i] = f2 { s0 ? prev.b[i].x : bb.x, s1 ? prev.b[i].y : bb.y };
+    } else {
+      o.r[i] = br; o.g[i] = bg; o.b[i] = bb;
     }
-    o.r[i] = still ? prev.r[i] : br; o.g[i] = still ? prev.g[i] : bg; o.b[i] = still ? prev.b[i] : bb;
   }
   return o;
 }
 
-constexpr int DEINTQ_ROWS = 8;
+constexpr int DEINTQ_ROWS = 8;      // rows per lane for one frame (batches: 16 / 32, deint_launch)
+
+// one lane's strip.  HIST (wave-uniform, decided outside the row loop so that the loop body is straight-line code): false = frame 0
+// of a stream (or of a batch on a fresh handle), which has no history — weave / greedy-H fall back to bob for that frame only,
+// the rest of the batch uses its predecessor in the batch.
+// The loop is software-pipelined by hand: the (up to five) dwords a row pair needs are loaded one iteration ahead, right after
+// the previous pair's have been converted, so that their latency is covered by this lane's own arithmetic and not only by the
+// other waves of the SIMD (rows past the frame are clamped: a load too many per strip, never a branch).
+template <bool PLANAR, bool TFF, int METHOD, bool HIST>
+__device__ __forceinline__ void deint_strip (const DeintParams &p, const DeintCoefs &kk, uint32_t q, int y0, int yend, float m2_limit)
+{
+  constexpr int M = (METHOD == VFHIP_DEINTERLACE_WEAVE || METHOD == VFHIP_DEINTERLACE_GREEDYH) && !HIST ? VFHIP_DEINTERLACE_BOB : METHOD;
+  constexpr bool NEED_PREV = M == VFHIP_DEINTERLACE_WEAVE || M == VFHIP_DEINTERLACE_GREEDYH;
+  constexpr bool GREEDY = M == VFHIP_DEINTERLACE_GREEDYH;
+  const int h = p.out.h;
+  const uint8_t *cy = p.cur.p[0], *cu = p.cur.p[1], *cv = p.cur.p[2];
+  const uint8_t *py = p.prev.p[0], *pu = p.prev.p[1], *pv = p.prev.p[2];
+  const uint32_t ys = (uint32_t) p.cur.s[0], cs = (uint32_t) p.cur.s[1], pys = (uint32_t) p.prev.s[0], pcs = (uint32_t) p.prev.s[1];
+  const YuvCoef &kc = kk.cur, &kp = kk.prev;
+  const RgbCoef &ko = kk.out;
+  // TFF: even rows are kept, odd rows reconstructed from the kept rows above (y) and below (y + 2);
+  // BFF: odd rows are kept, even rows reconstructed from the kept rows above (y - 1) and below (y + 1).
+  // y0 and y are even: rows y and y + 1 share chroma row y >> 1.
+  // per row pair: `t` = the reconstructed row itself (only greedy-H's motion test reads it), `k` = the kept row that enters the
+  // pair new (TFF: below, y + 2; BFF: y + 1), `pr` = row t of the previous frame; chroma comes with k (TFF) or t (BFF) and with pr
+  uint32_t y_t = 0, y_k = 0, c_k = 0, y_p = 0, c_p = 0;
+  auto fetch = [&] (int y) {
+    const int rt = min (TFF ? y + 1 : y, h - 1), rk = min (TFF ? y + 2 : y + 1, h - 1);
+    if (GREEDY) y_t = deint_luma4 (cy, ys, q, rt);
+    y_k = deint_luma4 (cy, ys, q, rk);
+    c_k = deint_chroma4<PLANAR> (cu, cv, cs, q, rk);
+    if (NEED_PREV) { y_p = deint_luma4 (py, pys, q, rt); c_p = deint_chroma4<PLANAR> (pu, pv, pcs, q, rt); }
+  };
+  const int yc = TFF ? y0 : max (y0 - 1, 0);
+  const uint32_t y_c = deint_luma4 (cy, ys, q, yc), c_c = deint_chroma4<PLANAR> (cu, cv, cs, q, yc);
+  fetch (y0);
+  Chroma2 cc = deint_chroma2<PLANAR> (c_c);
+  Rgb4 ra = deint_row4 (y_c, cc, kc);
+  // one row pair: `above` = the kept row over the reconstructed one (it came in with the pair before), `kept` = the one this pair brings
+  auto pair = [&] (int y, const Rgb4 &above, Rgb4 &kept) {
+    Rgb4 prev {};
+    Still4 st {};
+    // (the scheduling barriers keep the three row conversions from being interleaved: one at a time they fit in 68 VGPRs, seven waves per SIMD)
+    if (NEED_PREV) prev = deint_row4 (y_p, deint_chroma2<PLANAR> (c_p), kp);
+    __builtin_amdgcn_sched_barrier (0);
+    if (TFF) {
+      if (GREEDY) st = deint_still4 (deint_row4 (y_t, cc, kc), prev, m2_limit);          // row y + 1 shares the chroma of row y
+      cc = deint_chroma2<PLANAR> (c_k);
+    } else {
+      cc = deint_chroma2<PLANAR> (c_k);
+      if (GREEDY) st = deint_still4 (deint_row4 (y_t, cc, kc), prev, m2_limit);
+    }
+    __builtin_amdgcn_sched_barrier (0);
+    kept = deint_row4 (y_k, cc, kc);
+    __builtin_amdgcn_sched_barrier (0);
+    fetch (y + 2);
+    const Rgb4 rec = deint_recon4<M> (st, above, kept, prev);
+    __builtin_amdgcn_sched_barrier (0);
+    if (TFF) deint_store4<PLANAR> (p.out, ko, q, y, above, rec);
+    else deint_store4<PLANAR> (p.out, ko, q, y, rec, kept);
+  };
+  // two pairs per trip: the kept row changes hands between `ra` and `rb` instead of being copied (six 64-bit moves per pair)
+  Rgb4 rb;
+  for (int y = y0; y < yend; y += 4) {
+    pair (y, ra, rb);
+    if (y + 2 >= yend) break;
+    pair (y + 2, rb, ra);
+  }
+}
 
 template <bool PLANAR, bool TFF, int METHOD>
-__global__ __launch_bounds__ (256) void k_deinterlace_420q (const DeintParams pp, float m2_limit)
+__global__ __launch_bounds__ (256) void k_deinterlace_420q (const DeintParams pp, const DeintCoefs kk, float m2_limit, int rows)
 {
   const DeintParams p = deint_frame (pp, blockIdx.y);
   const int quads = p.out.w >> 2, h = p.out.h;
-  const int strips = (h + DEINTQ_ROWS - 1) / DEINTQ_ROWS;
+  const int strips = (h + rows - 1) / rows;
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= quads * strips) return;
   const int strip = t / quads;
   const uint32_t q = (uint32_t) (t - strip * quads);
-  const int y0 = strip * DEINTQ_ROWS, yend = min (y0 + DEINTQ_ROWS, h);
-  constexpr bool NEED_PREV = METHOD == VFHIP_DEINTERLACE_WEAVE || METHOD == VFHIP_DEINTERLACE_GREEDYH;
-  // frame 0 of a stream (or of a batch on a fresh handle) has no history: weave / greedy-H fall back to bob for that frame
-  // only (wave-uniform: blockIdx.y picks the frame), the rest of the batch uses its predecessor in the batch
-  const bool hist = p.prev.p[0] != nullptr;
-  const uint8_t *cy = p.cur.p[0], *cu = p.cur.p[1], *cv = p.cur.p[2];
-  const uint8_t *py = p.prev.p[0], *pu = p.prev.p[1], *pv = p.prev.p[2];
-  const uint32_t ys = (uint32_t) p.cur.s[0], cs = (uint32_t) p.cur.s[1], pys = (uint32_t) p.prev.s[0], pcs = (uint32_t) p.prev.s[1];
-  const YuvCoef kc = yuv_coef (p.cur.m709), kp = yuv_coef (p.prev.m709);
-  const RgbCoef ko = rgb_coef (p.out.m709);
-  // TFF: even rows are kept, odd rows reconstructed from the kept rows above (y) and below (y + 2);
-  // BFF: odd rows are kept, even rows reconstructed from the kept rows above (y - 1) and below (y + 1).
-  Rgb4 carry = deint_row4<PLANAR> (cy, cu, cv, ys, cs, kc, q, TFF ? y0 : max (y0 - 1, 0));
-  for (int y = y0; y < yend; y += 2) {
-    Rgb4 prev {};
-    if (TFF) {
-      Rgb4 cur {};
-      if (METHOD == VFHIP_DEINTERLACE_GREEDYH && hist) cur = deint_row4<PLANAR> (cy, cu, cv, ys, cs, kc, q, y + 1);      // only the motion test reads it
-      const Rgb4 below = deint_row4<PLANAR> (cy, cu, cv, ys, cs, kc, q, min (y + 2, h - 1));
-      if (NEED_PREV && hist) prev = deint_row4<PLANAR> (py, pu, pv, pys, pcs, kp, q, y + 1);
-      const Rgb4 rec = (!NEED_PREV || hist) ? deint_recon4<METHOD> (cur, carry, below, prev, m2_limit)
-                                            : deint_recon4<VFHIP_DEINTERLACE_BOB> (cur, carry, below, prev, m2_limit);
-      deint_store4<PLANAR> (p.out, ko, q, y, carry, rec);
-      carry = below;
-    } else {
-      Rgb4 cur {};
-      if (METHOD == VFHIP_DEINTERLACE_GREEDYH && hist) cur = deint_row4<PLANAR> (cy, cu, cv, ys, cs, kc, q, y);
-      const Rgb4 kept = deint_row4<PLANAR> (cy, cu, cv, ys, cs, kc, q, y + 1);
-      if (NEED_PREV && hist) prev = deint_row4<PLANAR> (py, pu, pv, pys, pcs, kp, q, y);
-      const Rgb4 rec = (!NEED_PREV || hist) ? deint_recon4<METHOD> (cur, carry, kept, prev, m2_limit)
-                                            : deint_recon4<VFHIP_DEINTERLACE_BOB> (cur, carry, kept, prev, m2_limit);
-      deint_store4<PLANAR> (p.out, ko, q, y, rec, kept);
-      carry = kept;
-    }
-  }
+  const int y0 = strip * rows, yend = min (y0 + rows, h);
+  if (METHOD == VFHIP_DEINTERLACE_BOB || p.prev.p[0] != nullptr) deint_strip<PLANAR, TFF, METHOD, true> (p, kk, q, y0, yend, m2_limit);
+  else deint_strip<PLANAR, TFF, METHOD, false> (p, kk, q, y0, yend, m2_limit);
 }
 
 }  // namespace vfhip
@@ -413,11 +493,19 @@ static int deint_launch (VfHipDeinterlace *h, const VfHipFrame *cur, const VfHip
     int method = p.method;
     if ((method == VFHIP_DEINTERLACE_WEAVE || method == VFHIP_DEINTERLACE_GREEDYH) && !p.prev.p[0] && n_frames == 1) method = VFHIP_DEINTERLACE_BOB;   // no history at all
     if (method == VFHIP_DEINTERLACE_LINEAR) method = VFHIP_DEINTERLACE_BOB;                    // the reference's linear IS bob (shaders.h:134-148)
-    const int strips = (h->info.height + DEINTQ_ROWS - 1) / DEINTQ_ROWS;
+    // rows per lane: a strip starts with one row conversion of its own (the row above it), so longer strips do less work, and a batch
+    // that fills the chip many times over can afford half as many lanes (a single frame cannot: 1080p in 8-row strips is 1012 waves)
+    static const int rows_env = [] { const char *e = getenv ("VFHIP_DEINT_ROWS"); return e ? atoi (e) : 0; } ();      // A/B knob (even, >= 2)
+    const size_t lanes8 = (size_t) (h->info.width / 4) * ((h->info.height + DEINTQ_ROWS - 1) / DEINTQ_ROWS) * (size_t) n_frames;
+    int rows = lanes8 >= ((size_t) 1 << 24) ? 4 * DEINTQ_ROWS : lanes8 >= ((size_t) 1 << 21) ? 2 * DEINTQ_ROWS : DEINTQ_ROWS;
+    if (rows_env >= 2 && !(rows_env & 1)) rows = rows_env;
+    const int strips = (h->info.height + rows - 1) / rows;
     dim3 grid ((unsigned) (((size_t) (h->info.width / 4) * strips + 255) / 256), (unsigned) n_frames);
     const float lim = motion2_limit (p.threshold);
     const bool planar = h->info.format == VFHIP_FORMAT_I420;
-#define VF_DQ(PL, TF, M) hipLaunchKernelGGL ((k_deinterlace_420q<PL, TF, M>), grid, dim3 (256), 0, s, p, lim)
+    DeintCoefs kk {};
+    kk.cur = yuv_coef (p.cur.m709); kk.prev = yuv_coef (prev ? p.prev.m709 : p.cur.m709); kk.out = rgb_coef (p.out.m709);
+#define VF_DQ(PL, TF, M) hipLaunchKernelGGL ((k_deinterlace_420q<PL, TF, M>), grid, dim3 (256), 0, s, p, kk, lim, rows)
 #define VF_DQ_M(PL, TF) do { if (method == VFHIP_DEINTERLACE_BOB) VF_DQ (PL, TF, VFHIP_DEINTERLACE_BOB); else if (method == VFHIP_DEINTERLACE_WEAVE) VF_DQ (PL, TF, VFHIP_DEINTERLACE_WEAVE); \
                               else VF_DQ (PL, TF, VFHIP_DEINTERLACE_GREEDYH); } while (0)
     if (planar) { if (p.tff) VF_DQ_M (true, true); else VF_DQ_M (true, false); }
