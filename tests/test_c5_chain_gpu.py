@@ -150,3 +150,27 @@ def test_c5_chain_through_host_api(vfhip, metalref, oracle, stream4):
         prev = f
     d.close()
     cs.close()
+
+
+def test_deinterlace_strip_heights_identical():
+    """k_deinterlace_420q walks 8-row strips for a frame and 16 / 32-row strips for big batches (deint_launch): the strip height is a
+    speed matter only.  $VFHIP_DEINT_ROWS is read once per process, so each height runs tools/exp/deint_hash.py --quick (NV12 / I420,
+    both field orders, bob / weave / greedy-H, 1080p and sizes that leave partial strips) in a process of its own; the digests over
+    all output frames must be equal."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for rows in ("", "2", "16", "32"):
+        env = dict(os.environ)
+        env.pop("VFHIP_DEINT_ROWS", None)
+        if rows:
+            env["VFHIP_DEINT_ROWS"] = rows
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "exp", "deint_hash.py"), "--quick"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        m = re.search(r"frames (\d+) sha256 ([0-9a-f]{64})", r.stdout)
+        assert m and int(m.group(1)) > 100, r.stdout[-500:]
+        digests[rows or "default (8)"] = m.group(2)
+    assert len(set(digests.values())) == 1, digests
