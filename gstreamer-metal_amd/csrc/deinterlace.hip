@@ -15,7 +15,20 @@ using namespace vfhip;
 
 namespace vfhip {
 
+// k_deinterlace_420q's pixel pairs.  The product build evaluates them as two scalars; -DVFHIP_DQ_PACKED (A/B builds: tools/exp/build_variants.sh -f
+// deinterlace) as packed f32 (v_pk_mul / add / fma_f32) — byte-identical, and 4 % slower: see the kernel's header
+#ifdef VFHIP_DQ_PACKED
 typedef float f2 __attribute__ ((ext_vector_type (2)));
+#else
+struct f2 { float x, y; };
+__device__ __forceinline__ f2 operator+ (f2 a, f2 b) { return f2 { a.x + b.x, a.y + b.y }; }
+__device__ __forceinline__ f2 operator- (f2 a, f2 b) { return f2 { a.x - b.x, a.y - b.y }; }
+__device__ __forceinline__ f2 operator* (f2 a, f2 b) { return f2 { a.x * b.x, a.y * b.y }; }
+__device__ __forceinline__ f2 operator* (f2 a, float b) { return f2 { a.x * b, a.y * b }; }
+__device__ __forceinline__ f2 operator* (float a, f2 b) { return f2 { a * b.x, a * b.y }; }
+__device__ __forceinline__ f2 operator+ (f2 a, float b) { return f2 { a.x + b, a.y + b }; }
+__device__ __forceinline__ f2 operator- (f2 a, float b) { return f2 { a.x - b, a.y - b }; }
+#endif
 
 struct DeintParams {
   metal::Img cur, prev;      // prev.p[0] == nullptr: no history
@@ -180,13 +193,16 @@ __global__ __launch_bounds__ (256) void k_deinterlace_420 (const DeintParams pp)
 //     between the input pass, the method pass and the RGB -> YUV pass (each row used to be unpacked up to three times).
 //   * Every source row is converted once per strip and carried as the above / below tap of its neighbours; the chroma of a
 //     row pair is converted once (the two rows of a 4:2:0 pair read the same chroma row).
-//   * The arithmetic is PACKED f32 (v_pk_mul / add / fma_f32: two lanes' worth in ~3.9 issue cycles against 2 x 2.2, and a third
-//     fewer instructions to fetch and schedule; the kernel sits at 0.96 VALU issue share, profiles/r03ad_deint_pmc.txt): the
-//     four pixels are held as the pairs (0, 2) and (1, 3), so that both pairs take the lane's two chroma samples (u0, u1) as
-//     they are, and the 2x2 chroma means of the output come out of the same packed adds in the reference's summation order.
-//     Each float operation is the one the scalar code made, on the same operands: the results are bit-identical.  Three
-//     products by powers of two are folded where that is exact: (a + b) * 0.5 * 255 == (a + b) * 127.5 and
-//     (k * (s * 0.25)) + c == fma (k * s, 0.25, c) (scaling by 2^-n commutes with rounding away from the denormals).
+//   * The four pixels are held as the PAIRS (0, 2) and (1, 3): both pairs take the lane's two chroma samples (u0, u1) as they are, and the 2x2
+//     chroma means of the output come out of the same adds in the reference's summation order.  Each float operation is the one the reference's
+//     passes make, on the same operands; three products by powers of two are folded where that is exact: (a + b) * 0.5 * 255 == (a + b) * 127.5
+//     and (k * (s * 0.25)) + c == fma (k * s, 0.25, c) (scaling by 2^-n commutes with rounding away from the denormals).
+//   * Scalar f32, not packed: a pair evaluated with v_pk_mul / add / fma_f32 (-DVFHIP_DQ_PACKED) gives the same bytes with a third fewer
+//     instructions and is 4 % SLOWER.  The conversions and roundings in the stream (v_cvt_f32_ubyte, v_rndne_f32: 80 of ~400 per row pair) cost
+//     3.4 cycles next to packed instructions but ~2 when they alternate with scalar full-rate ones — they overlap
+//     (tools/ubench/valu_mix.hip, profiles/r03ah_valu_mix.txt) — and fp32 peak is the same for both forms (64 flop per cycle and SIMD).
+//   * The matrix coefficients come in as kernel arguments, filled in by the host (selected inside the kernel they ended up as 30 loop-invariant
+//     VGPRs in the packed build), and are moved to VGPRs once per lane (an SGPR operand halves a full-rate scalar instruction).
 //   * greedy-H compares the squared distance with the smallest float whose correctly rounded square root reaches the
 //     threshold (computed on the host: `motion2_limit`), which decides exactly like sqrt (d2) < threshold without the
 //     square root.
@@ -217,17 +233,39 @@ static RgbCoef rgb_coef (int m709)
 
 __device__ __forceinline__ f2 splat2 (float x) { return f2 { x, x }; }
 __device__ __forceinline__ f2 rint2 (f2 x) { return f2 { __builtin_rintf (x.x), __builtin_rintf (x.y) }; }
+#ifdef VFHIP_DQ_PACKED
 __device__ __forceinline__ f2 fma2 (f2 a, f2 b, f2 c) { return __builtin_elementwise_fma (a, b, c); }
+#else
+__device__ __forceinline__ f2 fma2 (f2 a, f2 b, f2 c) { return f2 { fmaf (a.x, b.x, c.x), fmaf (a.y, b.y, c.y) }; }
+#endif
 // what an 8-bit unorm texel written with x in [0, 1] reads back as
 __device__ __forceinline__ f2 quant2 (f2 x) { return rint2 (x * 255.0f) * (1.0f / 255.0f); }
 // clamp01 (fmaf (a, b, c)) in ONE instruction: the clamp output modifier saturates the correctly rounded fma result to [0, 1]
 // (the compiler emits fma + v_max ... clamp: a fifth of the scalar kernel's instructions were such clamps)
-__device__ __forceinline__ f2 fma_sat2 (f2 a, f2 b, f2 c)      // a: wave-uniform coefficient { k, k } in an SGPR pair
+__device__ __forceinline__ f2 fma_sat2 (f2 a, f2 b, f2 c)      // a: wave-uniform coefficient { k, k } (packed build: in an SGPR pair)
 {
   f2 d;
+#ifdef VFHIP_DQ_PACKED
   asm ("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "s"(a), "v"(b), "v"(c));
+#else
+  asm ("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d.x) : "v"(a.x), "v"(b.x), "v"(c.x));
+  asm ("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d.y) : "v"(a.x), "v"(b.y), "v"(c.y));
+#endif
   return d;
 }
+#ifndef VFHIP_DQ_PACKED
+// the coefficient sets in VGPRs: an SGPR operand halves a full-rate scalar instruction (tools/ubench/valu_occ.hip); packed ones take it for free
+__device__ __forceinline__ float dq_vgpr (float x) { float v; asm volatile ("v_mov_b32 %0, %1" : "=v"(v) : "s"(x)); return v; }
+__device__ __forceinline__ DeintCoefs coefs_in_vgprs (const DeintCoefs &k)
+{
+  DeintCoefs v = k;
+  YuvCoef *y[2] = { &v.cur, &v.prev };
+  for (int i = 0; i < 2; i++) { y[i]->rv.x = dq_vgpr (y[i]->rv.x); y[i]->gv.x = dq_vgpr (y[i]->gv.x); y[i]->bu.x = dq_vgpr (y[i]->bu.x); y[i]->gu = dq_vgpr (y[i]->gu); }
+  v.out.yr = dq_vgpr (k.out.yr); v.out.yg = dq_vgpr (k.out.yg); v.out.yb = dq_vgpr (k.out.yb); v.out.ur = dq_vgpr (k.out.ur); v.out.ug = dq_vgpr (k.out.ug);
+  v.out.ub = dq_vgpr (k.out.ub); v.out.vr = dq_vgpr (k.out.vr); v.out.vg = dq_vgpr (k.out.vg); v.out.vb = dq_vgpr (k.out.vb);
+  return v;
+}
+#endif
 
 // raw loads: one dword of luma (four pixels), the lane's two chroma columns of row y >> 1 as one dword
 // (NV12: U0 V0 U1 V1; planar: U0 U1 V0 V1)
@@ -360,8 +398,14 @@ __device__ __forceinline__ void deint_strip (const DeintParams &p, const DeintCo
   const uint8_t *cy = p.cur.p[0], *cu = p.cur.p[1], *cv = p.cur.p[2];
   const uint8_t *py = p.prev.p[0], *pu = p.prev.p[1], *pv = p.prev.p[2];
   const uint32_t ys = (uint32_t) p.cur.s[0], cs = (uint32_t) p.cur.s[1], pys = (uint32_t) p.prev.s[0], pcs = (uint32_t) p.prev.s[1];
+#ifndef VFHIP_DQ_PACKED
+  const DeintCoefs kv = coefs_in_vgprs (kk);
+  const YuvCoef &kc = kv.cur, &kp = kv.prev;
+  const RgbCoef &ko = kv.out;
+#else
   const YuvCoef &kc = kk.cur, &kp = kk.prev;
   const RgbCoef &ko = kk.out;
+#endif
   // TFF: even rows are kept, odd rows reconstructed from the kept rows above (y) and below (y + 2);
   // BFF: odd rows are kept, even rows reconstructed from the kept rows above (y - 1) and below (y + 1).
   // y0 and y are even: rows y and y + 1 share chroma row y >> 1.
@@ -384,7 +428,7 @@ __device__ __forceinline__ void deint_strip (const DeintParams &p, const DeintCo
   auto pair = [&] (int y, const Rgb4 &above, Rgb4 &kept) {
     Rgb4 prev {};
     Still4 st {};
-    // (the scheduling barriers keep the three row conversions from being interleaved: one at a time they fit in 68 VGPRs, seven waves per SIMD)
+    // (the scheduling barriers keep the three row conversions from being interleaved: one at a time they fit in 80 VGPRs, six waves per SIMD; without them: the same speed)
     if (NEED_PREV) prev = deint_row4 (y_p, deint_chroma2<PLANAR> (c_p), kp);
     __builtin_amdgcn_sched_barrier (0);
     if (TFF) {
