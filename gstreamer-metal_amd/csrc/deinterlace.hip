@@ -15,11 +15,8 @@ using namespace vfhip;
 
 namespace vfhip {
 
-// k_deinterlace_420q's pixel pairs.  The product build evaluates them as two scalars; -DVFHIP_DQ_PACKED (A/B builds: tools/exp/build_variants.sh -f
-// deinterlace) as packed f32 (v_pk_mul / add / fma_f32) — byte-identical, and 4 % slower: see the kernel's header
-#ifdef VFHIP_DQ_PACKED
-typedef float f2 __attribute__ ((ext_vector_type (2)));
-#else
+// k_deinterlace_420q's pixel pairs: two scalars (a packed-f32 form of the same expressions, v_pk_mul / add / fma_f32, gave the same bytes 4 % slower:
+// the kernel's header; git history has it)
 struct f2 { float x, y; };
 __device__ __forceinline__ f2 operator+ (f2 a, f2 b) { return f2 { a.x + b.x, a.y + b.y }; }
 __device__ __forceinline__ f2 operator- (f2 a, f2 b) { return f2 { a.x - b.x, a.y - b.y }; }
@@ -28,7 +25,6 @@ __device__ __forceinline__ f2 operator* (f2 a, float b) { return f2 { a.x * b, a
 __device__ __forceinline__ f2 operator* (float a, f2 b) { return f2 { a * b.x, a * b.y }; }
 __device__ __forceinline__ f2 operator+ (f2 a, float b) { return f2 { a.x + b, a.y + b }; }
 __device__ __forceinline__ f2 operator- (f2 a, float b) { return f2 { a.x - b, a.y - b }; }
-#endif
 
 struct DeintParams {
   metal::Img cur, prev;      // prev.p[0] == nullptr: no history
@@ -189,7 +185,7 @@ __global__ __launch_bounds__ (256) void k_deinterlace_420 (const DeintParams pp)
 // k_deinterlace_420q.  Same values as the kernels above (and as the reference's three passes), organised for the
 // machine: a lane owns FOUR adjacent pixels (one dword of luma, two chroma columns) and walks a strip of rows in pairs.
 //   * The reference's 8-bit RGBA intermediate lives in registers as the float an 8-bit texel reads back as — byte / 255
-//     with the byte obtained by x255, round-to-nearest-even (`quant2`) — so nothing is packed to bytes and unpacked again
+//     with the byte obtained by x255, round-to-nearest-even (`quant_sat2`) — so nothing is packed to bytes and unpacked again
 //     between the input pass, the method pass and the RGB -> YUV pass (each row used to be unpacked up to three times).
 //   * Every source row is converted once per strip and carried as the above / below tap of its neighbours; the chroma of a
 //     row pair is converted once (the two rows of a 4:2:0 pair read the same chroma row).
@@ -197,75 +193,44 @@ __global__ __launch_bounds__ (256) void k_deinterlace_420 (const DeintParams pp)
 //     chroma means of the output come out of the same adds in the reference's summation order.  Each float operation is the one the reference's
 //     passes make, on the same operands; three products by powers of two are folded where that is exact: (a + b) * 0.5 * 255 == (a + b) * 127.5
 //     and (k * (s * 0.25)) + c == fma (k * s, 0.25, c) (scaling by 2^-n commutes with rounding away from the denormals).
-//   * Scalar f32, not packed: a pair evaluated with v_pk_mul / add / fma_f32 (-DVFHIP_DQ_PACKED) gives the same bytes with a third fewer
-//     instructions and is 4 % SLOWER.  The conversions and roundings in the stream (v_cvt_f32_ubyte, v_rndne_f32: 80 of ~400 per row pair) cost
-//     3.4 cycles next to packed instructions but ~2 when they alternate with scalar full-rate ones — they overlap
-//     (tools/ubench/valu_mix.hip, profiles/r03ah_valu_mix.txt) — and fp32 peak is the same for both forms (64 flop per cycle and SIMD).
-//   * The matrix coefficients come in as kernel arguments, filled in by the host (selected inside the kernel they ended up as 30 loop-invariant
-//     VGPRs in the packed build), and are moved to VGPRs once per lane (an SGPR operand halves a full-rate scalar instruction).
+//   * Scalar f32, not packed: a pair evaluated with v_pk_mul / add / fma_f32 gives the same bytes with a third fewer instructions and is 4 %
+//     SLOWER.  The conversions and roundings in the stream (v_cvt_f32_ubyte, v_rndne_f32: 80 of ~400 per row pair) cost 3.4 cycles next to packed
+//     instructions but ~2 when they alternate with scalar full-rate ones — they overlap (tools/ubench/valu_mix.hip, profiles/r03ah_valu_mix.txt) —
+//     and fp32 peak is the same for both forms (64 flop per cycle and SIMD).
+//   * The matrix is a template parameter, its coefficients LITERALS: v_fmamk / v_fmaak_f32 (a VOP2 multiply-add with a literal, 1.9 cycles) where a
+//     coefficient in a register made it v_fma_f32 (VOP3: 3.5 cycles; in an SGPR 3.9) and cost a VGPR per coefficient.  The quad kernel therefore
+//     wants input, history and output on one matrix (the element's frames are); anything else keeps k_deinterlace_420.
+//   * clamp01 (x) ahead of the 8-bit quantisation is not an instruction of its own, nor a modifier on the (then VOP3) multiply-add: the clamp sits
+//     on the LAST multiply, rint (x * 255) * (1 / 255) -> [0, 1].  Equal for every x: inside [0, 1] the clamp does nothing on either side
+//     (255 * fl (1 / 255) rounds to exactly 1); above, both give 1; below, both give 0 (rint and the products are monotone).
 //   * greedy-H compares the squared distance with the smallest float whose correctly rounded square root reaches the
 //     threshold (computed on the host: `motion2_limit`), which decides exactly like sqrt (d2) < threshold without the
 //     square root.
 //   * Dword loads / stores on luma and on NV12 chroma, 32-bit offsets from wave-uniform plane bases.
 struct Rgb4 { f2 r[2], g[2], b[2]; };                    // [0]: pixels 0 and 2 of the lane's four, [1]: pixels 1 and 3
 struct Chroma2 { f2 u, v; };                             // cb - 128/255, cr - 128/255 of the lane's two chroma columns
-// the two matrices of metal_common.h as wave-uniform coefficient sets, filled in by the host and passed as kernel arguments: they
-// arrive in SGPRs (the coefficients of the clamped fmas as aligned pairs { k, k }, which v_pk_fma_f32 takes as its one scalar operand;
-// coefficients selected inside the kernel ended up as splat VGPR pairs: 30 VGPRs of loop invariants)
-struct YuvCoef { f2 rv, gv, bu; float gu, pad; };
-struct RgbCoef { float yr, yg, yb, ur, ug, ub, vr, vg, vb, pad; };
-struct DeintCoefs { YuvCoef cur, prev; RgbCoef out; };
-static YuvCoef yuv_coef (int m709)
-{
-  YuvCoef k {};
-  const float rv = m709 ? 1.792741f : 1.596027f, gv = m709 ? -0.532909f : -0.812968f, bu = m709 ? 2.112402f : 2.017232f;
-  k.rv = f2 { rv, rv }; k.gv = f2 { gv, gv }; k.bu = f2 { bu, bu }; k.gu = m709 ? -0.213249f : -0.391762f;
-  return k;
-}
-static RgbCoef rgb_coef (int m709)
-{
-  RgbCoef k {};
-  k.yr = m709 ? 0.182586f : 0.256788f; k.yg = m709 ? 0.614231f : 0.504129f; k.yb = m709 ? 0.062007f : 0.097906f;
-  k.ur = m709 ? -0.100644f : -0.148223f; k.ug = m709 ? -0.338572f : -0.290993f; k.ub = 0.439216f;
-  k.vr = 0.439216f; k.vg = m709 ? -0.398942f : -0.367788f; k.vb = m709 ? -0.040274f : -0.071427f;
-  return k;
-}
+// the two matrices of metal_common.h (yuv_to_rgb / rgb_to_yuv) as compile-time coefficient sets
+template <bool M709> struct YuvK {
+  static constexpr float rv = M709 ? 1.792741f : 1.596027f, gu = M709 ? -0.213249f : -0.391762f, gv = M709 ? -0.532909f : -0.812968f, bu = M709 ? 2.112402f : 2.017232f;
+};
+template <bool M709> struct RgbK {
+  static constexpr float yr = M709 ? 0.182586f : 0.256788f, yg = M709 ? 0.614231f : 0.504129f, yb = M709 ? 0.062007f : 0.097906f;
+  static constexpr float ur = M709 ? -0.100644f : -0.148223f, ug = M709 ? -0.338572f : -0.290993f, ub = 0.439216f;
+  static constexpr float vr = 0.439216f, vg = M709 ? -0.398942f : -0.367788f, vb = M709 ? -0.040274f : -0.071427f;
+};
 
-__device__ __forceinline__ f2 splat2 (float x) { return f2 { x, x }; }
 __device__ __forceinline__ f2 rint2 (f2 x) { return f2 { __builtin_rintf (x.x), __builtin_rintf (x.y) }; }
-#ifdef VFHIP_DQ_PACKED
-__device__ __forceinline__ f2 fma2 (f2 a, f2 b, f2 c) { return __builtin_elementwise_fma (a, b, c); }
-#else
-__device__ __forceinline__ f2 fma2 (f2 a, f2 b, f2 c) { return f2 { fmaf (a.x, b.x, c.x), fmaf (a.y, b.y, c.y) }; }
-#endif
-// what an 8-bit unorm texel written with x in [0, 1] reads back as
-__device__ __forceinline__ f2 quant2 (f2 x) { return rint2 (x * 255.0f) * (1.0f / 255.0f); }
-// clamp01 (fmaf (a, b, c)) in ONE instruction: the clamp output modifier saturates the correctly rounded fma result to [0, 1]
-// (the compiler emits fma + v_max ... clamp: a fifth of the scalar kernel's instructions were such clamps)
-__device__ __forceinline__ f2 fma_sat2 (f2 a, f2 b, f2 c)      // a: wave-uniform coefficient { k, k } (packed build: in an SGPR pair)
+// k * a + c with a literal k
+__device__ __forceinline__ f2 fmak2 (float k, f2 a, f2 c) { return f2 { fmaf (k, a.x, c.x), fmaf (k, a.y, c.y) }; }
+// what an 8-bit unorm texel written with clamp01 (x) reads back as: the clamp on the last multiply (header).  r255: 1 / 255 in a VGPR (a VOP3
+// instruction takes no literal, and an SGPR operand would halve its rate)
+__device__ __forceinline__ float mul_sat (float a, float b) { float d; asm ("v_mul_f32 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ f2 quant_sat2 (f2 x, float r255)
 {
-  f2 d;
-#ifdef VFHIP_DQ_PACKED
-  asm ("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "s"(a), "v"(b), "v"(c));
-#else
-  asm ("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d.x) : "v"(a.x), "v"(b.x), "v"(c.x));
-  asm ("v_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d.y) : "v"(a.x), "v"(b.y), "v"(c.y));
-#endif
-  return d;
+  const f2 q = rint2 (x * 255.0f);
+  return f2 { mul_sat (q.x, r255), mul_sat (q.y, r255) };
 }
-#ifndef VFHIP_DQ_PACKED
-// the coefficient sets in VGPRs: an SGPR operand halves a full-rate scalar instruction (tools/ubench/valu_occ.hip); packed ones take it for free
 __device__ __forceinline__ float dq_vgpr (float x) { float v; asm volatile ("v_mov_b32 %0, %1" : "=v"(v) : "s"(x)); return v; }
-__device__ __forceinline__ DeintCoefs coefs_in_vgprs (const DeintCoefs &k)
-{
-  DeintCoefs v = k;
-  YuvCoef *y[2] = { &v.cur, &v.prev };
-  for (int i = 0; i < 2; i++) { y[i]->rv.x = dq_vgpr (y[i]->rv.x); y[i]->gv.x = dq_vgpr (y[i]->gv.x); y[i]->bu.x = dq_vgpr (y[i]->bu.x); y[i]->gu = dq_vgpr (y[i]->gu); }
-  v.out.yr = dq_vgpr (k.out.yr); v.out.yg = dq_vgpr (k.out.yg); v.out.yb = dq_vgpr (k.out.yb); v.out.ur = dq_vgpr (k.out.ur); v.out.ug = dq_vgpr (k.out.ug);
-  v.out.ub = dq_vgpr (k.out.ub); v.out.vr = dq_vgpr (k.out.vr); v.out.vg = dq_vgpr (k.out.vg); v.out.vb = dq_vgpr (k.out.vb);
-  return v;
-}
-#endif
 
 // raw loads: one dword of luma (four pixels), the lane's two chroma columns of row y >> 1 as one dword
 // (NV12: U0 V0 U1 V1; planar: U0 U1 V0 V1)
@@ -293,32 +258,35 @@ __device__ __forceinline__ Chroma2 deint_chroma2 (uint32_t c4)
   return c;
 }
 
-__device__ __forceinline__ Rgb4 deint_row4 (uint32_t Y4, const Chroma2 &c, const YuvCoef &k)
+template <bool M709>
+__device__ __forceinline__ Rgb4 deint_row4 (uint32_t Y4, const Chroma2 &c, float r255)
 {
+  typedef YuvK<M709> K;
   const f2 yb[2] = { f2 { (float) (Y4 & 0xffu), (float) ((Y4 >> 16) & 0xffu) }, f2 { (float) ((Y4 >> 8) & 0xffu), (float) (Y4 >> 24) } };
   Rgb4 o;
 #pragma unroll
   for (int i = 0; i < 2; i++) {
-    // metal::yuv_to_rgb with the coefficients in registers (same operations, same order)
+    // metal::yuv_to_rgb (same operations, same order)
     const f2 ly = 1.164383f * (yb[i] * (1.0f / 255.0f) - 16.0f / 255.0f);
-    o.r[i] = quant2 (fma_sat2 (k.rv, c.v, ly));
-    o.g[i] = quant2 (fma_sat2 (k.gv, c.v, fma2 (splat2 (k.gu), c.u, ly)));
-    o.b[i] = quant2 (fma_sat2 (k.bu, c.u, ly));
+    o.r[i] = quant_sat2 (fmak2 (K::rv, c.v, ly), r255);
+    o.g[i] = quant_sat2 (fmak2 (K::gv, c.v, fmak2 (K::gu, c.u, ly)), r255);
+    o.b[i] = quant_sat2 (fmak2 (K::bu, c.u, ly), r255);
   }
   return o;
 }
 
 // rows y (o0) and y+1 (o1) of one lane's four columns -> NV12 / I420 (the reference's rgbaToNV12 / rgbaToI420 pass:
 // luma per pixel, chroma from the mean of each 2x2 block, summed in the reference's order)
-template <bool PLANAR>
-__device__ __forceinline__ void deint_store4 (const metal::OutImg &o, const RgbCoef &k, uint32_t q, int y, const Rgb4 &o0, const Rgb4 &o1)
+template <bool PLANAR, bool M709>
+__device__ __forceinline__ void deint_store4 (const metal::OutImg &o, uint32_t q, int y, const Rgb4 &o0, const Rgb4 &o1)
 {
+  typedef RgbK<M709> K;
   uint32_t l0 = 0, l1 = 0;
 #pragma unroll
   for (int i = 0; i < 2; i++) {
-    // metal::rgb_to_yuv (luma row), coefficients in registers; pair i holds the bytes i and i + 2 of the dword
-    const f2 Y0 = (fma2 (splat2 (k.yb), o0.b[i], fma2 (splat2 (k.yg), o0.g[i], k.yr * o0.r[i])) + 16.0f / 255.0f) * 255.0f;
-    const f2 Y1 = (fma2 (splat2 (k.yb), o1.b[i], fma2 (splat2 (k.yg), o1.g[i], k.yr * o1.r[i])) + 16.0f / 255.0f) * 255.0f;
+    // metal::rgb_to_yuv (luma row); pair i holds the bytes i and i + 2 of the dword
+    const f2 Y0 = (fmak2 (K::yb, o0.b[i], fmak2 (K::yg, o0.g[i], K::yr * o0.r[i])) + 16.0f / 255.0f) * 255.0f;
+    const f2 Y1 = (fmak2 (K::yb, o1.b[i], fmak2 (K::yg, o1.g[i], K::yr * o1.r[i])) + 16.0f / 255.0f) * 255.0f;
     l0 = __builtin_amdgcn_cvt_pk_u8_f32 (Y0.x, (uint32_t) i, l0); l0 = __builtin_amdgcn_cvt_pk_u8_f32 (Y0.y, (uint32_t) i + 2u, l0);
     l1 = __builtin_amdgcn_cvt_pk_u8_f32 (Y1.x, (uint32_t) i, l1); l1 = __builtin_amdgcn_cvt_pk_u8_f32 (Y1.y, (uint32_t) i + 2u, l1);
   }
@@ -327,8 +295,9 @@ __device__ __forceinline__ void deint_store4 (const metal::OutImg &o, const RgbC
   __builtin_nontemporal_store (l1, reinterpret_cast<uint32_t *> (o.p[0] + (lo + (uint32_t) o.s[0])));
   // the two 2x2 blocks at once: ((row0 left + row0 right) + row1 left) + row1 right, x 0.25 folded into the last fma
   const f2 sr = ((o0.r[0] + o0.r[1]) + o1.r[0]) + o1.r[1], sg = ((o0.g[0] + o0.g[1]) + o1.g[0]) + o1.g[1], sb = ((o0.b[0] + o0.b[1]) + o1.b[0]) + o1.b[1];
-  const f2 U = fma2 (fma2 (splat2 (k.ub), sb, fma2 (splat2 (k.ug), sg, k.ur * sr)), splat2 (0.25f), splat2 (128.0f / 255.0f)) * 255.0f;
-  const f2 V = fma2 (fma2 (splat2 (k.vb), sb, fma2 (splat2 (k.vg), sg, k.vr * sr)), splat2 (0.25f), splat2 (128.0f / 255.0f)) * 255.0f;
+  const f2 c128 = f2 { 128.0f / 255.0f, 128.0f / 255.0f };
+  const f2 U = fmak2 (0.25f, fmak2 (K::ub, sb, fmak2 (K::ug, sg, K::ur * sr)), c128) * 255.0f;
+  const f2 V = fmak2 (0.25f, fmak2 (K::vb, sb, fmak2 (K::vg, sg, K::vr * sr)), c128) * 255.0f;
   if (PLANAR) {
     uint32_t uu = __builtin_amdgcn_cvt_pk_u8_f32 (U.x, 0u, 0u), vv = __builtin_amdgcn_cvt_pk_u8_f32 (V.x, 0u, 0u);
     uu = __builtin_amdgcn_cvt_pk_u8_f32 (U.y, 1u, uu); vv = __builtin_amdgcn_cvt_pk_u8_f32 (V.y, 1u, vv);
@@ -388,8 +357,8 @@ constexpr int DEINTQ_ROWS = 8;      // rows per lane for one frame (batches: 16 
 // The loop is software-pipelined by hand: the (up to five) dwords a row pair needs are loaded one iteration ahead, right after
 // the previous pair's have been converted, so that their latency is covered by this lane's own arithmetic and not only by the
 // other waves of the SIMD (rows past the frame are clamped: a load too many per strip, never a branch).
-template <bool PLANAR, bool TFF, int METHOD, bool HIST>
-__device__ __forceinline__ void deint_strip (const DeintParams &p, const DeintCoefs &kk, uint32_t q, int y0, int yend, float m2_limit)
+template <bool PLANAR, bool TFF, int METHOD, bool HIST, bool M709>
+__device__ __forceinline__ void deint_strip (const DeintParams &p, uint32_t q, int y0, int yend, float m2_limit)
 {
   constexpr int M = (METHOD == VFHIP_DEINTERLACE_WEAVE || METHOD == VFHIP_DEINTERLACE_GREEDYH) && !HIST ? VFHIP_DEINTERLACE_BOB : METHOD;
   constexpr bool NEED_PREV = M == VFHIP_DEINTERLACE_WEAVE || M == VFHIP_DEINTERLACE_GREEDYH;
@@ -398,14 +367,7 @@ __device__ __forceinline__ void deint_strip (const DeintParams &p, const DeintCo
   const uint8_t *cy = p.cur.p[0], *cu = p.cur.p[1], *cv = p.cur.p[2];
   const uint8_t *py = p.prev.p[0], *pu = p.prev.p[1], *pv = p.prev.p[2];
   const uint32_t ys = (uint32_t) p.cur.s[0], cs = (uint32_t) p.cur.s[1], pys = (uint32_t) p.prev.s[0], pcs = (uint32_t) p.prev.s[1];
-#ifndef VFHIP_DQ_PACKED
-  const DeintCoefs kv = coefs_in_vgprs (kk);
-  const YuvCoef &kc = kv.cur, &kp = kv.prev;
-  const RgbCoef &ko = kv.out;
-#else
-  const YuvCoef &kc = kk.cur, &kp = kk.prev;
-  const RgbCoef &ko = kk.out;
-#endif
+  const float r255 = dq_vgpr (1.0f / 255.0f);
   // TFF: even rows are kept, odd rows reconstructed from the kept rows above (y) and below (y + 2);
   // BFF: odd rows are kept, even rows reconstructed from the kept rows above (y - 1) and below (y + 1).
   // y0 and y are even: rows y and y + 1 share chroma row y >> 1.
@@ -423,29 +385,29 @@ __device__ __forceinline__ void deint_strip (const DeintParams &p, const DeintCo
   const uint32_t y_c = deint_luma4 (cy, ys, q, yc), c_c = deint_chroma4<PLANAR> (cu, cv, cs, q, yc);
   fetch (y0);
   Chroma2 cc = deint_chroma2<PLANAR> (c_c);
-  Rgb4 ra = deint_row4 (y_c, cc, kc);
+  Rgb4 ra = deint_row4<M709> (y_c, cc, r255);
   // one row pair: `above` = the kept row over the reconstructed one (it came in with the pair before), `kept` = the one this pair brings
   auto pair = [&] (int y, const Rgb4 &above, Rgb4 &kept) {
     Rgb4 prev {};
     Still4 st {};
     // (the scheduling barriers keep the three row conversions from being interleaved: one at a time they fit in 80 VGPRs, six waves per SIMD; without them: the same speed)
-    if (NEED_PREV) prev = deint_row4 (y_p, deint_chroma2<PLANAR> (c_p), kp);
+    if (NEED_PREV) prev = deint_row4<M709> (y_p, deint_chroma2<PLANAR> (c_p), r255);
     __builtin_amdgcn_sched_barrier (0);
     if (TFF) {
-      if (GREEDY) st = deint_still4 (deint_row4 (y_t, cc, kc), prev, m2_limit);          // row y + 1 shares the chroma of row y
+      if (GREEDY) st = deint_still4 (deint_row4<M709> (y_t, cc, r255), prev, m2_limit);          // row y + 1 shares the chroma of row y
       cc = deint_chroma2<PLANAR> (c_k);
     } else {
       cc = deint_chroma2<PLANAR> (c_k);
-      if (GREEDY) st = deint_still4 (deint_row4 (y_t, cc, kc), prev, m2_limit);
+      if (GREEDY) st = deint_still4 (deint_row4<M709> (y_t, cc, r255), prev, m2_limit);
     }
     __builtin_amdgcn_sched_barrier (0);
-    kept = deint_row4 (y_k, cc, kc);
+    kept = deint_row4<M709> (y_k, cc, r255);
     __builtin_amdgcn_sched_barrier (0);
     fetch (y + 2);
     const Rgb4 rec = deint_recon4<M> (st, above, kept, prev);
     __builtin_amdgcn_sched_barrier (0);
-    if (TFF) deint_store4<PLANAR> (p.out, ko, q, y, above, rec);
-    else deint_store4<PLANAR> (p.out, ko, q, y, rec, kept);
+    if (TFF) deint_store4<PLANAR, M709> (p.out, q, y, above, rec);
+    else deint_store4<PLANAR, M709> (p.out, q, y, rec, kept);
   };
   // two pairs per trip: the kept row changes hands between `ra` and `rb` instead of being copied (six 64-bit moves per pair)
   Rgb4 rb;
@@ -456,8 +418,8 @@ __device__ __forceinline__ void deint_strip (const DeintParams &p, const DeintCo
   }
 }
 
-template <bool PLANAR, bool TFF, int METHOD>
-__global__ __launch_bounds__ (256) void k_deinterlace_420q (const DeintParams pp, const DeintCoefs kk, float m2_limit, int rows)
+template <bool PLANAR, bool TFF, int METHOD, bool M709>
+__global__ __launch_bounds__ (256) void k_deinterlace_420q (const DeintParams pp, float m2_limit, int rows)
 {
   const DeintParams p = deint_frame (pp, blockIdx.y);
   const int quads = p.out.w >> 2, h = p.out.h;
@@ -467,8 +429,8 @@ __global__ __launch_bounds__ (256) void k_deinterlace_420q (const DeintParams pp
   const int strip = t / quads;
   const uint32_t q = (uint32_t) (t - strip * quads);
   const int y0 = strip * rows, yend = min (y0 + rows, h);
-  if (METHOD == VFHIP_DEINTERLACE_BOB || p.prev.p[0] != nullptr) deint_strip<PLANAR, TFF, METHOD, true> (p, kk, q, y0, yend, m2_limit);
-  else deint_strip<PLANAR, TFF, METHOD, false> (p, kk, q, y0, yend, m2_limit);
+  if (METHOD == VFHIP_DEINTERLACE_BOB || p.prev.p[0] != nullptr) deint_strip<PLANAR, TFF, METHOD, true, M709> (p, q, y0, yend, m2_limit);
+  else deint_strip<PLANAR, TFF, METHOD, false, M709> (p, q, y0, yend, m2_limit);
 }
 
 }  // namespace vfhip
@@ -502,7 +464,7 @@ static float motion2_limit (float thr)
 }
 
 // k_deinterlace_420q's contract: 4:2:0 frame, width % 4 == 0, even height, every plane (and the batch pitches) aligned
-// for the dword / 16-bit accesses it makes
+// for the dword / 16-bit accesses it makes, input / history / output on one colour matrix (a template parameter there)
 static bool deint_quad_ok (const VfHipVideoInfo &info, const VfHipFrame *cur, const VfHipFrame *prev, const VfHipFrame *out, size_t in_pitch, size_t out_pitch)
 {
   static const bool enabled = [] { const char *e = getenv ("VFHIP_DEINT_QUAD"); return !e || atoi (e) != 0; } ();     // test / A-B knob
@@ -510,6 +472,8 @@ static bool deint_quad_ok (const VfHipVideoInfo &info, const VfHipFrame *cur, co
   const bool nv12 = info.format == VFHIP_FORMAT_NV12, i420 = info.format == VFHIP_FORMAT_I420;
   if (!(nv12 || i420) || (info.width & 3) || (info.height & 1) || info.width < 4 || info.height < 2) return false;
   if ((in_pitch | out_pitch) & 3) return false;
+  const bool m709 = cur->info.color_matrix == VFHIP_MATRIX_BT709;
+  if ((out->info.color_matrix == VFHIP_MATRIX_BT709) != m709 || (prev && (prev->info.color_matrix == VFHIP_MATRIX_BT709) != m709)) return false;
   auto ok = [&] (const VfHipFrame *f) {
     if (!f) return true;
     if (((uintptr_t) f->data[0] | (uintptr_t) f->stride[0]) & 3) return false;
@@ -547,9 +511,9 @@ static int deint_launch (VfHipDeinterlace *h, const VfHipFrame *cur, const VfHip
     dim3 grid ((unsigned) (((size_t) (h->info.width / 4) * strips + 255) / 256), (unsigned) n_frames);
     const float lim = motion2_limit (p.threshold);
     const bool planar = h->info.format == VFHIP_FORMAT_I420;
-    DeintCoefs kk {};
-    kk.cur = yuv_coef (p.cur.m709); kk.prev = yuv_coef (prev ? p.prev.m709 : p.cur.m709); kk.out = rgb_coef (p.out.m709);
-#define VF_DQ(PL, TF, M) hipLaunchKernelGGL ((k_deinterlace_420q<PL, TF, M>), grid, dim3 (256), 0, s, p, kk, lim, rows)
+    const bool m709 = p.cur.m709 != 0;
+#define VF_DQ(PL, TF, M) do { if (m709) hipLaunchKernelGGL ((k_deinterlace_420q<PL, TF, M, true>), grid, dim3 (256), 0, s, p, lim, rows); \
+                              else hipLaunchKernelGGL ((k_deinterlace_420q<PL, TF, M, false>), grid, dim3 (256), 0, s, p, lim, rows); } while (0)
 #define VF_DQ_M(PL, TF) do { if (method == VFHIP_DEINTERLACE_BOB) VF_DQ (PL, TF, VFHIP_DEINTERLACE_BOB); else if (method == VFHIP_DEINTERLACE_WEAVE) VF_DQ (PL, TF, VFHIP_DEINTERLACE_WEAVE); \
                               else VF_DQ (PL, TF, VFHIP_DEINTERLACE_GREEDYH); } while (0)
     if (planar) { if (p.tff) VF_DQ_M (true, true); else VF_DQ_M (true, false); }
