@@ -249,6 +249,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ceilings", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the other BASELINE configs (C1, C3, C4, C5) measured after the headline's timed region")
+    ap.add_argument("--rehearse-shared-gpu", action="store_true",
+                    help="let the N ranks share the visible GPUs (ordinal = LOCAL_RANK %% device count): a rehearsal of the N-rank path on a box with fewer GPUs; the line is marked, it is not a scaling measurement")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="rank plumbing only (spawn, gloo rendezvous, barrier, max over ranks, aggregation) with a sleep in place of the GPU step; prints a line marked as such, never a measurement")
     args = ap.parse_args()
@@ -277,8 +279,10 @@ def main():
     import vfhip                                   # fails loudly when libvfhip.so is missing
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    if local_rank >= torch.cuda.device_count():
+    if local_rank >= torch.cuda.device_count() and not args.rehearse_shared_gpu:
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} device(s) visible")
+    if args.rehearse_shared_gpu:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev_name = vfhip.device_name(local_rank)
     devices = bd.gather_objects({"rank": rank, "ordinal": local_rank, "name": dev_name})
@@ -411,6 +415,8 @@ def main():
             "clocks": clocks,
             "roofline": roof,
         }
+        if args.rehearse_shared_gpu:
+            out["rehearsal"] = f"{world} ranks on {torch.cuda.device_count()} GPU(s) (--rehearse-shared-gpu): the N-rank path exercised on real HIP, NOT a scaling measurement"
         if world == 1 and not args.no_others and not c5:
             # the other BASELINE configs, kernel-only like the headline, AFTER its timed region and with its rings released (bench_configs.py)
             import bench_configs

@@ -4,6 +4,7 @@ import os
 import subprocess
 import sys
 import textwrap
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -111,3 +112,28 @@ def test_bench_py_single_rank_selftest_and_traffic_key():
         assert t == round(committed["hbm_bytes_per_frame"] * 128)
     else:
         assert t is None and "re-run" in note                    # a PMC figure of another kernel source is never printed
+
+
+@pytest.mark.gpu
+def test_bench_py_two_ranks_share_the_gpu_rehearsal():
+    """The N-rank path on real HIP, on the one GPU a test box has: bench.py --gpus 2 --rehearse-shared-gpu, once self-launched and once under
+    the driver's own launcher line.  Both ranks run the product path; the line says it is a rehearsal, not a scaling measurement."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--gpus", "2", "--rehearse-shared-gpu", "--steps", "3", "--warmup", "1", "--frames", "64", "--no-ceilings", "--precondition", "0.1"]
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    for cmd in ([sys.executable, os.path.join(root, "bench.py")] + common,
+                [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                 os.path.join(root, "bench.py")] + common):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]                  # rank 0 alone prints
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "rehearsal" in d and d["value"] > 0
+        assert [x["rank"] for x in d["config"]["devices"]] == [0, 1] and "others" not in d and "cpu_baseline" not in d
