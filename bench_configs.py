@@ -86,6 +86,20 @@ def c3(torch, vfhip, stream, dev=0, frames=64):
                                                               in_pitch=fin.shape[1], out_pitch=fout.shape[1]))
     out = _entry("configs[2]: vfhipvideofilter BGRA 1920x1080, all 15 properties + 33^3 LUT, single pass", "k_vf_sharp", ms, n, frames, 2 * 4 * w * h,
                  fin.numel() + fout.numel())
+    # beside it, NOT the config's figure: the same launch on picture-like frames (smooth gradients + a little noise, every frame different) — neighbouring
+    # pixels then fall into the same LUT cells, which is the case a grading filter meets in practice; uniform random bytes above are the gather's worst case
+    yy = torch.arange(h, device="cuda", dtype=torch.float32).view(1, h, 1, 1)
+    xx = torch.arange(w, device="cuda", dtype=torch.float32).view(1, 1, w, 1)
+    ph = torch.arange(frames, device="cuda", dtype=torch.float32).view(frames, 1, 1, 1)
+    ch = torch.tensor([0.0, 2.1, 4.2, 0.0], device="cuda").view(1, 1, 1, 4)
+    img = 128 + 90 * torch.sin(xx / 211.0 + ph * 0.37 + ch) * torch.cos(yy / 173.0 + ch * 0.5) + torch.randint(-3, 4, (frames, h, w, 4), device="cuda")
+    img[..., 3] = 255
+    fin[:, :4 * w * h] = img.clamp_(0, 255).to(torch.uint8).view(frames, -1)
+    del img
+    ms2, n2 = _measure(torch, stream, lambda: vf.process_device(fin.data_ptr(), fout.data_ptr(), prm, stream=stream.cuda_stream, n_frames=frames,
+                                                                in_pitch=fin.shape[1], out_pitch=fout.shape[1]), precondition_s=0.1, min_ms=60.0)
+    out["picture_like_input"] = {"frames_per_s": round(frames / ms2 * 1e3, 1), "kernel_ms": round(ms2, 4), "frac": round(2 * 4 * w * h * frames / (ms2 * 1e-3) / 1e9 / PEAK_GBS, 4),
+                                 "note": "smooth synthetic frames; beside the config's figure (uniform random bytes), not instead of it"}
     vf.close()
     return out
 
