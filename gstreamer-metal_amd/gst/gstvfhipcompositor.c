@@ -4,7 +4,7 @@
  * GstChildProxy, rank PRIMARY + 2 (:177-178), request pads sink_%u { BGRA, RGBA, NV12, I420 } and the same src template
  * (:65-78), element properties background {checker, black, white, transparent} and zero-size-is-unscaled (:1035-1051),
  * pad properties xpos, ypos, width, height, alpha, operator {source, over, add}, sizing-policy {none, keep-aspect-ratio}
- * (gstvfmetalcompositorpad.m:282-315) plus GstVideoAggregatorPad's own zorder and repeat-after-eos.
+ * (gstvfmetalcompositorpad.m:282-315) plus GstVideoAggregatorPad's own zorder, repeat-after-eos and max-last-buffer-repeat.
  * Inputs keep their own sizes (update_caps does not intersect pad sizes, :394-458); the output size is the bounding
  * box of the positioned pads, BGRA preferred, highest input frame rate (:460-540).
  *
@@ -17,10 +17,11 @@
  * rates therefore composite like in the reference.  Obscured-pad culling (gstvfmetalcompositorpad.m:180-255), pointer
  * navigation (:706-787), async-depth and memory:HIPMemory are part of the same code.
  *
- * NOT carried over from GstVideoAggregator (the reference inherits them from its base class, this element has no such base class on 1.14):
- * QoS-driven frame dropping (the QOS events of a late sink are accepted and ignored: every output frame is composited), the pad property
- * max-last-buffer-repeat (a pad's last buffer is held for its own duration, or for ever with repeat-after-eos), and the GstVideoAggregatorPad
- * C API on the request pads — an application that casts them to GstVideoAggregatorPad, rather than setting properties by name, does not drop in. */
+ * From GstVideoAggregator too, since the reference inherits them from that base class: QoS (the QOS events of a late sink in a non-live pipeline make
+ * aggregate () skip output frames that are already late — not composited, their time passes, a QoS message is posted: comp_update_qos / comp_qos_jitter)
+ * and the pad property max-last-buffer-repeat (comp_cap_repeat).
+ * NOT carried over: the GstVideoAggregatorPad C API on the request pads — an application that casts them to GstVideoAggregatorPad, rather than setting
+ * properties by name, does not drop in (this element has no such base class on 1.14). */
 #ifdef HAVE_CONFIG_H
 #include "config.h"
 #endif
@@ -45,6 +46,7 @@ typedef struct
   gint op, sizing_policy;
   guint zorder;
   gboolean repeat_after_eos;
+  GstClockTime max_last_buffer_repeat;   /* GstVideoAggregatorPad's property of the same name: how long a pad that is not at EOS keeps showing its last buffer */
   /* the buffer this pad currently shows and its running-time interval (GstVideoAggregatorPad's buffer / start_time / end_time) */
   GstBuffer *cur;
   GstClockTime cur_start, cur_end;
@@ -54,7 +56,7 @@ typedef struct
   GstAggregatorPadClass parent_class;
 } GstVfHipCompositorPadClass;
 
-enum { PAD_PROP_0, PAD_PROP_XPOS, PAD_PROP_YPOS, PAD_PROP_WIDTH, PAD_PROP_HEIGHT, PAD_PROP_ALPHA, PAD_PROP_OPERATOR, PAD_PROP_SIZING_POLICY, PAD_PROP_ZORDER, PAD_PROP_REPEAT_AFTER_EOS };
+enum { PAD_PROP_0, PAD_PROP_XPOS, PAD_PROP_YPOS, PAD_PROP_WIDTH, PAD_PROP_HEIGHT, PAD_PROP_ALPHA, PAD_PROP_OPERATOR, PAD_PROP_SIZING_POLICY, PAD_PROP_ZORDER, PAD_PROP_REPEAT_AFTER_EOS, PAD_PROP_MAX_LAST_BUFFER_REPEAT };
 
 static GType
 comp_enum (const gchar * name, const GEnumValue * v, gsize * once)
@@ -114,10 +116,11 @@ cpad_set_property (GObject * object, guint id, const GValue * value, GParamSpec 
     case PAD_PROP_SIZING_POLICY: pad->sizing_policy = g_value_get_enum (value); break;
     case PAD_PROP_ZORDER: pad->zorder = g_value_get_uint (value); break;
     case PAD_PROP_REPEAT_AFTER_EOS: pad->repeat_after_eos = g_value_get_boolean (value); break;
+    case PAD_PROP_MAX_LAST_BUFFER_REPEAT: pad->max_last_buffer_repeat = g_value_get_uint64 (value); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
   }
   GST_OBJECT_UNLOCK (pad);
-  if (id != PAD_PROP_ALPHA && id != PAD_PROP_OPERATOR && id != PAD_PROP_ZORDER && id != PAD_PROP_REPEAT_AFTER_EOS && (agg = gst_object_get_parent (GST_OBJECT (pad)))) {
+  if (id != PAD_PROP_ALPHA && id != PAD_PROP_OPERATOR && id != PAD_PROP_ZORDER && id != PAD_PROP_REPEAT_AFTER_EOS && id != PAD_PROP_MAX_LAST_BUFFER_REPEAT && (agg = gst_object_get_parent (GST_OBJECT (pad)))) {
     gst_pad_mark_reconfigure (GST_AGGREGATOR (agg)->srcpad);          /* the output bounding box may have changed */
     gst_object_unref (agg);
   }
@@ -138,6 +141,7 @@ cpad_get_property (GObject * object, guint id, GValue * value, GParamSpec * pspe
     case PAD_PROP_SIZING_POLICY: g_value_set_enum (value, pad->sizing_policy); break;
     case PAD_PROP_ZORDER: g_value_set_uint (value, pad->zorder); break;
     case PAD_PROP_REPEAT_AFTER_EOS: g_value_set_boolean (value, pad->repeat_after_eos); break;
+    case PAD_PROP_MAX_LAST_BUFFER_REPEAT: g_value_set_uint64 (value, pad->max_last_buffer_repeat); break;
     default: G_OBJECT_WARN_INVALID_PROPERTY_ID (object, id, pspec); break;
   }
   GST_OBJECT_UNLOCK (pad);
@@ -170,6 +174,8 @@ gst_vfhip_compositor_pad_class_init (GstVfHipCompositorPadClass * klass)
   g_object_class_install_property (oc, PAD_PROP_ZORDER, g_param_spec_uint ("zorder", "Z-Order", "Z Order of the picture", 0, G_MAXUINT, 0, f));
   g_object_class_install_property (oc, PAD_PROP_REPEAT_AFTER_EOS, g_param_spec_boolean ("repeat-after-eos", "Repeat After EOS",
           "Repeat the last frame after EOS until all pads are EOS", FALSE, f));
+  g_object_class_install_property (oc, PAD_PROP_MAX_LAST_BUFFER_REPEAT, g_param_spec_uint64 ("max-last-buffer-repeat", "Max Last Buffer Repeat",
+          "Repeat last buffer for time (in ns, -1=until EOS), behaviour on EOS is not affected", 0, G_MAXUINT64, GST_CLOCK_TIME_NONE, f));
 }
 
 static void
@@ -180,6 +186,7 @@ gst_vfhip_compositor_pad_init (GstVfHipCompositorPad * pad)
   pad->op = VFHIP_BLEND_OVER;
   pad->sizing_policy = SIZING_NONE;
   pad->cur_start = pad->cur_end = GST_CLOCK_TIME_NONE;
+  pad->max_last_buffer_repeat = GST_CLOCK_TIME_NONE;
   gst_video_info_init (&pad->info);
 }
 
@@ -201,6 +208,11 @@ typedef struct
   gint async_depth;
   gboolean have_pending;
   struct { GstBuffer *outbuf; GstVideoFrame out; guint n; GstBuffer **bufs; GstVideoFrame *frames; } pending;
+  /* QoS like GstVideoAggregator (gst_video_aggregator_update_qos / _do_qos): what the last QOS event from downstream said (object lock), and the
+   * counts its QoS messages carry */
+  gdouble qos_proportion;
+  GstClockTime qos_earliest;
+  guint64 qos_processed, qos_dropped;
 } GstVfHipCompositor;
 typedef struct
 {
@@ -433,6 +445,18 @@ comp_finish_pending (GstVfHipCompositor * self, gboolean push)
  *   - one that ended before the output frame is dropped and the pad is asked for more (a pad faster than the output);
  *   - a pad at EOS keeps its last buffer while that still runs, then disappears (unless repeat-after-eos);
  * -> GST_FLOW_OK, GST_AGGREGATOR_FLOW_NEED_DATA (wait for the pads that were asked for more) or GST_FLOW_EOS (all done). */
+/* max-last-buffer-repeat: a pad that is NOT at EOS shows its last buffer for at most that long past the buffer's end (EOS is repeat-after-eos's business) */
+static void
+comp_cap_repeat (GstVfHipCompositorPad * cpad, GstClockTime out_start)
+{
+  if (cpad->cur && GST_CLOCK_TIME_IS_VALID (cpad->max_last_buffer_repeat) && GST_CLOCK_TIME_IS_VALID (cpad->cur_end) && GST_CLOCK_TIME_IS_VALID (out_start) &&
+      out_start > cpad->cur_end && out_start - cpad->cur_end > cpad->max_last_buffer_repeat) {
+    GST_DEBUG_OBJECT (cpad, "last buffer repeated for more than %" GST_TIME_FORMAT ": dropped", GST_TIME_ARGS (cpad->max_last_buffer_repeat));
+    gst_buffer_replace (&cpad->cur, NULL);
+    cpad->cur_start = cpad->cur_end = GST_CLOCK_TIME_NONE;
+  }
+}
+
 static GstFlowReturn
 comp_fill_queues (GstVfHipCompositor * self, PadRef * refs, guint n, GstClockTime out_start, GstClockTime out_end, GstClockTime out_dur)
 {
@@ -452,8 +476,10 @@ comp_fill_queues (GstVfHipCompositor * self, PadRef * refs, guint n, GstClockTim
             gst_buffer_replace (&cpad->cur, NULL);
             cpad->cur_start = cpad->cur_end = GST_CLOCK_TIME_NONE;
           }
-        } else
+        } else {
           eos = FALSE;                                     /* nothing queued yet (timeout / just asked for more) */
+          comp_cap_repeat (cpad, out_start);
+        }
         break;
       }
       start = GST_BUFFER_PTS_IS_VALID (buf) ? GST_BUFFER_PTS (buf) : GST_BUFFER_DTS (buf);
@@ -503,6 +529,7 @@ comp_fill_queues (GstVfHipCompositor * self, PadRef * refs, guint n, GstClockTim
       if (start >= out_end) {                              /* for a later output frame: stays queued, the current buffer repeats */
         GST_LOG_OBJECT (cpad, "keeping buffer %" GST_TIME_FORMAT " for later, repeating the current one", GST_TIME_ARGS (start));
         gst_buffer_unref (buf);
+        comp_cap_repeat (cpad, out_start);
         eos = FALSE;
         break;
       }
@@ -535,6 +562,50 @@ comp_drop_current_buffers (GstVfHipCompositor * self)
   g_list_free (pads);
   self->n_frames = 0;
   self->ts_offset = GST_CLOCK_TIME_NONE;
+}
+
+/* QoS (GstVideoAggregator's): a QOS event from downstream says how late the frame with `timestamp` was; in a non-live pipeline output frames whose
+ * running time lies before `earliest` are not composited at all — their time still passes, their inputs are still consumed — and a QoS message
+ * tells the application */
+static void
+comp_reset_qos (GstVfHipCompositor * self)
+{
+  GST_OBJECT_LOCK (self);
+  self->qos_proportion = 0.5;
+  self->qos_earliest = GST_CLOCK_TIME_NONE;
+  GST_OBJECT_UNLOCK (self);
+  self->qos_processed = self->qos_dropped = 0;
+}
+
+static void
+comp_update_qos (GstVfHipCompositor * self, gdouble proportion, GstClockTimeDiff diff, GstClockTime timestamp)
+{
+  const gboolean live = GST_CLOCK_TIME_IS_VALID (gst_aggregator_get_latency (GST_AGGREGATOR (self)));
+  GST_OBJECT_LOCK (self);
+  self->qos_proportion = proportion;
+  if (!live && GST_CLOCK_TIME_IS_VALID (timestamp)) {
+    if (diff > 0) {
+      const gint fn = GST_VIDEO_INFO_FPS_N (&self->out_info), fd = GST_VIDEO_INFO_FPS_D (&self->out_info);
+      self->qos_earliest = timestamp + 2 * diff + ((fn > 0 && fd > 0) ? gst_util_uint64_scale_int_round (GST_SECOND, fd, fn) : 0);
+    } else
+      self->qos_earliest = (diff < 0 && (GstClockTime) (-diff) > timestamp) ? 0 : timestamp + diff;
+  } else
+    self->qos_earliest = GST_CLOCK_TIME_NONE;
+  GST_OBJECT_UNLOCK (self);
+}
+
+/* > 0: the output frame starting at running time `rt` is late by that much */
+static GstClockTimeDiff
+comp_qos_jitter (GstVfHipCompositor * self, GstClockTime rt, gdouble * proportion)
+{
+  GstClockTime earliest;
+  GST_OBJECT_LOCK (self);
+  earliest = self->qos_earliest;
+  *proportion = self->qos_proportion;
+  GST_OBJECT_UNLOCK (self);
+  if (!GST_CLOCK_TIME_IS_VALID (rt) || !GST_CLOCK_TIME_IS_VALID (earliest))
+    return -1;
+  return GST_CLOCK_DIFF (rt, earliest);
 }
 
 static GstFlowReturn
@@ -594,6 +665,24 @@ comp_aggregate (GstAggregator * agg, gboolean timeout)
     } else
       rc = sel;                                            /* GST_AGGREGATOR_FLOW_NEED_DATA: aggregate () runs again when the pads have data */
     goto done;
+  }
+  {
+    gdouble proportion;
+    const GstClockTimeDiff jitter = comp_qos_jitter (self, out_start_rt, &proportion);
+    if (jitter > 0) {
+      GstMessage *msg = gst_message_new_qos (GST_OBJECT_CAST (self), FALSE, out_start_rt, gst_segment_to_stream_time (seg, GST_FORMAT_TIME, out_start),
+          out_start, out_end - out_start);
+      self->qos_dropped++;
+      gst_message_set_qos_values (msg, jitter, proportion, 1000000);
+      gst_message_set_qos_stats (msg, GST_FORMAT_BUFFERS, self->qos_processed, self->qos_dropped);
+      gst_element_post_message (GST_ELEMENT_CAST (self), msg);
+      GST_DEBUG_OBJECT (self, "output frame %" GST_TIME_FORMAT " is late by %" GST_TIME_FORMAT ": not composited", GST_TIME_ARGS (out_start), GST_TIME_ARGS (jitter));
+      seg->position = out_end;
+      self->n_frames++;
+      rc = GST_FLOW_OK;
+      goto done;
+    }
+    self->qos_processed++;
   }
   for (i = 0; i < n; i++)                                  /* this composite holds its own reference (it may stay in flight: async-depth) */
     bufs[i] = refs[i].pad->cur ? gst_buffer_ref (refs[i].pad->cur) : NULL;
@@ -699,6 +788,15 @@ comp_src_event (GstAggregator * agg, GstEvent * event)
   gdouble px, py;
   GList *l, *pads = NULL;
   gboolean res = FALSE;
+  if (GST_EVENT_TYPE (event) == GST_EVENT_QOS) {
+    GstQOSType type;
+    gdouble proportion;
+    GstClockTimeDiff diff;
+    GstClockTime timestamp;
+    gst_event_parse_qos (event, &type, &proportion, &diff, &timestamp);
+    comp_update_qos (self, proportion, diff, timestamp);
+    return GST_AGGREGATOR_CLASS (gst_vfhip_compositor_parent_class)->src_event (agg, event);      /* ... and on to the sources */
+  }
   if (GST_EVENT_TYPE (event) != GST_EVENT_NAVIGATION || !(st = gst_event_get_structure (event)) ||
       !(kind = gst_structure_get_string (st, "event")) || !g_str_has_prefix (kind, "mouse-") ||
       !gst_structure_get_double (st, "pointer_x", &px) || !gst_structure_get_double (st, "pointer_y", &py) || !self->have_out_info)
@@ -751,6 +849,7 @@ comp_flush (GstAggregator * agg)
 {
   (void) comp_finish_pending (COMP (agg), FALSE);          /* a flushed frame is completed and dropped */
   comp_drop_current_buffers (COMP (agg));                  /* the time line restarts at the new segment */
+  comp_reset_qos (COMP (agg));
   return GST_FLOW_OK;
 }
 
@@ -762,6 +861,7 @@ comp_stop (GstAggregator * agg)
   if (self->renderer)
     vfhip_compositor_cleanup (self->renderer);
   comp_drop_current_buffers (self);
+  comp_reset_qos (self);
   self->have_out_info = FALSE;
   return TRUE;
 }
@@ -909,6 +1009,8 @@ gst_vfhip_compositor_init (GstVfHipCompositor * self)
   self->zero_size_is_unscaled = TRUE;
   self->device_id = GST_VFHIP_DEFAULT_DEVICE_ID;
   self->ts_offset = GST_CLOCK_TIME_NONE;
+  self->qos_proportion = 0.5;
+  self->qos_earliest = GST_CLOCK_TIME_NONE;
   gst_video_info_init (&self->out_info);
 }
 

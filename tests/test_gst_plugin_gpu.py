@@ -521,6 +521,35 @@ def test_compositor_drops_frames_of_a_faster_pad_and_repeats_after_eos(tmp_path)
     assert all(np.array_equal(fo[k][:, :160], fo[1][:, :160]) for k in range(1, 6)) and fo[5][:, :160].any()      # the ended pad's last frame stays
 
 
+def test_compositor_qos_skips_late_frames(tmp_path):
+    """GstVideoAggregator's QoS, which the reference inherits: a sink that reports lateness (sync + qos behind an element that takes 60 ms per 33 ms frame)
+    makes the compositor skip output frames that are already late — they are not composited, their time passes, a QoS message is posted — instead of
+    compositing every frame for a sink that throws it away.  Without the QOS events (qos=false) every frame is composited."""
+    pipe = (f"vfhipcompositor name=c background=black ! {caps('BGRA', 320, 240)},framerate=30/1 ! identity sleep-time=60000 ! fakesink sync=true qos={{q}} "
+            f"videotestsrc num-buffers=45 pattern=ball ! {caps('BGRA', 320, 240)},framerate=30/1 ! c.sink_0")
+    r = gst_env.launch(pipe.format(q="true"), timeout=180, debug="vfhipcompositor:5")
+    assert r.returncode == 0, r.stderr[-2000:]
+    late = [ln for ln in r.stderr.splitlines() if "not composited" in ln]
+    assert 3 <= len(late) < 45, (len(late), r.stderr[-1500:])
+    r = gst_env.launch(pipe.format(q="false"), timeout=180, debug="vfhipcompositor:5")
+    assert r.returncode == 0 and not [ln for ln in r.stderr.splitlines() if "not composited" in ln]
+
+
+def test_compositor_max_last_buffer_repeat_leaves_covered_frames_alone(tmp_path):
+    """max-last-buffer-repeat (GstVideoAggregatorPad's) caps how long a pad that is NOT at EOS shows a buffer past the buffer's END; a slower pad whose
+    buffers still cover the output frames is not touched by it, even at 0"""
+    o, o2 = tmp_path / "a.raw", tmp_path / "b.raw"
+    pipe = (f"vfhipcompositor name=c background=black sink_1::xpos=160 {{extra}} ! {caps('BGRA', 320, 120)},framerate=30/1 ! filesink location={{out}} "
+            f"videotestsrc num-buffers=6 pattern=ball ! {caps('BGRA', 160, 120)},framerate=30/1 ! c.sink_0 "
+            f"videotestsrc num-buffers=3 pattern=smpte ! {caps('BGRA', 160, 120)},framerate=15/1 ! c.sink_1")
+    r = gst_env.launch(pipe.format(extra="", out=o), timeout=120)
+    assert r.returncode == 0, r.stderr
+    r = gst_env.launch(pipe.format(extra="sink_1::max-last-buffer-repeat=0 sink_0::max-last-buffer-repeat=0", out=o2), timeout=120)
+    assert r.returncode == 0, r.stderr
+    a, b = np.fromfile(o, np.uint8), np.fromfile(o2, np.uint8)
+    assert a.size >= 6 * 320 * 120 * 4 and np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("element,chain", [("vfhipconvertscale", "vfhipconvertscale ! video/x-raw,format=BGRA,width=160,height=120"), ("vfhipvideofilter", "vfhipvideofilter brightness=0.1"),
                                            ("vfhipdeinterlace", "vfhipdeinterlace"), ("vfhiptransform", "vfhiptransform method=clockwise"), ("vfhipoverlay", "vfhipoverlay"),
                                            ("vfhipcompositor", "vfhipcompositor")])

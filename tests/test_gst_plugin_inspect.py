@@ -74,7 +74,8 @@ def test_compositor_api():
     assert "primary + 2" in t
     assert t.count("(string)BGRA, (string)RGBA, (string)NV12, (string)I420 }") == 4          # src and sink_%u, each in both memories
     src = open(gst_env.PLUGIN_DIR + "/gstvfhipcompositor.c").read()
-    for prop in ("xpos", "ypos", "width", "height", "alpha", "operator", "sizing-policy", "zorder"):
+    # (... and GstVideoAggregatorPad's own, which the reference's pads inherit)
+    for prop in ("xpos", "ypos", "width", "height", "alpha", "operator", "sizing-policy", "zorder", "repeat-after-eos", "max-last-buffer-repeat"):
         assert f'("{prop}"' in src
 
 
