@@ -1,10 +1,10 @@
 #!/bin/bash
 # tools/gpu_fuzz.sh <tag> <seconds> [first seed] [metal every n-th run, default 5] — a fuzz campaign on the GPU box: five workers (the box allows six GPU processes) take turns with
 # tools/fuzz_gst_exact.py (3000 cases a run, 4 of 5 runs) and tools/fuzz_metal.py (1000 cases), fresh seeds, until <seconds> have passed; every device
-# allocation poisoned, the oracle on 16 threads.  One line per run in gpurun_out/<tag>/summary.txt; mismatch records land in gpurun_out/fuzz_dumps/.
+# allocation poisoned, the oracle single-threaded (or $VFHIP_ORACLE_THREADS: on these small frames 16 threads halve the case rate).    One line per run in gpurun_out/<tag>/summary.txt; mismatch records land in gpurun_out/fuzz_dumps/.
 T=$1; SECS=$2; SEED=${3:-7000}; EVERY=${4:-5}
 OUT=gpurun_out/$T; mkdir -p $OUT
-export VFHIP_DEBUG_POISON=1 VFHIP_ORACLE_THREADS=16
+export VFHIP_DEBUG_POISON=1 VFHIP_ORACLE_THREADS=${VFHIP_ORACLE_THREADS:-1}
 END=$(( $(date +%s) + SECS ))
 worker () {
   local w=$1 s=$(( SEED + $1 * 1000 ))
